@@ -1,0 +1,341 @@
+#!/usr/bin/env python3
+"""bench.py -- Msamples/s of complex IQ through the FIR / decimator hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload fir256]
+
+N > 1 is launched by the driver as
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+(one rank per GPU, backend nccl == RCCL).
+
+A "step" = one pass of the hot path over one batch: every rank runs its operator once over
+its 2^LOG2N-sample chunk of a continuous synthetic IQ stream that is already resident in
+HBM.  With N > 1 the stream is cut block-cyclically over the ranks and each step begins with
+the ring-neighbour halo hand-off (the previous chunk's last H input samples -> this rank's
+filter history, RCCL send/recv over xGMI, qdsp_amd/sharding.py); there is no other
+communication.  Per-GPU work is fixed, so scaling is "weak".
+
+Workloads (BASELINE.json configs):
+    fir256            configs[1]: 256-tap complex FIR                      (default; the metric)
+    xlate_fir_decim8  configs[2]: fused NCO + 256-tap FIR + decimate-by-8
+    decim8            256-tap decimate-by-8 (no NCO)
+    xlate             NCO mixer alone
+    fir63             63-tap FIR (the reference BlackmanWindow design of configs[0])
+
+Rank 0 prints ONE JSON line (contract in the task statement) extended with
+  "roofline":     dominant kernel vs the HBM roofline: algorithmic bytes per launch / mean
+                  launch duration (HIP events on the launch stream, measured here)
+  "roofline_fp32": the same launch vs the FP32 vector peak (the direct-form 256-tap FIR is
+                  compute-bound: 1024 FLOP / 16 B per sample)
+  "cpu_baseline": the CPU oracle (VOLK-generic order) timed on this host's cores, N = 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
+FP32_PEAK_TFLOPS = 157.3   # FP32 vector == FP32 MFMA peak (same file)
+
+# algorithmic bytes / flops per INPUT sample
+WORKLOADS = {
+    "fir256": dict(ntaps=256, decim=1, rot=False, bytes=16.0, flops=1024.0),
+    "fir63": dict(ntaps=63, decim=1, rot=False, bytes=16.0, flops=252.0),
+    "decim8": dict(ntaps=256, decim=8, rot=False, bytes=9.0, flops=128.0),
+    "xlate_fir_decim8": dict(ntaps=256, decim=8, rot=True, bytes=9.0, flops=134.0),
+    "xlate": dict(ntaps=0, decim=1, rot=True, bytes=16.0, flops=6.0),
+}
+
+
+def lowpass_taps(ntaps: int, fc: float):
+    """Harness taps: Blackman-windowed sinc designed in FP64, unit DC gain.
+    The reference's own BlackmanWindow cannot produce an even tap count."""
+    import numpy as np
+
+    n = np.arange(ntaps, dtype=np.float64)
+    c = (ntaps - 1) / 2.0
+    h = 2 * fc * np.sinc(2 * fc * (n - c))
+    w = 0.42 - 0.5 * np.cos(2 * np.pi * n / (ntaps - 1)) + 0.08 * np.cos(4 * np.pi * n / (ntaps - 1))
+    h = h * w
+    return (h / h.sum()).astype(np.float32)
+
+
+def make_op(ops, name: str, device: int):
+    w = WORKLOADS[name]
+    if name == "xlate":
+        return ops.Xlator(phase_inc=ops.phase_delta(1.0, 0.1234), device=device, max_block=0)
+    taps = lowpass_taps(w["ntaps"], 1.0 / 16.0) if w["ntaps"] != 63 else None
+    if taps is None:
+        import numpy as np
+
+        # BlackmanWindow(cutoff=0.1 fs, transWidth=4 fs/63) of SURVEY 8d config 1, as designed by
+        # the C++ host mirror; for the bench any fixed 63 taps do: use the FP64 design.
+        taps = lowpass_taps(63, 0.1)
+    if w["rot"]:
+        return ops.Vfo(taps, 1, w["decim"], ops.phase_delta(1.0, 0.1234), device=device, max_block=0)
+    if w["decim"] > 1:
+        return ops.Resampler(taps, 1, w["decim"], device=device, max_block=0)
+    return ops.Fir(taps, device=device, max_block=0)
+
+
+def cpu_baseline(name: str, seconds: float):
+    """The CPU oracle (kind 'port': the repo's restatement of the reference algorithm with
+    VOLK-generic accumulation order) on this host's cores: every thread filters its own
+    chunk of the same synthetic stream (own history), as the reference would with one block
+    graph per core.  Bounded to roughly `seconds` of wall time."""
+    import numpy as np
+
+    import oracle as O
+
+    w = WORKLOADS[name]
+    taps = lowpass_taps(w["ntaps"] or 256, 1.0 / 16.0)
+
+    def make():
+        if name == "xlate":
+            return O.Xlator(1.0, 0.1234)
+        if w["rot"]:
+            xl, rs = O.Xlator(1.0, 0.1234), O.Resampler(taps, 1, w["decim"])
+
+            class _V:
+                def process(self, x):
+                    return rs.process(xl.process(x))
+            return _V()
+        if w["decim"] > 1:
+            return O.Resampler(taps, 1, w["decim"])
+        return O.Fir(taps)
+
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    probe_n = 1 << 18
+    x = O.synth_iq(0, probe_n, seed=1234)
+    op = make()
+    op.process(x[:4096])
+    t0 = time.perf_counter()
+    op.process(x)
+    r1 = probe_n / (time.perf_counter() - t0)            # samples/s, one thread
+    per_thread = int(min(max(r1 * seconds * 0.8, probe_n), 1 << 27))
+    blocks = max(1, per_thread // probe_n)
+    per_thread = blocks * probe_n
+
+    def worker(i, res):
+        o = make()
+        xi = O.synth_iq(i * per_thread, probe_n, seed=1234)
+        for _ in range(blocks):                          # blocks of 2^18, history carried
+            o.process(xi)
+        res[i] = True
+
+    res = [False] * cores
+    ths = [threading.Thread(target=worker, args=(i, res)) for i in range(cores)]
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    dt = time.perf_counter() - t0
+    assert all(res)
+    return {
+        "value": round(cores * per_thread / dt / 1e6, 3),
+        "unit": "Msamples/s",
+        "cores": cores,
+        "kind": "port",
+        "value_1core": round(r1 / 1e6, 3),
+        "sample": f"{cores} threads x {per_thread} samples ({blocks} blocks of {probe_n}) of the same synthetic IQ, "
+                  f"workload {name}, oracle/qdsp_oracle.c (VOLK-generic accumulation order, gcc -O3 target_clones), "
+                  f"{dt:.1f} s wall",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="fir256", choices=sorted(WORKLOADS))
+    ap.add_argument("--log2n", type=int, default=27, help="input samples per GPU per step = 2^log2n")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-iters", type=int, default=10)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from qdsp_amd import ops, sharding
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: there is no CPU fallback for the hot path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    w = WORKLOADS[args.workload]
+    n = 1 << args.log2n
+    op = make_op(ops, args.workload, local_rank)
+    has_hist = args.workload != "xlate"
+    H = op.history_len if has_hist else 0
+
+    # Block-cyclic cut of one continuous stream: step s, rank r owns samples
+    # [(s*world + r)*n, +n).  The synthetic block content repeats every step (same buffer),
+    # so the halo a rank needs is always its ring predecessor's current tail.
+    x = ops.synth_iq(n, first_sample=rank * n, seed=1234, device=local_rank)
+    nout = n // w["decim"]
+    out = torch.empty(nout, dtype=torch.complex64, device=dev)
+    tail = x[n - H:] if H else None
+    hist_views = {}
+
+    def hist_tensor():
+        p = op.history_dev_ptr()
+        if p not in hist_views:
+            hist_views[p] = op.history_dev_tensor()
+        return hist_views[p]
+
+    def step():
+        if world > 1 and H:
+            # ring halo: my tail -> next rank's history; previous rank's tail -> mine
+            reqs = dist.batch_isend_irecv([
+                dist.P2POp(dist.isend, tail, (rank + 1) % world),
+                dist.P2POp(dist.irecv, hist_tensor(), (rank - 1) % world),
+            ])
+            for r in reqs:
+                r.wait()
+        if args.workload == "xlate" and world > 1:
+            pass  # NCO phase needs no communication (advance() below keeps it on the stream)
+        op.process(x, out)
+
+    if args.workload in ("xlate", "xlate_fir_decim8") and world > 1:
+        op.advance(rank * n)  # phase of this rank's first sample; each step then advances by n
+
+    for _ in range(args.warmup):
+        step()
+        if args.workload in ("xlate", "xlate_fir_decim8") and world > 1:
+            op.advance((world - 1) * n)
+    torch.cuda.synchronize()
+
+    # Halo check (outside the timed region, no oracle): a fresh operator fed the predecessor's
+    # regenerated tail + my head must reproduce my head bit for bit.
+    if world > 1 and H and not w["rot"]:
+        step()
+        torch.cuda.synchronize()
+        m = 1 << 16
+        prev_tail = ops.synth_iq(H, first_sample=((rank - 1) % world) * n + n - H, seed=1234, device=local_rank)
+        chk = make_op(ops, args.workload, local_rank)
+        chk.set_history(prev_tail.cpu().numpy())
+        ref = chk.process(x[:m])
+        torch.cuda.synchronize()
+        if not torch.equal(ref, out[: ref.numel()]):
+            raise SystemExit(f"rank {rank}: halo exchange produced different outputs than the unsharded filter")
+        chk.close()
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        if args.workload in ("xlate", "xlate_fir_decim8") and world > 1:
+            op.advance((world - 1) * n)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * n / (dt / args.steps) / 1e6
+
+    # Dominant kernel, timed with HIP events on the stream it is launched on.
+    kms = op.time_dev(x, out, args.kernel_iters)
+    kinfo = op.last_kernel()
+    torch.cuda.synchronize()
+    achieved_gbs = w["bytes"] * n / (kms * 1e-3) / 1e9
+    achieved_tf = w["flops"] * n / (kms * 1e-3) / 1e12
+
+    if rank == 0:
+        line = {
+            "metric": "Msamples/s complex IQ through 256-tap FIR+decimate chain, 1/2/4/8 GPU",
+            "value": round(value, 1),
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": {
+                    "fir256": "256-tap complex FIR (real taps), synthetic IQ resident in HBM (BASELINE configs[1])",
+                    "fir63": "63-tap complex FIR, synthetic IQ (BASELINE configs[0] shape)",
+                    "decim8": "256-tap polyphase decimate-by-8, synthetic IQ",
+                    "xlate_fir_decim8": "fused NCO + 256-tap FIR + decimate-by-8 (BASELINE configs[2])",
+                    "xlate": "NCO frequency translator alone",
+                }[args.workload],
+                "name": args.workload,
+                "samples_per_gpu_per_step": n,
+                "ntaps": w["ntaps"],
+                "decim": w["decim"],
+                "halo_samples": H if world > 1 else 0,
+                "partition": "single stream" if world == 1 else f"block-cyclic time chunks over {world} ranks, ring halo over RCCL",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved_gbs, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "kernel": kinfo["name"],
+                "kernel_ms": round(kms, 4),
+                "algorithmic_bytes_per_sample": w["bytes"],
+                "launch": {"grid": kinfo["grid"], "block": kinfo["block"], "lds_bytes": kinfo["lds_bytes"]},
+            },
+            "roofline_fp32": {
+                "bound": "valu",
+                "achieved": round(achieved_tf, 2),
+                "peak": FP32_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(achieved_tf / FP32_PEAK_TFLOPS, 4),
+                "flops_per_sample": w["flops"],
+            },
+            "hbm_roofline_msps": round(HBM_PEAK_GBS * 1e9 / w["bytes"] / 1e6, 1),
+            "frac_of_hbm_roofline_msps": round(value / world / (HBM_PEAK_GBS * 1e9 / w["bytes"] / 1e6), 4),
+        }
+        tj = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tj):
+            try:
+                t = json.load(open(tj)).get(args.workload)
+                if t and t.get("samples") == n:
+                    line["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+                    line["roofline"]["traffic_source"] = t.get("source")
+            except Exception:
+                pass
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

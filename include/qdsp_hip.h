@@ -1,0 +1,218 @@
+/*
+ * qdsp_hip.h -- C ABI of libqdsp_hip.so: qdsp's FIR / polyphase-resampler / NCO-mixer
+ * hot path as hand-written HIP kernels for MI355X (gfx950).
+ *
+ * This is the drop-in boundary.  The reference (AlexandreRouma/qdsp) has no FFI of its
+ * own: its blocks call VOLK from inside `run()`.  Each entry point below replaces one of
+ * those call sites (cited per function, paths relative to the reference tree), and is
+ * what a HIP-backed `dsp::FIR<T>::run()` etc. binds to -- see INTEGRATION.md and the
+ * host-side mirror in qdsp_amd/host/dsp/.
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, opaque `void*` handles; no C++/torch types, no exceptions.
+ *   - complex samples are interleaved {re, im} float pairs (dsp::complex_t,
+ *     src/dsp/types.h:65-66); `count` is always in SAMPLES, not floats.
+ *   - return value: 0 (or a non-negative count where stated) on success, negative on
+ *     failure: -(hipError_t) for runtime errors, QDSP_HIP_E* below for argument errors.
+ *     qdsp_hip_error_string() decodes either.
+ *   - every handle is bound to one device and is NOT thread-safe; as in the reference,
+ *     `run()` owns it on the block's worker thread and setters are called with the block
+ *     stopped (src/dsp/block.h:108-120).
+ *   - `*_process`      : host pointers (the stream's readBuf / writeBuf).  Synchronous:
+ *                        on return the output is in host memory, so `out.swap()` may
+ *                        follow immediately (src/dsp/filter.h:69).
+ *   - `*_process_dev`  : device pointers + a hipStream_t (as void*).  Asynchronous on that
+ *                        stream; state (history, NCO phase) is advanced in stream order.
+ *                        in/out must not alias.  `stream` NULL = the handle's own stream.
+ *   - one `process*` call == one `run()` of the reference block: history carries over
+ *     exactly as the reference's memmove does, and the resampler's phase counter restarts
+ *     at 0 (src/dsp/resampling.h:114,121).
+ */
+#ifndef QDSP_HIP_H
+#define QDSP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QDSP_HIP_ABI_VERSION 1
+
+#define QDSP_HIP_EINVAL (-10001)  /* bad argument                                    */
+#define QDSP_HIP_ENOMEM (-10002)  /* host allocation failed                          */
+#define QDSP_HIP_ESIZE (-10003)   /* count exceeds the handle's max_block            */
+#define QDSP_HIP_ENODEV (-10004)  /* no usable gfx950 device / device index invalid  */
+
+/* ---- library ------------------------------------------------------------------------- */
+int qdsp_hip_abi_version(void);
+const char* qdsp_hip_error_string(int code);
+int qdsp_hip_device_count(int* count);
+/* Name / gcnArchName of a device into caller buffers (may be NULL). */
+int qdsp_hip_device_info(int device, char* name, int name_len, char* arch, int arch_len,
+                         int* compute_units);
+
+/* ---- memory helpers (for hosts that do not link the HIP runtime themselves) ----------- */
+/* Pinned host memory: replaces volk_malloc for stream buffers (src/dsp/stream.h:25-26) so
+ * readBuf/writeBuf are DMA-able without staging. */
+int qdsp_hip_host_alloc(void** p, size_t bytes);
+int qdsp_hip_host_free(void* p);
+/* Pin / unpin memory the caller already owns (e.g. an unmodified reference stream). */
+int qdsp_hip_host_register(void* p, size_t bytes);
+int qdsp_hip_host_unregister(void* p);
+int qdsp_hip_dev_alloc(int device, void** p, size_t bytes);
+int qdsp_hip_dev_free(int device, void* p);
+int qdsp_hip_memcpy_h2d(int device, void* d_dst, const void* h_src, size_t bytes);
+int qdsp_hip_memcpy_d2h(int device, void* h_dst, const void* d_src, size_t bytes);
+int qdsp_hip_device_sync(int device);
+
+/* ---- FIR<complex_t> : src/dsp/filter.h:51-74 ------------------------------------------ */
+/* Replaces the loop of volk_32fc_32f_dot_prod_32fc calls (filter.h:63-67) plus the
+ * memcpy-into-history (filter.h:55) and memmove (filter.h:71):
+ *     y[n] = sum_{k<ntaps} taps[k] * x[n - (ntaps-1) + k]
+ * History = the last ntaps-1 input samples, zero after create/reset (the reference leaves
+ * it uninitialised, filter.h:28).  max_block bounds `count` of the host-pointer path only
+ * (STREAM_BUFFER_SIZE, src/dsp/stream.h:7). */
+int qdsp_hip_fir_cf32_create(void** h, int device, const float* taps, int ntaps, int max_block);
+int qdsp_hip_fir_cf32_process(void* h, const float* in_iq, int count, float* out_iq);
+int qdsp_hip_fir_cf32_process_dev(void* h, const void* d_in, int64_t count, void* d_out,
+                                  void* hip_stream);
+/* FIR<T>::updateWindow (filter.h:43-49): new taps; history is kept (resized, newest
+ * samples preserved) as the reference keeps its buffer. */
+int qdsp_hip_fir_cf32_set_taps(void* h, const float* taps, int ntaps);
+int qdsp_hip_fir_cf32_reset(void* h);
+/* History access for the multi-GPU halo: `nsamples` = ntaps-1.
+ * get/set copy through host memory; history_dev exposes the device buffer that the NEXT
+ * process call will read, so an RCCL recv can land in it directly. */
+int qdsp_hip_fir_cf32_history_len(void* h);
+int qdsp_hip_fir_cf32_get_history(void* h, float* hist_iq);
+int qdsp_hip_fir_cf32_set_history(void* h, const float* hist_iq);
+int qdsp_hip_fir_cf32_history_dev(void* h, void** d_hist);
+void qdsp_hip_fir_cf32_destroy(void* h);
+
+/* ---- FIR<float> : src/dsp/filter.h:58-62 (volk_32f_x2_dot_prod_32f) -------------------- */
+int qdsp_hip_fir_f32_create(void** h, int device, const float* taps, int ntaps, int max_block);
+int qdsp_hip_fir_f32_process(void* h, const float* in, int count, float* out);
+int qdsp_hip_fir_f32_process_dev(void* h, const void* d_in, int64_t count, void* d_out,
+                                 void* hip_stream);
+int qdsp_hip_fir_f32_set_taps(void* h, const float* taps, int ntaps);
+int qdsp_hip_fir_f32_reset(void* h);
+int qdsp_hip_fir_f32_history_len(void* h);
+int qdsp_hip_fir_f32_get_history(void* h, float* hist);
+int qdsp_hip_fir_f32_set_history(void* h, const float* hist);
+int qdsp_hip_fir_f32_history_dev(void* h, void** d_hist);
+void qdsp_hip_fir_f32_destroy(void* h);
+
+/* ---- PolyphaseResampler<complex_t> : src/dsp/resampling.h:99-132 ----------------------- */
+/* Rational interp/decim resampler; a pure decimator when interp == 1.  `taps` is the
+ * prototype exactly as the window hands it over (already scaled by interp,
+ * resampling.h:34); the phase split of buildTapPhases (resampling.h:137-166) happens
+ * inside.  Replaces the volk_32fc_32f_dot_prod_32fc loop (resampling.h:121-125):
+ *     P = ceil(ntaps/interp);  outCount = count*interp/decim;
+ *     y[n] = sum_{t<P} phase[(n*decim) % interp][t] * x[(n*decim)/interp - P + t]
+ * History = last P input samples (zero after create/reset, resampling.h:39).
+ * process* return outCount (>= 0) or a negative error. */
+int qdsp_hip_decim_cf32_create(void** h, int device, const float* taps, int ntaps, int interp,
+                               int decim, int max_block);
+int qdsp_hip_decim_cf32_process(void* h, const float* in_iq, int count, float* out_iq);
+int64_t qdsp_hip_decim_cf32_process_dev(void* h, const void* d_in, int64_t count, void* d_out,
+                                        void* hip_stream);
+/* updateWindow / setInSampleRate / setOutSampleRate (resampling.h:53-93) all funnel here. */
+int qdsp_hip_decim_cf32_configure(void* h, const float* taps, int ntaps, int interp, int decim);
+int64_t qdsp_hip_decim_cf32_out_size(void* h, int64_t count); /* calcOutSize, :95-97 */
+int qdsp_hip_decim_cf32_reset(void* h);
+int qdsp_hip_decim_cf32_history_len(void* h); /* = taps per phase */
+int qdsp_hip_decim_cf32_get_history(void* h, float* hist_iq);
+int qdsp_hip_decim_cf32_set_history(void* h, const float* hist_iq);
+int qdsp_hip_decim_cf32_history_dev(void* h, void** d_hist);
+void qdsp_hip_decim_cf32_destroy(void* h);
+
+/* ---- PolyphaseResampler<float> : src/dsp/resampling.h:113-119 -------------------------- */
+int qdsp_hip_decim_f32_create(void** h, int device, const float* taps, int ntaps, int interp,
+                              int decim, int max_block);
+int qdsp_hip_decim_f32_process(void* h, const float* in, int count, float* out);
+int64_t qdsp_hip_decim_f32_process_dev(void* h, const void* d_in, int64_t count, void* d_out,
+                                       void* hip_stream);
+int qdsp_hip_decim_f32_configure(void* h, const float* taps, int ntaps, int interp, int decim);
+int64_t qdsp_hip_decim_f32_out_size(void* h, int64_t count);
+int qdsp_hip_decim_f32_reset(void* h);
+int qdsp_hip_decim_f32_history_len(void* h);
+int qdsp_hip_decim_f32_get_history(void* h, float* hist);
+int qdsp_hip_decim_f32_set_history(void* h, const float* hist);
+int qdsp_hip_decim_f32_history_dev(void* h, void** d_hist);
+void qdsp_hip_decim_f32_destroy(void* h);
+
+/* ---- FrequencyXlator<complex_t> : src/dsp/processing.h:55-70 --------------------------- */
+/* Replaces volk_32fc_s32fc_x2_rotator_32fc (processing.h:64): y[n] = x[n] * phase_n,
+ * phase_{n+1} = phase_n * phase_inc, phase_0 = (1,0) after create.  phase_inc is the
+ * float pair the reference computes in init/setFrequency (processing.h:20,48).
+ * The device NCO is not recursive: phase_n = phase_0 * exp(j*n*arg(phase_inc)) with a
+ * 64-bit fixed-point phase accumulator, so it has none of the float phasor's drift
+ * (DESIGN.md "NCO").  The carried phase is readable/writable as the reference's
+ * lv_32fc_t `phase`. */
+int qdsp_hip_xlate_cf32_create(void** h, int device, float phase_inc_re, float phase_inc_im,
+                               int max_block);
+int qdsp_hip_xlate_cf32_process(void* h, const float* in_iq, int count, float* out_iq);
+int qdsp_hip_xlate_cf32_process_dev(void* h, const void* d_in, int64_t count, void* d_out,
+                                    void* hip_stream);
+int qdsp_hip_xlate_cf32_set_phase_inc(void* h, float phase_inc_re, float phase_inc_im);
+int qdsp_hip_xlate_cf32_get_phase(void* h, float* phase_re, float* phase_im);
+int qdsp_hip_xlate_cf32_set_phase(void* h, float phase_re, float phase_im);
+/* Jump the NCO as if `nsamples` samples had been processed (multi-GPU chunk start,
+ * no communication needed for the phase). */
+int qdsp_hip_xlate_cf32_advance(void* h, int64_t nsamples);
+/* VOLK's rotator renormalises its float phasor only every 512 samples and at the end of a
+ * call, so what it multiplies by has magnitude |phase_inc|^(n mod 512) (n from the start of
+ * the call; |phase_inc| of the rounded float pair is 1 +- ~3e-8).  on = 1 (default)
+ * reproduces that deterministic gain so results sit within float rounding of the
+ * reference; on = 0 gives the ideal unit-magnitude NCO. */
+int qdsp_hip_xlate_cf32_set_volk_gain(void* h, int on);
+void qdsp_hip_xlate_cf32_destroy(void* h);
+
+/* ---- VFO : src/dsp/vfo.h:19-36 (FrequencyXlator -> PolyphaseResampler), fused ---------- */
+/* One kernel does what the reference runs as two blocks/threads with a stream hop between
+ * them: rotate while staging into LDS, then the polyphase dot products.  Semantics are
+ * those of xlate_cf32 followed by decim_cf32 (history holds ROTATED samples, exactly as
+ * the reference resampler's buffer does).  Returns outCount or a negative error. */
+int qdsp_hip_xlate_fir_decim_cf32_create(void** h, int device, const float* taps, int ntaps,
+                                         int interp, int decim, float phase_inc_re,
+                                         float phase_inc_im, int max_block);
+int qdsp_hip_xlate_fir_decim_cf32_process(void* h, const float* in_iq, int count, float* out_iq);
+int64_t qdsp_hip_xlate_fir_decim_cf32_process_dev(void* h, const void* d_in, int64_t count,
+                                                  void* d_out, void* hip_stream);
+int qdsp_hip_xlate_fir_decim_cf32_configure(void* h, const float* taps, int ntaps, int interp,
+                                            int decim);
+int qdsp_hip_xlate_fir_decim_cf32_set_phase_inc(void* h, float phase_inc_re, float phase_inc_im);
+int qdsp_hip_xlate_fir_decim_cf32_get_phase(void* h, float* phase_re, float* phase_im);
+int qdsp_hip_xlate_fir_decim_cf32_set_phase(void* h, float phase_re, float phase_im);
+int qdsp_hip_xlate_fir_decim_cf32_advance(void* h, int64_t nsamples);
+int qdsp_hip_xlate_fir_decim_cf32_set_volk_gain(void* h, int on);
+int64_t qdsp_hip_xlate_fir_decim_cf32_out_size(void* h, int64_t count);
+int qdsp_hip_xlate_fir_decim_cf32_reset(void* h);
+int qdsp_hip_xlate_fir_decim_cf32_history_len(void* h);
+int qdsp_hip_xlate_fir_decim_cf32_get_history(void* h, float* hist_iq);
+int qdsp_hip_xlate_fir_decim_cf32_set_history(void* h, const float* hist_iq);
+int qdsp_hip_xlate_fir_decim_cf32_history_dev(void* h, void** d_hist);
+void qdsp_hip_xlate_fir_decim_cf32_destroy(void* h);
+
+/* ---- synthetic IQ source (measurement harness) ------------------------------ */
+/* Counter-based uniform [-1,1) per float component, generated on device so benchmarks are
+ * HBM->HBM.  Bit-identical to oracle_synth_iq() for the same (first_sample, seed). */
+int qdsp_hip_synth_iq_dev(int device, void* d_out_iq, int64_t first_sample, int64_t count,
+                          uint32_t seed, void* hip_stream);
+
+/* ---- introspection for the measurement harness ----------------------------------------- */
+/* Name of the kernel the last process* call of this handle launched, and its launch
+ * geometry; used by bench.py to pick the right row out of a rocprofv3 kernel trace. */
+int qdsp_hip_last_kernel(void* h, char* name, int name_len, int* grid, int* block, int* lds_bytes);
+/* Time `iters` back-to-back process_dev launches of this handle on `hip_stream` with HIP
+ * events recorded on that same stream; returns mean milliseconds per launch in *ms.
+ * State advances as for `iters` ordinary calls. */
+int qdsp_hip_time_process_dev(void* h, const void* d_in, int64_t count, void* d_out,
+                              void* hip_stream, int iters, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QDSP_HIP_H */

@@ -1,0 +1,479 @@
+/*
+ * qdsp_oracle.c -- CPU restatement of qdsp's FIR / polyphase-resampler / NCO-mixer path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under qdsp_amd/ (the product) may include, link,
+ * dlopen or execute this file.  Only tests/, __graft_entry__.smoke() and the
+ * `cpu_baseline` leg of bench.py use it, and only as the checker / the reported CPU
+ * baseline -- never as the thing that is shipped or measured as the GPU result.
+ *
+ * PARITY STATUS: **parity unpinned** at the VOLK boundary.
+ *   - The reference (AlexandreRouma/qdsp, /root/reference) ships no tests, fixtures or
+ *     golden vectors for this path.
+ *   - Its arithmetic lives in VOLK (`target_link_libraries(dsptest PUBLIC volk)`,
+ *     CMakeLists.txt:24), an un-vendored and un-pinned system dependency that is absent
+ *     from this image, so the reference is unbuildable here and no stand-in was written.
+ *   - What this file restates for VOLK is the published *generic* (non-SIMD) kernel
+ *     behaviour of upstream VOLK 2.x:
+ *       volk_32fc_32f_dot_prod_32fc_generic : res_re += a.re*b ; res_im += a.im*b,
+ *           sequentially from tap 0, separate real/imag float accumulators.
+ *       volk_32f_x2_dot_prod_32f_generic    : res += a*b sequentially from 0.
+ *       volk_32fc_s32fc_x2_rotator_32fc_generic : out = in*phase; phase *= inc;
+ *           phase /= hypotf(phase) after every ROTATOR_RELOAD (512) samples, and once
+ *           more at the end of a call when the remainder loop ran at least once.
+ *   - The pins that do exist: the hand-checkable known-answer vectors of SURVEY.md
+ *     section 8a (tests/golden/kat.json), the reference's own call sites cited below,
+ *     and an FP64-accumulation variant of every routine (the mathematically intended
+ *     value) to bound how far any FP32 summation order can sit from it.
+ *
+ * Every routine cites the reference file:line it follows (paths relative to
+ * /root/reference).  All sample data is interleaved complex<float> {re, im}
+ * (src/dsp/types.h:65-66) unless the name says f32.
+ *
+ * Build: see oracle/Makefile (plain gcc, -ffp-contract=off so `acc += a*b` stays a
+ * separately rounded multiply and add, as a generic non-FMA VOLK build computes it).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define FL_M_PI 3.1415926535f /* src/dsp/types.h:4 */
+#define ROTATOR_RELOAD 512    /* VOLK generic rotator renormalisation cadence */
+
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(QDSP_ORACLE_NO_CLONES)
+/* Run-time dispatch of the *same* C loops to wider vectors.  The loops below vectorise
+ * ACROSS outputs, so every output still sees the taps in order 0..N-1 with one rounding
+ * per multiply and per add: bit-identical results on every clone. */
+#define ORACLE_HOT __attribute__((target_clones("avx512f", "avx2", "default")))
+#else
+#define ORACLE_HOT
+#endif
+
+enum { ORACLE_ACC_F32 = 0, ORACLE_ACC_FMA = 1, ORACLE_ACC_F64 = 2 };
+
+/* ------------------------------------------------------------------------------------ */
+/* dot products                                                                          */
+/* ------------------------------------------------------------------------------------ */
+
+/* Tile of outputs computed tap-major so the compiler can vectorise across outputs while
+ * each output keeps the generic sequential order (see ORACLE_HOT note). */
+#define OT 64
+
+/* y[i] = sum_k taps[k] * x[i + k], complex x / real taps, VOLK-generic order.
+ * x must hold n + ntaps - 1 complex samples.  step = distance (in samples) between the
+ * window starts of consecutive outputs (1 for FIR, decim for an L=1 resampler). */
+ORACLE_HOT static void dot_rows_cf32(const float* x, const float* taps, int ntaps, long n,
+                                     long step, float* y) {
+    for (long i0 = 0; i0 < n; i0 += OT) {
+        long m = n - i0 < OT ? n - i0 : OT;
+        float ar[OT], ai[OT];
+        for (long j = 0; j < m; j++) { ar[j] = 0.0f; ai[j] = 0.0f; }
+        for (int k = 0; k < ntaps; k++) {
+            const float t = taps[k];
+            const float* xp = x + 2 * (i0 * step + k);
+            for (long j = 0; j < m; j++) {
+                ar[j] += xp[2 * j * step] * t;
+                ai[j] += xp[2 * j * step + 1] * t;
+            }
+        }
+        for (long j = 0; j < m; j++) { y[2 * (i0 + j)] = ar[j]; y[2 * (i0 + j) + 1] = ai[j]; }
+    }
+}
+
+ORACLE_HOT static void dot_rows_f32(const float* x, const float* taps, int ntaps, long n,
+                                    long step, float* y) {
+    for (long i0 = 0; i0 < n; i0 += OT) {
+        long m = n - i0 < OT ? n - i0 : OT;
+        float a[OT];
+        for (long j = 0; j < m; j++) a[j] = 0.0f;
+        for (int k = 0; k < ntaps; k++) {
+            const float t = taps[k];
+            const float* xp = x + (i0 * step + k);
+            for (long j = 0; j < m; j++) a[j] += xp[j * step] * t;
+        }
+        for (long j = 0; j < m; j++) y[i0 + j] = a[j];
+    }
+}
+
+/* Single dot product with a selectable accumulator (used where the window start and the
+ * tap vector change per output, i.e. the general L/M resampler, and for the FMA / FP64
+ * variants). `ch` = 2 for complex, 1 for real. */
+static void dot_one(const float* x, const float* taps, int ntaps, int ch, int acc, float* y) {
+    if (acc == ORACLE_ACC_F64) {
+        double a0 = 0.0, a1 = 0.0;
+        for (int k = 0; k < ntaps; k++) {
+            a0 += (double)x[ch * k] * (double)taps[k];
+            if (ch == 2) a1 += (double)x[2 * k + 1] * (double)taps[k];
+        }
+        y[0] = (float)a0;
+        if (ch == 2) y[1] = (float)a1;
+    } else if (acc == ORACLE_ACC_FMA) {
+        float a0 = 0.0f, a1 = 0.0f;
+        for (int k = 0; k < ntaps; k++) {
+            a0 = fmaf(x[ch * k], taps[k], a0);
+            if (ch == 2) a1 = fmaf(x[2 * k + 1], taps[k], a1);
+        }
+        y[0] = a0;
+        if (ch == 2) y[1] = a1;
+    } else {
+        float a0 = 0.0f, a1 = 0.0f;
+        for (int k = 0; k < ntaps; k++) {
+            a0 += x[ch * k] * taps[k];
+            if (ch == 2) a1 += x[2 * k + 1] * taps[k];
+        }
+        y[0] = a0;
+        if (ch == 2) y[1] = a1;
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* FIR<T>::run  -- src/dsp/filter.h:51-74                                                */
+/* ------------------------------------------------------------------------------------ */
+/*
+ * One call == one block handed to run().
+ *   buffer = [ hist (ntaps samples) | in (count samples) ]            filter.h:29,55
+ *   out[i] = dot(&buffer[i+1], taps, ntaps)                            filter.h:64-66
+ *   hist'  = buffer[count .. count+ntaps)                              filter.h:71
+ * `hist` is ntaps samples (ch floats each), caller-owned, updated in place; the reference
+ * never zeroes it (filter.h:28) -- callers of the oracle start it at zero.
+ * Returns count.
+ */
+static long fir_block(const float* taps, int ntaps, float* hist, const float* in, long count,
+                      float* out, int ch, int acc) {
+    if (count < 0 || ntaps <= 0) return -1;
+    size_t tot = (size_t)(count + ntaps);
+    float* buffer = (float*)malloc(tot * ch * sizeof(float) + 16);
+    if (!buffer) return -2;
+    memcpy(buffer, hist, (size_t)ntaps * ch * sizeof(float));
+    memcpy(buffer + (size_t)ntaps * ch, in, (size_t)count * ch * sizeof(float));
+    if (acc == ORACLE_ACC_F32) {
+        if (ch == 2) dot_rows_cf32(buffer + 2, taps, ntaps, count, 1, out);
+        else dot_rows_f32(buffer + 1, taps, ntaps, count, 1, out);
+    } else {
+        for (long i = 0; i < count; i++)
+            dot_one(buffer + (size_t)(i + 1) * ch, taps, ntaps, ch, acc, out + (size_t)i * ch);
+    }
+    memcpy(hist, buffer + (size_t)count * ch, (size_t)ntaps * ch * sizeof(float));
+    free(buffer);
+    return count;
+}
+
+long oracle_fir_cf32(const float* taps, int ntaps, float* hist, const float* in, long count,
+                     float* out, int acc) {
+    return fir_block(taps, ntaps, hist, in, count, out, 2, acc);
+}
+
+long oracle_fir_f32(const float* taps, int ntaps, float* hist, const float* in, long count,
+                    float* out, int acc) {
+    return fir_block(taps, ntaps, hist, in, count, out, 1, acc);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* PolyphaseResampler<T>  -- src/dsp/resampling.h                                        */
+/* ------------------------------------------------------------------------------------ */
+
+static int gcd_int(int a, int b) {
+    /* std::gcd on the int-cast rates, resampling.h:28 */
+    if (a < 0) a = -a;
+    if (b < 0) b = -b;
+    while (b) { int t = a % b; a = b; b = t; }
+    return a;
+}
+
+/* resampling.h:28-30 : interp = outSR / gcd, decim = inSR / gcd.  The reference divides
+ * the FLOAT rate by the int gcd and stores into an int. */
+void oracle_resamp_ratio(float inSampleRate, float outSampleRate, int* interp, int* decim) {
+    int g = gcd_int((int)inSampleRate, (int)outSampleRate);
+    *interp = (int)(outSampleRate / g);
+    *decim = (int)(inSampleRate / g);
+}
+
+/* resampling.h:145 : tapsPerPhase = ceil(tapCount / interp) */
+int oracle_resamp_taps_per_phase(int ntaps, int interp) { return (ntaps + interp - 1) / interp; }
+
+/* resampling.h:95-97 */
+long oracle_resamp_out_size(long in, int interp, int decim) { return (in * interp) / decim; }
+
+/* buildTapPhases, resampling.h:137-166.  phases_out is interp rows of tapsPerPhase floats:
+ * phases[(interp-1) - phase][tap] = taps[currentTap++] walking tap-major, phase-minor,
+ * zero once the prototype runs out. */
+void oracle_resamp_build_phases(const float* taps, int ntaps, int interp, float* phases_out) {
+    int tpp = oracle_resamp_taps_per_phase(ntaps, interp);
+    int cur = 0;
+    for (int tap = 0; tap < tpp; tap++) {
+        for (int phase = 0; phase < interp; phase++) {
+            float v = (cur < ntaps) ? taps[cur++] : 0.0f;
+            phases_out[(size_t)((interp - 1) - phase) * tpp + tap] = v;
+        }
+    }
+}
+
+/*
+ * PolyphaseResampler<T>::run, resampling.h:99-132.  One call == one block.
+ *   buffer = [ hist (tapsPerPhase samples) | in (count samples) ]      resampling.h:107
+ *   outCount = count*interp/decim                                       resampling.h:105
+ *   for (i = 0; outIndex < outCount; i += decim)                        resampling.h:121
+ *       out[outIndex++] = dot(&buffer[i / interp], tapPhases[i % interp], tapsPerPhase)
+ *   hist' = buffer[count .. count + tapsPerPhase)                       resampling.h:129
+ * `i` restarts at 0 on every call.  `hist` starts zeroed (resampling.h:39).
+ * `taps` is the prototype (already scaled by `interp` by the window, resampling.h:34).
+ * Returns outCount.
+ */
+static long resamp_block(const float* taps, int ntaps, int interp, int decim, float* hist,
+                         const float* in, long count, float* out, int ch, int acc) {
+    if (count < 0 || ntaps <= 0 || interp <= 0 || decim <= 0) return -1;
+    int tpp = oracle_resamp_taps_per_phase(ntaps, interp);
+    float* phases = (float*)malloc((size_t)interp * tpp * sizeof(float));
+    float* buffer = (float*)malloc((size_t)(count + tpp) * ch * sizeof(float) + 16);
+    if (!phases || !buffer) { free(phases); free(buffer); return -2; }
+    oracle_resamp_build_phases(taps, ntaps, interp, phases);
+    memcpy(buffer, hist, (size_t)tpp * ch * sizeof(float));
+    memcpy(buffer + (size_t)tpp * ch, in, (size_t)count * ch * sizeof(float));
+    long outCount = oracle_resamp_out_size(count, interp, decim);
+    if (interp == 1 && acc == ORACLE_ACC_F32) {
+        if (ch == 2) dot_rows_cf32(buffer, phases, tpp, outCount, decim, out);
+        else dot_rows_f32(buffer, phases, tpp, outCount, decim, out);
+    } else {
+        long i = 0;
+        for (long o = 0; o < outCount; o++, i += decim) {
+            int phase = (int)(i % interp);
+            dot_one(buffer + (size_t)(i / interp) * ch, phases + (size_t)phase * tpp, tpp, ch, acc,
+                    out + (size_t)o * ch);
+        }
+    }
+    memcpy(hist, buffer + (size_t)count * ch, (size_t)tpp * ch * sizeof(float));
+    free(buffer);
+    free(phases);
+    return outCount;
+}
+
+long oracle_resamp_cf32(const float* taps, int ntaps, int interp, int decim, float* hist,
+                        const float* in, long count, float* out, int acc) {
+    return resamp_block(taps, ntaps, interp, decim, hist, in, count, out, 2, acc);
+}
+
+long oracle_resamp_f32(const float* taps, int ntaps, int interp, int decim, float* hist,
+                       const float* in, long count, float* out, int acc) {
+    return resamp_block(taps, ntaps, interp, decim, hist, in, count, out, 1, acc);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* FrequencyXlator<complex_t>  -- src/dsp/processing.h:16-24,45-49,55-70                 */
+/* ------------------------------------------------------------------------------------ */
+
+/* processing.h:20,48 : phaseDelta = (cos(theta), sin(theta)), theta evaluated in float
+ * with FL_M_PI (std::cos/std::sin on a float argument are the float overloads). */
+void oracle_xlator_phase_delta(float sampleRate, float freq, float* delta_re_im) {
+    float theta = (freq / sampleRate) * 2.0f * FL_M_PI;
+    delta_re_im[0] = cosf(theta);
+    delta_re_im[1] = sinf(theta);
+}
+
+/* volk_32fc_s32fc_x2_rotator_32fc (generic), called from processing.h:64 and
+ * source.h:56.  phase persists across calls (processing.h:19: starts at (1,0)). */
+void oracle_rotator_cf32(const float* in, float* out, const float* inc, float* phase,
+                         long count) {
+    float pr = phase[0], pi = phase[1];
+    const float dr = inc[0], di = inc[1];
+    long i = 0, full = count / ROTATOR_RELOAD, rem = count % ROTATOR_RELOAD;
+    for (long b = 0; b < full; b++) {
+        for (int j = 0; j < ROTATOR_RELOAD; j++, i++) {
+            float xr = in[2 * i], xi = in[2 * i + 1];
+            out[2 * i] = xr * pr - xi * pi;
+            out[2 * i + 1] = xr * pi + xi * pr;
+            float nr = pr * dr - pi * di, ni = pr * di + pi * dr;
+            pr = nr; pi = ni;
+        }
+        float mag = hypotf(pr, pi);
+        pr /= mag; pi /= mag;
+    }
+    for (long j = 0; j < rem; j++, i++) {
+        float xr = in[2 * i], xi = in[2 * i + 1];
+        out[2 * i] = xr * pr - xi * pi;
+        out[2 * i + 1] = xr * pi + xi * pr;
+        float nr = pr * dr - pi * di, ni = pr * di + pi * dr;
+        pr = nr; pi = ni;
+    }
+    if (rem) {
+        float mag = hypotf(pr, pi);
+        pr /= mag; pi /= mag;
+    }
+    phase[0] = pr; phase[1] = pi;
+}
+
+/* The NCO with all phase arithmetic in double: out[n] = in[n] * g_n * exp(j*(phi0 + n*arg(inc))).
+ * `turns` (phase / 2pi, in [0,1)) persists across calls.
+ *   volk_gain = 0 : g_n = 1, the mathematically intended mixer -- the yardstick for
+ *                   SURVEY H2 (shows the drift of the recursive float phasor above).
+ *   volk_gain = 1 : g_n = |inc|^(n mod ROTATOR_RELOAD), n counted from the start of the
+ *                   call: the deterministic part of what the generic rotator does to the
+ *                   MAGNITUDE (|inc| of the rounded float pair is not exactly 1, and the
+ *                   phasor is only renormalised every 512 samples and at the end of a
+ *                   call).  What is left between this and oracle_rotator_cf32 is float
+ *                   rounding noise of the recursion. */
+void oracle_rotator_cf32_f64(const float* in, float* out, const float* inc, double* turns,
+                             long count, int volk_gain) {
+    const double two_pi = 6.283185307179586476925286766559;
+    double dt = atan2((double)inc[1], (double)inc[0]) / two_pi;
+    double lnm = log(hypot((double)inc[0], (double)inc[1]));
+    double t0 = *turns;
+    for (long i = 0; i < count; i++) {
+        double t = t0 + (double)i * dt;
+        t -= floor(t);
+        double g = volk_gain ? exp(lnm * (double)(i % ROTATOR_RELOAD)) : 1.0;
+        double c = g * cos(two_pi * t), s = g * sin(two_pi * t);
+        double xr = in[2 * i], xi = in[2 * i + 1];
+        out[2 * i] = (float)(xr * c - xi * s);
+        out[2 * i + 1] = (float)(xr * s + xi * c);
+    }
+    double t = t0 + (double)count * dt;
+    *turns = t - floor(t);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Tap designers  -- src/dsp/window.h                                                    */
+/* ------------------------------------------------------------------------------------ */
+
+/* BlackmanWindow::getTapCount, window.h:36-50 (identical in BlackmanBandpassWindow,
+ * window.h:105-119). */
+int oracle_blackman_tap_count(float cutoff, float transWidth, float sampleRate) {
+    float fc = cutoff / sampleRate;
+    if (fc > 1.0f) fc = 1.0f;
+    (void)fc;
+    int M = (int)(4.0f / (transWidth / sampleRate));
+    if (M < 4) M = 4;
+    if (M % 2 == 0) M++;
+    return M;
+}
+
+/* BlackmanWindow::createTaps, window.h:52-70.  Reproduced verbatim in float, including
+ * the index-free "window" factor: do not fix. */
+void oracle_blackman_taps(float cutoff, float sampleRate, float* taps, int tapCount,
+                          float factor) {
+    float fc = cutoff / sampleRate;
+    if (fc > 1.0f) fc = 1.0f;
+    float tc = (float)tapCount;
+    float sum = 0.0f;
+    for (int i = 0; i < tapCount; i++) {
+        float d = (float)i - (tc / 2);
+        float val = (sinf(2.0f * FL_M_PI * fc * d) / d) *
+                    (0.42f - (0.5f * cosf(2.0f * FL_M_PI / tc)) + (0.8f * cosf(4.0f * FL_M_PI / tc)));
+        taps[i] = val;
+        sum += val;
+    }
+    for (int i = 0; i < tapCount; i++) {
+        taps[i] *= factor;
+        taps[i] /= sum;
+    }
+}
+
+/* BlackmanBandpassWindow::createTaps, window.h:121-140. */
+void oracle_blackman_bandpass_taps(float cutoff, float offset, float sampleRate, float* taps,
+                                   int tapCount, float factor) {
+    float fc = cutoff / sampleRate;
+    if (fc > 1.0f) fc = 1.0f;
+    float tc = (float)tapCount;
+    float sum = 0.0f;
+    for (int i = 0; i < tapCount; i++) {
+        float d = (float)i - (tc / 2);
+        float val = (sinf(2.0f * FL_M_PI * fc * d) / d) *
+                    (0.42f - (0.5f * cosf(2.0f * FL_M_PI / tc)) + (0.8f * cosf(4.0f * FL_M_PI / tc)));
+        taps[i] = val;
+        sum += val;
+    }
+    for (int i = 0; i < tapCount; i++) {
+        taps[i] *= cosf(2.0f * (offset / sampleRate) * FL_M_PI * (float)i);
+        taps[i] *= factor;
+        taps[i] /= sum;
+    }
+}
+
+/* RRCTaps::createTaps, window.h:181-225 (double arithmetic, float FL_M_PI, float rate
+ * ratio).  tapCount must be odd: the reference does `tapCount |= 1` and would write one
+ * past an even-sized array; the oracle refuses even counts (returns -1). */
+int oracle_rrc_taps(int tapCount, float sampleRate, float baudRate, float alpha, float* taps) {
+    if ((tapCount & 1) == 0) return -1;
+    double spb = sampleRate / baudRate;
+    double scale = 0;
+    for (int i = 0; i < tapCount; i++) {
+        double x1, x2, x3, num, den;
+        double xindx = i - tapCount / 2;
+        x1 = FL_M_PI * xindx / spb;
+        x2 = 4 * alpha * xindx / spb;
+        x3 = x2 * x2 - 1;
+        if (fabs(x3) >= 0.000001) {
+            if (i != tapCount / 2)
+                num = cos((1 + alpha) * x1) + sin((1 - alpha) * x1) / (4 * alpha * xindx / spb);
+            else
+                num = cos((1 + alpha) * x1) + (1 - alpha) * FL_M_PI / (4 * alpha);
+            den = x3 * FL_M_PI;
+        } else {
+            if (alpha == 1) {
+                taps[i] = -1;
+                scale += taps[i];
+                continue;
+            }
+            x3 = (1 - alpha) * x1;
+            x2 = (1 + alpha) * x1;
+            num = (sin(x2) * (1 + alpha) * FL_M_PI -
+                   cos(x3) * ((1 - alpha) * FL_M_PI * spb) / (4 * alpha * xindx) +
+                   sin(x3) * spb * spb / (4 * alpha * xindx * xindx));
+            den = -32 * FL_M_PI * alpha * alpha * xindx / spb;
+        }
+        taps[i] = (float)(4 * alpha * num / den);
+        scale += taps[i];
+    }
+    for (int i = 0; i < tapCount; i++) taps[i] = (float)(taps[i] / scale);
+    return tapCount;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* VFO  -- src/dsp/vfo.h:19-36 : xlator(-offset) -> resampler(BlackmanWindow)            */
+/* ------------------------------------------------------------------------------------ */
+/* Derives the VFO's configuration exactly as VFO::init does.  Outputs: interp, decim,
+ * tap count, and (if taps != NULL, capacity max_taps) the resampler prototype taps.
+ *   realCutoff = min(bw, min(inSR, outSR)) / 2                          vfo.h:26
+ *   win.init(realCutoff, realCutoff, inSR); resamp.init(...)            vfo.h:29-30
+ *   win.setSampleRate(inSR * interp); resamp.updateWindow(&win)         vfo.h:32-33
+ * so the taps that run are designed at sampleRate = inSR*interp with gain `interp`
+ * (resampling.h:88-90).  Returns the tap count, or -1 if it exceeds max_taps. */
+int oracle_vfo_design(float inSampleRate, float outSampleRate, float bandWidth, int* interp,
+                      int* decim, float* taps, int max_taps) {
+    float m = inSampleRate < outSampleRate ? inSampleRate : outSampleRate;
+    float realCutoff = (bandWidth < m ? bandWidth : m) / 2.0f;
+    oracle_resamp_ratio(inSampleRate, outSampleRate, interp, decim);
+    float designRate = inSampleRate * (float)(*interp);
+    int n = oracle_blackman_tap_count(realCutoff, realCutoff, designRate);
+    if (taps) {
+        if (n > max_taps) return -1;
+        oracle_blackman_taps(realCutoff, designRate, taps, n, (float)(*interp));
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Synthetic IQ (shared definition with the device generator in qdsp_amd/csrc)           */
+/* ------------------------------------------------------------------------------------ */
+/* Counter-based uniform [-1,1) per float component: value index c (= 2*sample + {0,1}),
+ * 32-bit finaliser of (c ^ seed-derived key).  Not part of the reference; it is the
+ * harness-defined synthetic input of SURVEY section 8d, restated here so host and device
+ * inputs are bit-identical. */
+static inline uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU;
+    x ^= x >> 15; x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+
+void oracle_synth_iq(float* out, long first_sample, long count, uint32_t seed) {
+    uint32_t key = mix32(seed * 0x9e3779b9U + 0x85ebca6bU);
+    for (long i = 0; i < 2 * count; i++) {
+        uint64_t c = (uint64_t)(2 * first_sample + i);
+        uint32_t h = mix32((uint32_t)c ^ key);
+        h = mix32(h + (uint32_t)(c >> 32) * 0x9e3779b9U);
+        /* 24 random bits -> [-1, 1) exactly representable in float */
+        out[i] = (float)((int32_t)(h >> 8) - (1 << 23)) * (1.0f / (float)(1 << 23));
+    }
+}
+
+int oracle_abi_version(void) { return 1; }

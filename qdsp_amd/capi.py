@@ -1,0 +1,119 @@
+"""ctypes binding of libqdsp_hip.so (include/qdsp_hip.h).
+
+This is plumbing for the tests and the measurement harness: every call goes straight
+through the C ABI that a C++ block's run() uses.  There is no fallback of any kind: if the
+shared library is missing or a call fails, a QdspHipError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libqdsp_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "qdsp_hip.h")
+
+
+class QdspHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def declared_symbols() -> list[str]:
+    """Every function name include/qdsp_hip.h declares (used by the symbol-export test)."""
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(qdsp_hip_[a-z0-9_]+)\s*\(", text)))
+
+
+def load():
+    """dlopen libqdsp_hip.so.  torch is imported first so that the process holds exactly one
+    HIP runtime (torch bundles a libamdhip64 with the same SONAME as /opt/rocm's)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise QdspHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C qdsp_amd/csrc` (there is no CPU fallback)"
+        )
+    try:
+        import torch  # noqa: F401  (runtime unification only)
+    except Exception:  # pragma: no cover - torch is optional for pure C users
+        pass
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp, fp, i32, i64 = C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int64
+    pvp = C.POINTER(C.c_void_p)
+
+    def sig(name, res, *args):
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = list(args)
+
+    sig("qdsp_hip_abi_version", i32)
+    sig("qdsp_hip_error_string", C.c_char_p, i32)
+    sig("qdsp_hip_device_count", i32, C.POINTER(i32))
+    sig("qdsp_hip_device_info", i32, i32, C.c_char_p, i32, C.c_char_p, i32, C.POINTER(i32))
+    sig("qdsp_hip_host_alloc", i32, pvp, C.c_size_t)
+    sig("qdsp_hip_host_free", i32, vp)
+    sig("qdsp_hip_host_register", i32, vp, C.c_size_t)
+    sig("qdsp_hip_host_unregister", i32, vp)
+    sig("qdsp_hip_dev_alloc", i32, i32, pvp, C.c_size_t)
+    sig("qdsp_hip_dev_free", i32, i32, vp)
+    sig("qdsp_hip_memcpy_h2d", i32, i32, vp, vp, C.c_size_t)
+    sig("qdsp_hip_memcpy_d2h", i32, i32, vp, vp, C.c_size_t)
+    sig("qdsp_hip_device_sync", i32, i32)
+
+    for p in ("qdsp_hip_fir_cf32", "qdsp_hip_fir_f32"):
+        sig(p + "_create", i32, pvp, i32, fp, i32, i32)
+        sig(p + "_process", i32, vp, vp, i32, vp)
+        sig(p + "_process_dev", i32, vp, vp, i64, vp, vp)
+        sig(p + "_set_taps", i32, vp, fp, i32)
+    for p in ("qdsp_hip_decim_cf32", "qdsp_hip_decim_f32"):
+        sig(p + "_create", i32, pvp, i32, fp, i32, i32, i32, i32)
+        sig(p + "_process", i32, vp, vp, i32, vp)
+        sig(p + "_process_dev", i64, vp, vp, i64, vp, vp)
+        sig(p + "_configure", i32, vp, fp, i32, i32, i32)
+        sig(p + "_out_size", i64, vp, i64)
+    sig("qdsp_hip_xlate_cf32_create", i32, pvp, i32, C.c_float, C.c_float, i32)
+    sig("qdsp_hip_xlate_cf32_process", i32, vp, vp, i32, vp)
+    sig("qdsp_hip_xlate_cf32_process_dev", i32, vp, vp, i64, vp, vp)
+    sig("qdsp_hip_xlate_cf32_destroy", None, vp)
+    p = "qdsp_hip_xlate_fir_decim_cf32"
+    sig(p + "_create", i32, pvp, i32, fp, i32, i32, i32, C.c_float, C.c_float, i32)
+    sig(p + "_process", i32, vp, vp, i32, vp)
+    sig(p + "_process_dev", i64, vp, vp, i64, vp, vp)
+    sig(p + "_configure", i32, vp, fp, i32, i32, i32)
+    sig(p + "_out_size", i64, vp, i64)
+    for p in ("qdsp_hip_xlate_cf32", "qdsp_hip_xlate_fir_decim_cf32"):
+        sig(p + "_set_phase_inc", i32, vp, C.c_float, C.c_float)
+        sig(p + "_get_phase", i32, vp, fp, fp)
+        sig(p + "_set_phase", i32, vp, C.c_float, C.c_float)
+        sig(p + "_advance", i32, vp, i64)
+        sig(p + "_set_volk_gain", i32, vp, i32)
+    for p in ("qdsp_hip_fir_cf32", "qdsp_hip_fir_f32", "qdsp_hip_decim_cf32", "qdsp_hip_decim_f32",
+              "qdsp_hip_xlate_fir_decim_cf32"):
+        sig(p + "_reset", i32, vp)
+        sig(p + "_history_len", i32, vp)
+        sig(p + "_get_history", i32, vp, vp)
+        sig(p + "_set_history", i32, vp, vp)
+        sig(p + "_history_dev", i32, vp, pvp)
+        sig(p + "_destroy", None, vp)
+    sig("qdsp_hip_synth_iq_dev", i32, i32, vp, i64, i64, C.c_uint32, vp)
+    sig("qdsp_hip_last_kernel", i32, vp, C.c_char_p, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32))
+    sig("qdsp_hip_time_process_dev", i32, vp, vp, i64, vp, vp, i32, fp)
+    if L.qdsp_hip_abi_version() != 1:
+        raise QdspHipError("libqdsp_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str = "qdsp_hip") -> int:
+    if rc < 0:
+        msg = load().qdsp_hip_error_string(int(rc)).decode()
+        raise QdspHipError(f"{what} failed: {msg} ({rc})")
+    return rc

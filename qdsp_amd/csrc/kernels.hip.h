@@ -1,0 +1,350 @@
+// kernels.hip.h -- device code of libqdsp_hip.so (gfx950 / CDNA4 only).
+//
+// Three kernels carry the whole path (DESIGN.md "Kernels"):
+//   fir_core_kernel     direct-form FIR / integer decimator (interp == 1), optional fused
+//                       NCO rotation while staging.  LDS-staged sliding window, taps from
+//                       SGPRs, R register-blocked outputs per lane.
+//   resamp_any_kernel   any interp/decim (the reference's general polyphase loop).
+//   xlate_kernel        stand-alone NCO mixer (elementwise, HBM-bound).
+// plus synth_iq_kernel (measurement input) and small helpers.
+//
+// Reference semantics each kernel reproduces are cited at the kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace qk {
+
+template <int CH> struct Smp;
+template <> struct Smp<1> {
+    using T = float;
+    static __device__ __forceinline__ T zero() { return 0.0f; }
+};
+template <> struct Smp<2> {
+    using T = float2;
+    static __device__ __forceinline__ T zero() { return make_float2(0.0f, 0.0f); }
+};
+
+__device__ __forceinline__ void mac(float& acc, float h, float x) { acc = fmaf(h, x, acc); }
+__device__ __forceinline__ void mac(float2& acc, float h, float2 x) {
+    acc.x = fmaf(h, x.x, acc.x);
+    acc.y = fmaf(h, x.y, acc.y);
+}
+
+// ---- NCO ------------------------------------------------------------------------------
+// Phase is a 64-bit fixed-point fraction of a turn (2^64 == one full turn), so
+// phase0 + n*dphase wraps exactly and never drifts; only the final sincos rounds.
+__device__ __forceinline__ double2 phasor_fx(unsigned long long ph) {
+    const double t = (double)(ph >> 11) * (1.0 / 9007199254740992.0);  // [0,1) turns
+    double s, c;
+    sincospi(2.0 * t, &s, &c);
+    return make_double2(c, s);
+}
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+    return make_double2(fma(a.x, b.x, -a.y * b.y), fma(a.x, b.y, a.y * b.x));
+}
+// x * phase, FrequencyXlator semantics (src/dsp/processing.h:64): (xr + j xi)(pr + j pi).
+// `g` = index of the sample within this call, gm1 = |phase_inc| - 1: VOLK's rotator only
+// renormalises its recursive phasor every 512 samples (and at the end of a call), so the
+// magnitude of what it multiplies by is |phase_inc|^(g mod 512); to first order that is
+// 1 + (g mod 512)*gm1 (gm1 ~ 3e-8).  gm1 = 0 turns the emulation off (ideal NCO).
+__device__ __forceinline__ float2 rotate(float2 x, double2 p, long long g, float gm1) {
+    const float gain = fmaf((float)(int)(g & 511), gm1, 1.0f);
+    const float pr = (float)p.x * gain, pi = (float)p.y * gain;
+    return make_float2(fmaf(x.x, pr, -x.y * pi), fmaf(x.x, pi, x.y * pr));
+}
+__device__ __forceinline__ float rotate(float x, double2, long long, float) { return x; }  // CH==1: unused
+
+// ---- direct-form core -----------------------------------------------------------------
+struct CoreArgs {
+    const void* in;       // count samples
+    void* out;            // nout samples
+    const void* hist;     // H samples: the H inputs preceding in[0]
+    void* hist_next;      // H samples: written by the extra block, read by the next call
+    const float* taps;    // branch-major: tp[m*Q + q] = h[q*M + m], zero padded
+    long long count;      // input samples of this call
+    long long nout;       // outputs of this call
+    int H;                // history length == delay D of the window start
+    int M;                // decimation
+    int Q;                // taps per branch = ceil(K / M)
+    int nblocks;          // compute blocks; block index nblocks updates the history
+    int sb;               // LDS branch stride (elements)
+    unsigned long long phase0;  // NCO phase of in[0]            (ROT only)
+    unsigned long long dphase;  // NCO phase increment per sample (ROT only)
+    double2 rot_nt;             // exp(j*2pi*NT*dphase)           (ROT only)
+    float gm1;                  // |phase_inc| - 1, 0 = ideal NCO  (ROT only)
+};
+
+template <int R> __device__ __forceinline__ int slot(int v) {
+    // Lane stride of the window reads is R elements; an even R gets one pad element per R
+    // so 32 consecutive lanes fall on distinct banks of ds_read_b64 / ds_read_b32.
+    return (R % 2 == 0) ? v + v / R : v;
+}
+
+// out[n] = sum_{k < M*Q} h[k] * s[n*M + k - H],  s = hist ++ in      (one tile per block)
+//   FIR<T>::run              src/dsp/filter.h:63-67      (M = 1, H = ntaps-1)
+//   PolyphaseResampler::run  src/dsp/resampling.h:121-125 with interp == 1 (H = P)
+//   + FrequencyXlator::run   src/dsp/processing.h:64 applied to `in` while staging (ROT)
+// Written as M interleaved branch filters (k = q*M + m) so every branch is a unit-stride
+// sliding window: lane t keeps R accumulators for outputs tR..tR+R-1 and a rotating window
+// of R samples; each tap costs one LDS read and R (complex: 2R) FMAs with the tap in an SGPR.
+template <int CH, int R, int NT, bool ROT>
+__global__ __launch_bounds__(NT) void fir_core_kernel(const CoreArgs a) {
+    using T = typename Smp<CH>::T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* lds = reinterpret_cast<T*>(smem_raw);
+    const int t = threadIdx.x;
+    const T* __restrict__ in = static_cast<const T*>(a.in);
+    const T* __restrict__ hist = static_cast<const T*>(a.hist);
+    const int H = a.H, M = a.M, Q = a.Q;
+
+    if ((int)blockIdx.x == a.nblocks) {
+        // History hand-over (filter.h:71 / resampling.h:129): the last H samples of
+        // hist ++ in, into the *other* buffer so block 0 of this launch can still read.
+        T* __restrict__ hn = static_cast<T*>(a.hist_next);
+        for (int i = t; i < H; i += NT) {
+            const long long g = a.count - H + i;
+            T v;
+            if (g < 0) {
+                v = hist[g + H];
+            } else {
+                v = in[g];
+                if (ROT) v = rotate(v, phasor_fx(a.phase0 + (unsigned long long)g * a.dphase), g, a.gm1);
+            }
+            hn[i] = v;
+        }
+        return;
+    }
+
+    constexpr int TILE = NT * R;
+    const long long n0 = (long long)blockIdx.x * TILE;
+    const long long base = n0 * M - H;  // sample index (relative to in[0]) of tile element 0
+    const int V = TILE + Q;             // elements staged per branch
+    const int U = V * M;
+
+    // ---- stage hist ++ in (rotated if ROT) into LDS, de-interleaved by branch -----------
+    {
+        double2 ph;
+        if (ROT) ph = phasor_fx(a.phase0 + (unsigned long long)(base + t) * a.dphase);
+        for (int u = t; u < U; u += NT) {
+            const long long g = base + u;
+            T v = Smp<CH>::zero();
+            if (g < 0) {
+                v = hist[g + H];
+            } else if (g < a.count) {
+                v = in[g];
+                if (ROT) v = rotate(v, ph, g, a.gm1);
+            }
+            int m, vv;
+            if (M == 1) { m = 0; vv = u; }
+            else { vv = u / M; m = u - vv * M; }
+            lds[m * a.sb + slot<R>(vv)] = v;
+            if (ROT) ph = cmul(ph, a.rot_nt);
+        }
+    }
+    __syncthreads();
+
+    // ---- sliding-window dot products ------------------------------------------------------
+    T acc[R];
+#pragma unroll
+    for (int p = 0; p < R; p++) acc[p] = Smp<CH>::zero();
+
+    for (int m = 0; m < M; m++) {
+        const T* B = lds + m * a.sb + slot<R>(t * R);  // element tR of branch m
+        const float* __restrict__ hp = a.taps + m * Q;
+        T win[R];
+#pragma unroll
+        for (int p = 0; p < R; p++) win[p] = B[p];
+        int q0 = 0;
+        for (; q0 + R <= Q; q0 += R) {
+            const T* Bn = B + slot<R>(q0 + R);  // q0 is a multiple of R
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                const float h = hp[q0 + j];
+#pragma unroll
+                for (int p = 0; p < R; p++) mac(acc[p], h, win[(p + j) % R]);
+                win[j] = Bn[j];
+            }
+        }
+        if (q0 < Q) {
+            const T* Bn = B + slot<R>(q0 + R);
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                if (q0 + j < Q) {
+                    const float h = hp[q0 + j];
+#pragma unroll
+                    for (int p = 0; p < R; p++) mac(acc[p], h, win[(p + j) % R]);
+                    win[j] = Bn[j];
+                }
+            }
+        }
+    }
+
+    // ---- store --------------------------------------------------------------------------
+    T* __restrict__ out = static_cast<T*>(a.out);
+    const long long n = n0 + (long long)t * R;
+    if (n + R <= a.nout) {
+#pragma unroll
+        for (int p = 0; p < R; p++) out[n + p] = acc[p];
+    } else {
+#pragma unroll
+        for (int p = 0; p < R; p++)
+            if (n + p < a.nout) out[n + p] = acc[p];
+    }
+}
+
+// ---- general interp/decim -------------------------------------------------------------
+struct AnyArgs {
+    const void* in;
+    void* out;
+    const void* hist;      // P samples
+    void* hist_next;
+    const float* phases;   // [L][P] as buildTapPhases lays them out (resampling.h:137-166)
+    long long count, nout;
+    int L, M, P;
+    int tile;              // outputs per block
+    int nblocks;
+    unsigned long long phase0, dphase;
+    float gm1;
+};
+
+// PolyphaseResampler<T>::run for any interp L / decim M (src/dsp/resampling.h:121-125):
+//   y[n] = sum_t phases[(n*M) % L][t] * s[(n*M)/L - P + t],   s = hist ++ in
+// One output per lane per pass; the tile's input span is staged once in LDS.
+template <int CH, int NT, bool ROT>
+__global__ __launch_bounds__(NT) void resamp_any_kernel(const AnyArgs a) {
+    using T = typename Smp<CH>::T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* lds = reinterpret_cast<T*>(smem_raw);
+    const int t = threadIdx.x;
+    const T* __restrict__ in = static_cast<const T*>(a.in);
+    const T* __restrict__ hist = static_cast<const T*>(a.hist);
+    const int P = a.P;
+
+    if ((int)blockIdx.x == a.nblocks) {
+        T* __restrict__ hn = static_cast<T*>(a.hist_next);
+        for (int i = t; i < P; i += NT) {
+            const long long g = a.count - P + i;
+            T v;
+            if (g < 0) {
+                v = hist[g + P];
+            } else {
+                v = in[g];
+                if (ROT) v = rotate(v, phasor_fx(a.phase0 + (unsigned long long)g * a.dphase), g, a.gm1);
+            }
+            hn[i] = v;
+        }
+        return;
+    }
+
+    const long long n0 = (long long)blockIdx.x * a.tile;
+    long long n1 = n0 + a.tile;
+    if (n1 > a.nout) n1 = a.nout;
+    const long long lo = (n0 * a.M) / a.L - P;           // first staged sample
+    const long long hi = ((n1 - 1) * a.M) / a.L;         // one past the last needed sample
+    const int span = (int)(hi - lo);
+    for (int u = t; u < span; u += NT) {
+        const long long g = lo + u;
+        T v = Smp<CH>::zero();
+        if (g < 0) {
+            v = hist[g + P];
+        } else if (g < a.count) {
+            v = in[g];
+            if (ROT) v = rotate(v, phasor_fx(a.phase0 + (unsigned long long)g * a.dphase), g, a.gm1);
+        }
+        lds[u] = v;
+    }
+    __syncthreads();
+
+    T* __restrict__ out = static_cast<T*>(a.out);
+    for (long long n = n0 + t; n < n1; n += NT) {
+        const long long i = n * a.M;
+        const long long d = i / a.L;
+        const int phase = (int)(i - d * a.L);
+        const T* w = lds + (int)(d - P - lo);
+        const float* __restrict__ hp = a.phases + (size_t)phase * P;
+        T acc = Smp<CH>::zero();
+        for (int k = 0; k < P; k++) mac(acc, hp[k], w[k]);
+        out[n] = acc;
+    }
+}
+
+// ---- stand-alone NCO mixer ------------------------------------------------------------
+struct XlateArgs {
+    const float2* in;
+    float2* out;
+    long long count;
+    unsigned long long phase0, dphase;
+    double2 rot_one;     // exp(j*2pi*dphase)
+    double2 rot_stride;  // exp(j*2pi*stride*dphase), stride = 2*gridDim.x*NT samples
+    int vec;             // 1: in/out 16-byte aligned -> float4 (two samples) per lane
+    float gm1;           // |phase_inc| - 1, 0 = ideal NCO
+};
+
+// FrequencyXlator<complex_t>::run (src/dsp/processing.h:64): y[n] = x[n] * phase_n.
+template <int NT> __global__ __launch_bounds__(NT) void xlate_kernel(const XlateArgs a) {
+    const long long npairs = (a.count + 1) >> 1;
+    const long long stride = (long long)gridDim.x * NT;
+    long long p = (long long)blockIdx.x * NT + threadIdx.x;
+    if (p >= npairs) return;
+    double2 ph = phasor_fx(a.phase0 + (unsigned long long)(2 * p) * a.dphase);
+    for (; p < npairs; p += stride) {
+        const long long g = 2 * p;
+        const double2 ph1 = cmul(ph, a.rot_one);
+        if (g + 1 < a.count) {
+            float2 x0, x1;
+            if (a.vec) {
+                const float4 v = reinterpret_cast<const float4*>(a.in)[p];
+                x0 = make_float2(v.x, v.y);
+                x1 = make_float2(v.z, v.w);
+            } else {
+                x0 = a.in[g];
+                x1 = a.in[g + 1];
+            }
+            const float2 y0 = rotate(x0, ph, g, a.gm1), y1 = rotate(x1, ph1, g + 1, a.gm1);
+            if (a.vec) {
+                reinterpret_cast<float4*>(a.out)[p] = make_float4(y0.x, y0.y, y1.x, y1.y);
+            } else {
+                a.out[g] = y0;
+                a.out[g + 1] = y1;
+            }
+        } else {
+            a.out[g] = rotate(a.in[g], ph, g, a.gm1);
+        }
+        ph = cmul(ph, a.rot_stride);
+    }
+}
+
+// ---- synthetic IQ ---------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU;
+    x ^= x >> 15; x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+__host__ __device__ __forceinline__ float synth_value(uint64_t c, uint32_t key) {
+    uint32_t h = mix32((uint32_t)c ^ key);
+    h = mix32(h + (uint32_t)(c >> 32) * 0x9e3779b9U);
+    return (float)((int32_t)(h >> 8) - (1 << 23)) * (1.0f / (float)(1 << 23));
+}
+
+// Same counter-based generator as oracle_synth_iq(); one float4 (two samples) per lane.
+template <int NT>
+__global__ __launch_bounds__(NT) void synth_iq_kernel(float* out, long long first_sample,
+                                                      long long count, uint32_t key) {
+    const long long nf = 2 * count;
+    const long long stride = (long long)gridDim.x * NT * 4;
+    for (long long i = ((long long)blockIdx.x * NT + threadIdx.x) * 4; i < nf; i += stride) {
+        const uint64_t c = (uint64_t)(2 * first_sample + i);
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = synth_value(c + j, key);
+        if (i + 4 <= nf && ((reinterpret_cast<uintptr_t>(out) & 15) == 0)) {
+            *reinterpret_cast<float4*>(out + i) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            for (int j = 0; j < 4 && i + j < nf; j++) out[i + j] = v[j];
+        }
+    }
+}
+
+}  // namespace qk

@@ -1,0 +1,752 @@
+// qdsp_hip.hip -- host side of libqdsp_hip.so: engine state + the extern "C" boundary
+// declared in include/qdsp_hip.h.  gfx950 only; no CPU fallback exists anywhere in this
+// library: without a HIP device every entry point returns an error.
+#include "../../include/qdsp_hip.h"
+#include "kernels.hip.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+namespace {
+
+#define HIPCHK(expr)                                   \
+    do {                                               \
+        hipError_t e_ = (expr);                        \
+        if (e_ != hipSuccess) return -(int)e_;         \
+    } while (0)
+
+constexpr int kMaxDynLds = 64 * 1024;  // default dynamic-LDS ceiling; tiles are sized under it
+
+enum Kind : int { KIND_FIR = 1, KIND_DECIM = 2, KIND_XLATE = 3, KIND_VFO = 4 };
+constexpr uint32_t kMagic = 0x51445350u;  // "QDSP"
+
+struct Launch {
+    const char* name = "";
+    int grid = 0, block = 0, lds = 0;
+};
+
+// One engine serves FIR, resampler, xlator and the fused VFO: they differ only in
+// (ch, interp, decim, rotate) and in which kernel the launch picks.
+struct Engine {
+    uint32_t magic = kMagic;
+    Kind kind;
+    int device = 0;
+    int ch = 2;               // floats per sample
+    int L = 1, M = 1;         // interp, decim
+    int ntaps = 0;            // prototype length
+    int P = 0;                // taps per phase = ceil(ntaps / L)
+    int H = 0;                // history length in samples
+    bool rotate = false;
+    bool has_filter = true;
+    // NCO: fixed-point turns, 2^64 == one turn
+    unsigned long long phase = 0, dphase = 0;
+    long double dturns = 0.0L;
+    float inc_re = 1.0f, inc_im = 0.0f;
+    bool volk_gain = true;     // emulate the VOLK rotator's magnitude sawtooth (see rotate())
+    float gm1 = 0.0f;          // |phase_inc| - 1
+    // device state
+    float* d_taps = nullptr;    // core layout (branch-major) or phases [L][P]
+    float* d_hist[2] = {nullptr, nullptr};
+    int cur = 0;
+    size_t hist_cap = 0;        // samples
+    // host-pointer path
+    hipStream_t stream = nullptr;
+    void* d_in = nullptr;
+    void* d_out = nullptr;
+    int max_block = 0;
+    size_t out_cap = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // tuning / introspection
+    int R = 0, NT = 0;          // 0 = pick automatically
+    Launch last;
+};
+
+Engine* as_engine(void* h, Kind k) {
+    Engine* e = static_cast<Engine*>(h);
+    if (!e || e->magic != kMagic || e->kind != k) return nullptr;
+    return e;
+}
+
+int env_int(const char* name, int dflt) {
+    const char* s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+
+long double turns_of(float re, float im) {
+    // arg(phase_inc)/2pi in [0,1): the angle the reference's recursive phasor actually
+    // advances by each sample is that of the ROUNDED float pair, not of the ideal theta.
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    long double t = atan2l((long double)im, (long double)re) / two_pi;
+    t -= floorl(t);
+    return t;
+}
+unsigned long long fx_of_turns(long double t) {
+    t -= floorl(t);
+    long double s = ldexpl(t, 64);
+    if (s >= 18446744073709551615.0L) return 0ULL;
+    return (unsigned long long)s;
+}
+void unit_of_fx(unsigned long long ph, long double mult, double* c, double* s) {
+    // exp(j*2pi*frac(ph/2^64 * mult)) in long double, rounded to double
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    long double t = ldexpl((long double)ph, -64) * mult;
+    t -= floorl(t);
+    *c = (double)cosl(two_pi * t);
+    *s = (double)sinl(two_pi * t);
+}
+
+int64_t out_size(const Engine* e, int64_t count) {
+    if (!e->has_filter) return count;
+    return (count * e->L) / e->M;  // calcOutSize, resampling.h:95-97 (L = M = 1 for FIR)
+}
+
+bool use_core(const Engine* e) { return e->L == 1 && e->M <= 16 && !env_int("QDSP_HIP_FORCE_ANY", 0); }
+
+int upload_taps(Engine* e, const float* taps, int ntaps) {
+    // FIR: h[k] pairs with s[n - (ntaps-1) + k]  -> core with M=1, Q=ntaps, H=ntaps-1
+    // resampler L==1: tapPhases[0][t] = taps[t]   -> core with M, Q=ceil(P/M), H=P
+    // otherwise: [L][P] phase table, buildTapPhases (resampling.h:137-166)
+    std::vector<float> host;
+    if (use_core(e)) {
+        const int K = e->P;
+        const int Q = (K + e->M - 1) / e->M;
+        host.assign((size_t)e->M * Q, 0.0f);
+        for (int k = 0; k < K; k++) host[(size_t)(k % e->M) * Q + k / e->M] = taps[k];
+    } else {
+        host.assign((size_t)e->L * e->P, 0.0f);
+        int cur = 0;
+        for (int tap = 0; tap < e->P; tap++)
+            for (int phase = 0; phase < e->L; phase++)
+                host[(size_t)((e->L - 1) - phase) * e->P + tap] = (cur < ntaps) ? taps[cur++] : 0.0f;
+    }
+    if (e->d_taps) { HIPCHK(hipFree(e->d_taps)); e->d_taps = nullptr; }
+    HIPCHK(hipMalloc(&e->d_taps, host.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(e->d_taps, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// (Re)configure the filter part.  History keeps its newest samples across a resize.
+int configure(Engine* e, const float* taps, int ntaps, int interp, int decim) {
+    if (!taps || ntaps <= 0 || interp <= 0 || decim <= 0) return QDSP_HIP_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipDeviceSynchronize());
+    const int oldH = e->H;
+    e->L = interp;
+    e->M = decim;
+    e->ntaps = ntaps;
+    e->P = (ntaps + interp - 1) / interp;
+    const int newH = (e->kind == KIND_FIR) ? ntaps - 1 : e->P;
+    int rc = upload_taps(e, taps, ntaps);
+    if (rc) return rc;
+    const size_t bytes = (size_t)(newH > 0 ? newH : 1) * e->ch * sizeof(float);
+    float* nh[2] = {nullptr, nullptr};
+    for (int i = 0; i < 2; i++) {
+        HIPCHK(hipMalloc(&nh[i], bytes));
+        HIPCHK(hipMemset(nh[i], 0, bytes));
+    }
+    if (e->d_hist[0] && oldH > 0 && newH > 0) {
+        const int keep = oldH < newH ? oldH : newH;
+        HIPCHK(hipMemcpy(nh[0] + (size_t)(newH - keep) * e->ch,
+                         e->d_hist[e->cur] + (size_t)(oldH - keep) * e->ch,
+                         (size_t)keep * e->ch * sizeof(float), hipMemcpyDeviceToDevice));
+    }
+    for (int i = 0; i < 2; i++)
+        if (e->d_hist[i]) HIPCHK(hipFree(e->d_hist[i]));
+    e->d_hist[0] = nh[0];
+    e->d_hist[1] = nh[1];
+    e->cur = 0;
+    e->H = newH;
+    e->hist_cap = newH;
+    return 0;
+}
+
+void set_inc(Engine* e, float re, float im) {
+    e->inc_re = re;
+    e->inc_im = im;
+    e->dturns = turns_of(re, im);
+    e->dphase = fx_of_turns(e->dturns);
+    e->gm1 = (float)(hypotl((long double)re, (long double)im) - 1.0L);
+}
+
+int ensure_io(Engine* e, int max_block) {
+    if (max_block <= 0) return 0;
+    HIPCHK(hipSetDevice(e->device));
+    const size_t in_bytes = (size_t)max_block * e->ch * sizeof(float);
+    const size_t oc = (size_t)out_size(e, max_block) + 1;
+    if (!e->d_in || max_block > e->max_block) {
+        if (e->d_in) HIPCHK(hipFree(e->d_in));
+        HIPCHK(hipMalloc(&e->d_in, in_bytes));
+        e->max_block = max_block;
+    }
+    if (!e->d_out || oc > e->out_cap) {
+        if (e->d_out) HIPCHK(hipFree(e->d_out));
+        HIPCHK(hipMalloc(&e->d_out, oc * e->ch * sizeof(float)));
+        e->out_cap = oc;
+    }
+    return 0;
+}
+
+int create(void** h, Kind kind, int device, int ch, bool rotate, bool has_filter, int max_block) {
+    if (!h) return QDSP_HIP_EINVAL;
+    *h = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return QDSP_HIP_ENODEV;
+    if (device < 0 || device >= ndev) return QDSP_HIP_ENODEV;
+    HIPCHK(hipSetDevice(device));
+    Engine* e = new (std::nothrow) Engine();
+    if (!e) return QDSP_HIP_ENOMEM;
+    e->kind = kind;
+    e->device = device;
+    e->ch = ch;
+    e->rotate = rotate;
+    e->has_filter = has_filter;
+    e->R = env_int("QDSP_HIP_R", 0);
+    e->NT = env_int("QDSP_HIP_NT", 0);
+    hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipEventCreate(&e->ev0);
+    if (err == hipSuccess) err = hipEventCreate(&e->ev1);
+    if (err != hipSuccess) { delete e; return -(int)err; }
+    e->max_block = 0;
+    (void)max_block;
+    *h = e;
+    return 0;
+}
+
+void destroy(Engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipDeviceSynchronize();
+    if (e->d_taps) (void)hipFree(e->d_taps);
+    for (int i = 0; i < 2; i++)
+        if (e->d_hist[i]) (void)hipFree(e->d_hist[i]);
+    if (e->d_in) (void)hipFree(e->d_in);
+    if (e->d_out) (void)hipFree(e->d_out);
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    e->magic = 0;
+    delete e;
+}
+
+// ---- launches --------------------------------------------------------------------------
+
+// host copy of qk::slot (must match kernels.hip.h)
+inline int qk_slot_host(int R, int v) { return (R % 2 == 0) ? v + v / R : v; }
+
+template <int CH, int R, int NT, bool ROT>
+int launch_core_t(Engine* e, qk::CoreArgs& a, hipStream_t s) {
+    constexpr int TILE = NT * R;
+    const int V = TILE + a.Q;
+    int sb = qk_slot_host(R, V - 1) + 1;
+    // Spread the M branch bases over the banks for the de-interleaving LDS writes.
+    if (a.M > 1) {
+        const int want = (a.M >= 16) ? 1 : 16 / a.M;
+        while ((sb % 16) != (want % 16)) sb++;
+    }
+    a.sb = sb;
+    const size_t lds = (size_t)a.M * sb * CH * sizeof(float);
+    if (lds > (size_t)kMaxDynLds) return QDSP_HIP_EINVAL;
+    a.nblocks = (int)((a.nout + TILE - 1) / TILE);
+    if (ROT) unit_of_fx(a.dphase, (long double)NT, &a.rot_nt.x, &a.rot_nt.y);
+    hipLaunchKernelGGL((qk::fir_core_kernel<CH, R, NT, ROT>), dim3(a.nblocks + 1), dim3(NT), lds, s, a);
+    HIPCHK(hipGetLastError());
+    e->last.name = "fir_core_kernel";
+    e->last.grid = a.nblocks + 1;
+    e->last.block = NT;
+    e->last.lds = (int)lds;
+    return 0;
+}
+
+template <int CH, bool ROT> int launch_core(Engine* e, qk::CoreArgs& a, hipStream_t s) {
+    // Geometry: (R outputs per lane, NT lanes).  FIR (M == 1) is VALU-bound: a long
+    // register window amortises the LDS read per tap.  Decimators stage M*TILE inputs per
+    // tile, so TILE shrinks with M to stay inside the LDS budget.
+    int R = e->R, NT = e->NT;
+    if (R == 0 || NT == 0) {
+        if (a.M == 1) { R = 8; NT = 256; }
+        else if (a.M <= 2) { R = 8; NT = 128; }
+        else if (a.M <= 8) { R = 4; NT = 128; }
+        else { R = 4; NT = 64; }
+    }
+#define QK_CASE(r, nt) \
+    if (R == r && NT == nt) return launch_core_t<CH, r, nt, ROT>(e, a, s);
+    QK_CASE(8, 256)
+    QK_CASE(16, 256)
+    QK_CASE(4, 256)
+    QK_CASE(8, 128)
+    QK_CASE(4, 128)
+    QK_CASE(4, 64)
+    QK_CASE(2, 64)
+#undef QK_CASE
+    return QDSP_HIP_EINVAL;
+}
+
+template <int CH, bool ROT> int launch_any(Engine* e, qk::AnyArgs& a, hipStream_t s) {
+    constexpr int NT = 256;
+    // Tile = as many outputs as keep the staged input span inside the LDS budget.
+    const long long max_elems = kMaxDynLds / (CH * (int)sizeof(float));
+    long long tile = 4LL * NT;
+    auto span_of = [&](long long t) { return ((t - 1) * a.M) / a.L + a.P + 2; };
+    while (tile > 1 && span_of(tile) > max_elems) tile /= 2;
+    if (span_of(tile) > max_elems) return QDSP_HIP_EINVAL;  // taps per phase beyond LDS
+    a.tile = (int)tile;
+    a.nblocks = (int)((a.nout + tile - 1) / tile);
+    const size_t lds = (size_t)span_of(tile) * CH * sizeof(float);
+    hipLaunchKernelGGL((qk::resamp_any_kernel<CH, NT, ROT>), dim3(a.nblocks + 1), dim3(NT), lds, s, a);
+    HIPCHK(hipGetLastError());
+    e->last.name = "resamp_any_kernel";
+    e->last.grid = a.nblocks + 1;
+    e->last.block = NT;
+    e->last.lds = (int)lds;
+    return 0;
+}
+
+int launch_xlate(Engine* e, const void* d_in, int64_t count, void* d_out, hipStream_t s) {
+    constexpr int NT = 256;
+    if (count <= 0) return 0;
+    qk::XlateArgs a;
+    a.in = static_cast<const float2*>(d_in);
+    a.out = static_cast<float2*>(d_out);
+    a.count = count;
+    a.phase0 = e->phase;
+    a.dphase = e->dphase;
+    const long long npairs = (count + 1) / 2;
+    long long grid = (npairs + NT - 1) / NT;
+    if (grid > 256 * 16) grid = 256 * 16;  // 16 blocks per CU, grid-stride beyond
+    unit_of_fx(e->dphase, 1.0L, &a.rot_one.x, &a.rot_one.y);
+    unit_of_fx(e->dphase, (long double)(2 * grid * NT), &a.rot_stride.x, &a.rot_stride.y);
+    a.vec = (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0;
+    a.gm1 = e->volk_gain ? e->gm1 : 0.0f;
+    hipLaunchKernelGGL((qk::xlate_kernel<NT>), dim3((unsigned)grid), dim3(NT), 0, s, a);
+    HIPCHK(hipGetLastError());
+    e->last.name = "xlate_kernel";
+    e->last.grid = (int)grid;
+    e->last.block = NT;
+    e->last.lds = 0;
+    return 0;
+}
+
+// One run() worth of work on device pointers.  Returns the output count.
+int64_t process_dev(Engine* e, const void* d_in, int64_t count, void* d_out, void* stream) {
+    if (count < 0 || (count > 0 && (!d_in || !d_out))) return QDSP_HIP_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : e->stream;
+    const int64_t nout = out_size(e, count);
+    int rc = 0;
+    if (!e->has_filter) {
+        rc = launch_xlate(e, d_in, count, d_out, s);
+    } else if (use_core(e)) {
+        qk::CoreArgs a;
+        memset(&a, 0, sizeof(a));
+        a.in = d_in;
+        a.out = d_out;
+        a.hist = e->d_hist[e->cur];
+        a.hist_next = e->d_hist[e->cur ^ 1];
+        a.taps = e->d_taps;
+        a.count = count;
+        a.nout = nout;
+        a.H = e->H;
+        a.M = e->M;
+        a.Q = (e->P + e->M - 1) / e->M;
+        a.phase0 = e->phase;
+        a.dphase = e->dphase;
+        a.gm1 = e->volk_gain ? e->gm1 : 0.0f;
+        if (e->ch == 2) rc = e->rotate ? launch_core<2, true>(e, a, s) : launch_core<2, false>(e, a, s);
+        else rc = launch_core<1, false>(e, a, s);
+        if (rc == 0) e->cur ^= 1;
+    } else {
+        qk::AnyArgs a;
+        memset(&a, 0, sizeof(a));
+        a.in = d_in;
+        a.out = d_out;
+        a.hist = e->d_hist[e->cur];
+        a.hist_next = e->d_hist[e->cur ^ 1];
+        a.phases = e->d_taps;
+        a.count = count;
+        a.nout = nout;
+        a.L = e->L;
+        a.M = e->M;
+        a.P = e->P;
+        a.phase0 = e->phase;
+        a.dphase = e->dphase;
+        a.gm1 = e->volk_gain ? e->gm1 : 0.0f;
+        if (e->ch == 2) rc = e->rotate ? launch_any<2, true>(e, a, s) : launch_any<2, false>(e, a, s);
+        else rc = launch_any<1, false>(e, a, s);
+        if (rc == 0) e->cur ^= 1;
+    }
+    if (rc) return rc;
+    if (e->rotate) e->phase += (unsigned long long)count * e->dphase;  // exact mod 2^64
+    return nout;
+}
+
+// Host-pointer path: what a block's run() calls between _in->read() and out.swap().
+int64_t process_host(Engine* e, const float* in, int count, float* out) {
+    if (count < 0 || (count > 0 && (!in || !out))) return QDSP_HIP_EINVAL;
+    if (count > e->max_block) {
+        int rc = ensure_io(e, count);
+        if (rc) return rc;
+    }
+    HIPCHK(hipSetDevice(e->device));
+    const size_t in_bytes = (size_t)count * e->ch * sizeof(float);
+    if (count) HIPCHK(hipMemcpyAsync(e->d_in, in, in_bytes, hipMemcpyHostToDevice, e->stream));
+    const int64_t nout = process_dev(e, e->d_in, count, e->d_out, e->stream);
+    if (nout < 0) return nout;
+    if (nout)
+        HIPCHK(hipMemcpyAsync(out, e->d_out, (size_t)nout * e->ch * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return nout;
+}
+
+int reset(Engine* e) {
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipDeviceSynchronize());
+    for (int i = 0; i < 2; i++)
+        if (e->d_hist[i] && e->H > 0) HIPCHK(hipMemset(e->d_hist[i], 0, (size_t)e->H * e->ch * sizeof(float)));
+    e->phase = 0;
+    return 0;
+}
+
+int get_history(Engine* e, float* hist) {
+    if (!hist) return QDSP_HIP_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipDeviceSynchronize());
+    if (e->H > 0)
+        HIPCHK(hipMemcpy(hist, e->d_hist[e->cur], (size_t)e->H * e->ch * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+int set_history(Engine* e, const float* hist) {
+    if (!hist) return QDSP_HIP_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipDeviceSynchronize());
+    if (e->H > 0)
+        HIPCHK(hipMemcpy(e->d_hist[e->cur], hist, (size_t)e->H * e->ch * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int get_phase(Engine* e, float* re, float* im) {
+    if (!re || !im) return QDSP_HIP_EINVAL;
+    double c, s;
+    unit_of_fx(e->phase, 1.0L, &c, &s);
+    *re = (float)c;
+    *im = (float)s;
+    return 0;
+}
+int set_phase(Engine* e, float re, float im) {
+    if (re == 0.0f && im == 0.0f) return QDSP_HIP_EINVAL;
+    e->phase = fx_of_turns(turns_of(re, im));
+    return 0;
+}
+
+int time_process(Engine* e, const void* d_in, int64_t count, void* d_out, void* stream, int iters, float* ms) {
+    if (iters <= 0 || !ms) return QDSP_HIP_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : e->stream;
+    HIPCHK(hipEventRecord(e->ev0, s));
+    for (int i = 0; i < iters; i++) {
+        int64_t r = process_dev(e, d_in, count, d_out, stream);
+        if (r < 0) return (int)r;
+    }
+    HIPCHK(hipEventRecord(e->ev1, s));
+    HIPCHK(hipEventSynchronize(e->ev1));
+    float t = 0.0f;
+    HIPCHK(hipEventElapsedTime(&t, e->ev0, e->ev1));
+    *ms = t / (float)iters;
+    return 0;
+}
+
+Engine* any_engine(void* h) {
+    Engine* e = static_cast<Engine*>(h);
+    return (e && e->magic == kMagic) ? e : nullptr;
+}
+
+}  // namespace
+
+// ==========================================================================================
+// extern "C" boundary
+// ==========================================================================================
+extern "C" {
+
+int qdsp_hip_abi_version(void) { return QDSP_HIP_ABI_VERSION; }
+
+const char* qdsp_hip_error_string(int code) {
+    if (code >= 0) return "success";
+    switch (code) {
+        case QDSP_HIP_EINVAL: return "qdsp_hip: invalid argument";
+        case QDSP_HIP_ENOMEM: return "qdsp_hip: out of host memory";
+        case QDSP_HIP_ESIZE: return "qdsp_hip: block larger than max_block";
+        case QDSP_HIP_ENODEV: return "qdsp_hip: no usable HIP device";
+        default: return hipGetErrorString((hipError_t)(-code));
+    }
+}
+
+int qdsp_hip_device_count(int* count) {
+    if (!count) return QDSP_HIP_EINVAL;
+    *count = 0;
+    HIPCHK(hipGetDeviceCount(count));
+    return 0;
+}
+
+int qdsp_hip_device_info(int device, char* name, int name_len, char* arch, int arch_len, int* cus) {
+    hipDeviceProp_t p;
+    HIPCHK(hipGetDeviceProperties(&p, device));
+    if (name && name_len > 0) { strncpy(name, p.name, name_len - 1); name[name_len - 1] = 0; }
+    if (arch && arch_len > 0) { strncpy(arch, p.gcnArchName, arch_len - 1); arch[arch_len - 1] = 0; }
+    if (cus) *cus = p.multiProcessorCount;
+    return 0;
+}
+
+int qdsp_hip_host_alloc(void** p, size_t bytes) {
+    if (!p) return QDSP_HIP_EINVAL;
+    HIPCHK(hipHostMalloc(p, bytes, hipHostMallocDefault));
+    return 0;
+}
+int qdsp_hip_host_free(void* p) { HIPCHK(hipHostFree(p)); return 0; }
+int qdsp_hip_host_register(void* p, size_t bytes) { HIPCHK(hipHostRegister(p, bytes, hipHostRegisterDefault)); return 0; }
+int qdsp_hip_host_unregister(void* p) { HIPCHK(hipHostUnregister(p)); return 0; }
+int qdsp_hip_dev_alloc(int device, void** p, size_t bytes) {
+    if (!p) return QDSP_HIP_EINVAL;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMalloc(p, bytes));
+    return 0;
+}
+int qdsp_hip_dev_free(int device, void* p) { HIPCHK(hipSetDevice(device)); HIPCHK(hipFree(p)); return 0; }
+int qdsp_hip_memcpy_h2d(int device, void* d, const void* h, size_t bytes) {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMemcpy(d, h, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+int qdsp_hip_memcpy_d2h(int device, void* h, const void* d, size_t bytes) {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+int qdsp_hip_device_sync(int device) { HIPCHK(hipSetDevice(device)); HIPCHK(hipDeviceSynchronize()); return 0; }
+
+// ---- filter-bearing operators: FIR, resampler, fused VFO ---------------------------------
+#define QDSP_FILTER_COMMON(prefix, KIND)                                                          \
+    int prefix##_reset(void* h) { Engine* e = as_engine(h, KIND); return e ? reset(e) : QDSP_HIP_EINVAL; } \
+    int prefix##_history_len(void* h) { Engine* e = as_engine(h, KIND); return e ? e->H : QDSP_HIP_EINVAL; } \
+    int prefix##_get_history(void* h, float* p) { Engine* e = as_engine(h, KIND); return e ? get_history(e, p) : QDSP_HIP_EINVAL; } \
+    int prefix##_set_history(void* h, const float* p) { Engine* e = as_engine(h, KIND); return e ? set_history(e, p) : QDSP_HIP_EINVAL; } \
+    int prefix##_history_dev(void* h, void** d) {                                                 \
+        Engine* e = as_engine(h, KIND);                                                           \
+        if (!e || !d) return QDSP_HIP_EINVAL;                                                     \
+        *d = e->d_hist[e->cur];                                                                   \
+        return 0;                                                                                 \
+    }                                                                                             \
+    void prefix##_destroy(void* h) { Engine* e = as_engine(h, KIND); if (e) destroy(e); }
+
+#define QDSP_FIR_API(prefix, CH)                                                                  \
+    int prefix##_create(void** h, int device, const float* taps, int ntaps, int max_block) {      \
+        int rc = create(h, KIND_FIR, device, CH, false, true, max_block);                         \
+        if (rc) return rc;                                                                        \
+        Engine* e = static_cast<Engine*>(*h);                                                     \
+        rc = configure(e, taps, ntaps, 1, 1);                                                     \
+        if (!rc) rc = ensure_io(e, max_block);                                                    \
+        if (rc) { destroy(e); *h = nullptr; }                                                     \
+        return rc;                                                                                \
+    }                                                                                             \
+    int prefix##_process(void* h, const float* in, int count, float* out) {                       \
+        Engine* e = as_engine(h, KIND_FIR);                                                       \
+        if (!e || e->ch != CH) return QDSP_HIP_EINVAL;                                            \
+        int64_t r = process_host(e, in, count, out);                                              \
+        return r < 0 ? (int)r : 0;                                                                \
+    }                                                                                             \
+    int prefix##_process_dev(void* h, const void* d_in, int64_t count, void* d_out, void* s) {    \
+        Engine* e = as_engine(h, KIND_FIR);                                                       \
+        if (!e || e->ch != CH) return QDSP_HIP_EINVAL;                                            \
+        int64_t r = process_dev(e, d_in, count, d_out, s);                                        \
+        return r < 0 ? (int)r : 0;                                                                \
+    }                                                                                             \
+    int prefix##_set_taps(void* h, const float* taps, int ntaps) {                                \
+        Engine* e = as_engine(h, KIND_FIR);                                                       \
+        return e ? configure(e, taps, ntaps, 1, 1) : QDSP_HIP_EINVAL;                             \
+    }                                                                                             \
+    QDSP_FILTER_COMMON(prefix, KIND_FIR)
+
+QDSP_FIR_API(qdsp_hip_fir_cf32, 2)
+QDSP_FIR_API(qdsp_hip_fir_f32, 1)
+
+#define QDSP_DECIM_API(prefix, CH)                                                                \
+    int prefix##_create(void** h, int device, const float* taps, int ntaps, int interp, int decim, int max_block) { \
+        int rc = create(h, KIND_DECIM, device, CH, false, true, max_block);                       \
+        if (rc) return rc;                                                                        \
+        Engine* e = static_cast<Engine*>(*h);                                                     \
+        rc = configure(e, taps, ntaps, interp, decim);                                            \
+        if (!rc) rc = ensure_io(e, max_block);                                                    \
+        if (rc) { destroy(e); *h = nullptr; }                                                     \
+        return rc;                                                                                \
+    }                                                                                             \
+    int prefix##_process(void* h, const float* in, int count, float* out) {                       \
+        Engine* e = as_engine(h, KIND_DECIM);                                                     \
+        if (!e || e->ch != CH) return QDSP_HIP_EINVAL;                                            \
+        return (int)process_host(e, in, count, out);                                              \
+    }                                                                                             \
+    int64_t prefix##_process_dev(void* h, const void* d_in, int64_t count, void* d_out, void* s) { \
+        Engine* e = as_engine(h, KIND_DECIM);                                                     \
+        if (!e || e->ch != CH) return QDSP_HIP_EINVAL;                                            \
+        return process_dev(e, d_in, count, d_out, s);                                             \
+    }                                                                                             \
+    int prefix##_configure(void* h, const float* taps, int ntaps, int interp, int decim) {        \
+        Engine* e = as_engine(h, KIND_DECIM);                                                     \
+        if (!e) return QDSP_HIP_EINVAL;                                                           \
+        int rc = configure(e, taps, ntaps, interp, decim);                                        \
+        if (!rc && e->max_block) { int mb = e->max_block; e->max_block = 0; rc = ensure_io(e, mb); } \
+        return rc;                                                                                \
+    }                                                                                             \
+    int64_t prefix##_out_size(void* h, int64_t count) {                                           \
+        Engine* e = as_engine(h, KIND_DECIM);                                                     \
+        return e ? out_size(e, count) : QDSP_HIP_EINVAL;                                          \
+    }                                                                                             \
+    QDSP_FILTER_COMMON(prefix, KIND_DECIM)
+
+QDSP_DECIM_API(qdsp_hip_decim_cf32, 2)
+QDSP_DECIM_API(qdsp_hip_decim_f32, 1)
+
+// ---- FrequencyXlator ----------------------------------------------------------------------
+int qdsp_hip_xlate_cf32_create(void** h, int device, float inc_re, float inc_im, int max_block) {
+    if (inc_re == 0.0f && inc_im == 0.0f) return QDSP_HIP_EINVAL;
+    int rc = create(h, KIND_XLATE, device, 2, true, false, max_block);
+    if (rc) return rc;
+    Engine* e = static_cast<Engine*>(*h);
+    set_inc(e, inc_re, inc_im);
+    rc = ensure_io(e, max_block);
+    if (rc) { destroy(e); *h = nullptr; }
+    return rc;
+}
+int qdsp_hip_xlate_cf32_process(void* h, const float* in, int count, float* out) {
+    Engine* e = as_engine(h, KIND_XLATE);
+    if (!e) return QDSP_HIP_EINVAL;
+    int64_t r = process_host(e, in, count, out);
+    return r < 0 ? (int)r : 0;
+}
+int qdsp_hip_xlate_cf32_process_dev(void* h, const void* d_in, int64_t count, void* d_out, void* s) {
+    Engine* e = as_engine(h, KIND_XLATE);
+    if (!e) return QDSP_HIP_EINVAL;
+    int64_t r = process_dev(e, d_in, count, d_out, s);
+    return r < 0 ? (int)r : 0;
+}
+int qdsp_hip_xlate_cf32_set_phase_inc(void* h, float re, float im) {
+    Engine* e = as_engine(h, KIND_XLATE);
+    if (!e || (re == 0.0f && im == 0.0f)) return QDSP_HIP_EINVAL;
+    set_inc(e, re, im);
+    return 0;
+}
+int qdsp_hip_xlate_cf32_get_phase(void* h, float* re, float* im) {
+    Engine* e = as_engine(h, KIND_XLATE);
+    return e ? get_phase(e, re, im) : QDSP_HIP_EINVAL;
+}
+int qdsp_hip_xlate_cf32_set_phase(void* h, float re, float im) {
+    Engine* e = as_engine(h, KIND_XLATE);
+    return e ? set_phase(e, re, im) : QDSP_HIP_EINVAL;
+}
+int qdsp_hip_xlate_cf32_advance(void* h, int64_t n) {
+    Engine* e = as_engine(h, KIND_XLATE);
+    if (!e) return QDSP_HIP_EINVAL;
+    e->phase += (unsigned long long)n * e->dphase;
+    return 0;
+}
+int qdsp_hip_xlate_cf32_set_volk_gain(void* h, int on) {
+    Engine* e = as_engine(h, KIND_XLATE);
+    if (!e) return QDSP_HIP_EINVAL;
+    e->volk_gain = on != 0;
+    return 0;
+}
+void qdsp_hip_xlate_cf32_destroy(void* h) { Engine* e = as_engine(h, KIND_XLATE); if (e) destroy(e); }
+
+// ---- fused VFO ------------------------------------------------------------------------------
+int qdsp_hip_xlate_fir_decim_cf32_create(void** h, int device, const float* taps, int ntaps, int interp,
+                                         int decim, float inc_re, float inc_im, int max_block) {
+    if (inc_re == 0.0f && inc_im == 0.0f) return QDSP_HIP_EINVAL;
+    int rc = create(h, KIND_VFO, device, 2, true, true, max_block);
+    if (rc) return rc;
+    Engine* e = static_cast<Engine*>(*h);
+    set_inc(e, inc_re, inc_im);
+    rc = configure(e, taps, ntaps, interp, decim);
+    if (!rc) rc = ensure_io(e, max_block);
+    if (rc) { destroy(e); *h = nullptr; }
+    return rc;
+}
+int qdsp_hip_xlate_fir_decim_cf32_process(void* h, const float* in, int count, float* out) {
+    Engine* e = as_engine(h, KIND_VFO);
+    return e ? (int)process_host(e, in, count, out) : QDSP_HIP_EINVAL;
+}
+int64_t qdsp_hip_xlate_fir_decim_cf32_process_dev(void* h, const void* d_in, int64_t count, void* d_out, void* s) {
+    Engine* e = as_engine(h, KIND_VFO);
+    return e ? process_dev(e, d_in, count, d_out, s) : QDSP_HIP_EINVAL;
+}
+int qdsp_hip_xlate_fir_decim_cf32_configure(void* h, const float* taps, int ntaps, int interp, int decim) {
+    Engine* e = as_engine(h, KIND_VFO);
+    if (!e) return QDSP_HIP_EINVAL;
+    int rc = configure(e, taps, ntaps, interp, decim);
+    if (!rc && e->max_block) { int mb = e->max_block; e->max_block = 0; rc = ensure_io(e, mb); }
+    return rc;
+}
+int qdsp_hip_xlate_fir_decim_cf32_set_phase_inc(void* h, float re, float im) {
+    Engine* e = as_engine(h, KIND_VFO);
+    if (!e || (re == 0.0f && im == 0.0f)) return QDSP_HIP_EINVAL;
+    set_inc(e, re, im);
+    return 0;
+}
+int qdsp_hip_xlate_fir_decim_cf32_get_phase(void* h, float* re, float* im) {
+    Engine* e = as_engine(h, KIND_VFO);
+    return e ? get_phase(e, re, im) : QDSP_HIP_EINVAL;
+}
+int qdsp_hip_xlate_fir_decim_cf32_set_phase(void* h, float re, float im) {
+    Engine* e = as_engine(h, KIND_VFO);
+    return e ? set_phase(e, re, im) : QDSP_HIP_EINVAL;
+}
+int qdsp_hip_xlate_fir_decim_cf32_advance(void* h, int64_t n) {
+    Engine* e = as_engine(h, KIND_VFO);
+    if (!e) return QDSP_HIP_EINVAL;
+    e->phase += (unsigned long long)n * e->dphase;
+    return 0;
+}
+int qdsp_hip_xlate_fir_decim_cf32_set_volk_gain(void* h, int on) {
+    Engine* e = as_engine(h, KIND_VFO);
+    if (!e) return QDSP_HIP_EINVAL;
+    e->volk_gain = on != 0;
+    return 0;
+}
+int64_t qdsp_hip_xlate_fir_decim_cf32_out_size(void* h, int64_t count) {
+    Engine* e = as_engine(h, KIND_VFO);
+    return e ? out_size(e, count) : QDSP_HIP_EINVAL;
+}
+QDSP_FILTER_COMMON(qdsp_hip_xlate_fir_decim_cf32, KIND_VFO)
+
+// ---- harness ----------------------------------------------------------------------------------
+int qdsp_hip_synth_iq_dev(int device, void* d_out, int64_t first_sample, int64_t count, uint32_t seed, void* stream) {
+    if (count < 0 || (count > 0 && !d_out)) return QDSP_HIP_EINVAL;
+    if (count == 0) return 0;
+    HIPCHK(hipSetDevice(device));
+    constexpr int NT = 256;
+    const uint32_t key = qk::mix32(seed * 0x9e3779b9U + 0x85ebca6bU);
+    long long grid = (2 * count / 4 + NT - 1) / NT + 1;
+    if (grid > 256 * 16) grid = 256 * 16;
+    hipLaunchKernelGGL((qk::synth_iq_kernel<NT>), dim3((unsigned)grid), dim3(NT), 0, static_cast<hipStream_t>(stream),
+                       static_cast<float*>(d_out), (long long)first_sample, (long long)count, key);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int qdsp_hip_last_kernel(void* h, char* name, int name_len, int* grid, int* block, int* lds) {
+    Engine* e = any_engine(h);
+    if (!e) return QDSP_HIP_EINVAL;
+    if (name && name_len > 0) { strncpy(name, e->last.name, name_len - 1); name[name_len - 1] = 0; }
+    if (grid) *grid = e->last.grid;
+    if (block) *block = e->last.block;
+    if (lds) *lds = e->last.lds;
+    return 0;
+}
+
+int qdsp_hip_time_process_dev(void* h, const void* d_in, int64_t count, void* d_out, void* stream, int iters, float* ms) {
+    Engine* e = any_engine(h);
+    return e ? time_process(e, d_in, count, d_out, stream, iters, ms) : QDSP_HIP_EINVAL;
+}
+
+}  // extern "C"

@@ -1,0 +1,72 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/qdsp_hip.h
+declares, and -- with no GPU -- refuses to do anything (no CPU fallback)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from qdsp_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    L = capi.load()
+    names = capi.declared_symbols()
+    assert len(names) >= 80
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert L.qdsp_hip_abi_version() == 1
+
+
+def test_exported_symbols_are_all_declared():
+    """Nothing leaks out of the .so beyond the header (C-ABI is exactly the header)."""
+    out = subprocess.check_output(["nm", "-D", "--defined-only", capi.LIB_PATH], text=True)
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l and "qdsp_hip_" in l}
+    assert exported == set(capi.declared_symbols())
+
+
+def test_header_is_plain_c(tmp_path):
+    src = tmp_path / "t.c"
+    src.write_text('#include "qdsp_hip.h"\nint main(void){return QDSP_HIP_ABI_VERSION==1?0:1;}\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(tmp_path / "t")])
+    subprocess.check_call([str(tmp_path / "t")])
+
+
+def _has_gpu():
+    n = C.c_int(0)
+    return capi.load().qdsp_hip_device_count(C.byref(n)) == 0 and n.value > 0
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-device behaviour")
+def test_no_device_fails_loudly():
+    from qdsp_amd import ops
+
+    with pytest.raises(capi.QdspHipError):
+        ops.Fir(np.ones(4, np.float32))
+    with pytest.raises(capi.QdspHipError):
+        ops.Xlator(4.0, 1.0)
+    assert b"no usable HIP device" in capi.load().qdsp_hip_error_string(-10004)
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under qdsp_amd/ may reference it."""
+    bad = []
+    for d, _, files in os.walk(os.path.join(ROOT, "qdsp_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp", "Makefile")):
+                txt = open(os.path.join(d, f), errors="ignore").read()
+                if "import oracle" in txt or "from oracle" in txt or "qdsp_oracle" in txt or "liboracle" in txt:
+                    bad.append(os.path.join(d, f))
+    assert not bad, bad
+
+
+def test_phase_delta_matches_reference_formula():
+    from qdsp_amd.ops import phase_delta
+    import oracle as O
+
+    for fs, f in ((4.0, 1.0), (2.4e6, 123456.0), (48000.0, -7000.0)):
+        d = O.Xlator(fs, f).delta
+        assert phase_delta(fs, f) == (float(d[0]), float(d[1]))

@@ -1,0 +1,339 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs, the committed golden vectors, and size-independent properties at full size.
+
+Tolerances (north_star: output within 1e-5 RMS of the CPU reference):
+  * FIR (decim 1): the device accumulates taps in order 0..N-1 with one fused multiply-add
+    per tap -- exactly the oracle's ACC_FMA variant -> BIT-EXACT against it; against the
+    VOLK-generic-order oracle (separately rounded multiply and add) RMS <= 1e-6.
+  * decimators / resamplers / fused VFO: branch-major tap order -> RMS <= 2e-6 vs the
+    generic-order oracle, <= 1e-6 vs the FP64-accumulate oracle.
+  * NCO: <= 2e-6 max abs on streams <= 4096 samples per call vs the VOLK-generic rotator
+    (longer streams are compared with the FP64-phase yardstick; the reference's own drift
+    is asserted next to it).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+from conftest import rel_rms
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+TOL_RMS = 1e-5  # the north_star bar; individual asserts are tighter and say so
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from qdsp_amd import ops as _ops
+
+    info = _ops.device_info(0)
+    assert "gfx950" in info["arch"], info
+    return _ops
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(HERE, "golden", "vectors.npz"))
+
+
+@pytest.fixture(scope="module")
+def kat():
+    with open(os.path.join(HERE, "golden", "kat.json")) as f:
+        return json.load(f)
+
+
+def run_blocks(op, x, sizes):
+    ys, i, k = [], 0, 0
+    while i < len(x):
+        b = min(sizes[k % len(sizes)], len(x) - i)
+        ys.append(np.array(op.process(x[i:i + b])))
+        i += b
+        k += 1
+    return np.concatenate(ys)
+
+
+def dev(x):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+# ------------------------------------------------------------------------------ known answers
+def test_kat_fir(ops, kat):
+    for c in kat["fir"]:
+        x = np.array(c["x_re"], np.float32)
+        x = (x - 1j * x).astype(np.complex64)
+        y = run_blocks(ops.Fir(c["taps"]), x, c["blocks"])
+        assert np.allclose(y.real, c["y_re"], atol=2e-6) and np.array_equal(y.imag, -y.real)
+
+
+def test_kat_resampler(ops, kat):
+    for c in kat["resamp"]:
+        x = np.array(c["x_re"], np.float32).astype(np.complex64)
+        y = run_blocks(ops.Resampler(np.array(c["taps"], np.float32), c["interp"], c["decim"]), x, c["blocks"])
+        assert np.array_equal(y.real, np.array(c["y_re"], np.float32)), (c, y.real)
+        assert not y.imag.any()
+
+
+def test_kat_xlator(ops, kat):
+    for c in kat["xlator"]:
+        y = ops.Xlator(c["sample_rate"], c["freq"]).process(np.ones(c["n"], np.complex64))
+        want = np.array([complex(a, b) for a, b in c["y"]])
+        assert np.abs(y - want).max() < c["tol"]
+
+
+# ------------------------------------------------------------------------------ FIR
+@pytest.mark.parametrize("name", ["taps4", "taps63", "taps256"])
+def test_fir_golden_host_path(ops, gold, name):
+    """Host-pointer entry point, ragged blocks incl. blocks shorter than the history."""
+    y = run_blocks(ops.Fir(gold[name]), gold["x"], [1000, 37, 1, 2048, 5])
+    want = gold[f"fir_{name}"]
+    assert rel_rms(y, want) < 1e-6
+    fma = run_blocks(O.Fir(gold[name], acc=O.ACC_FMA), gold["x"], [6000])
+    assert np.array_equal(y, fma), "device FIR must equal the k-ordered fmaf chain bit for bit"
+
+
+@pytest.mark.parametrize("name", ["taps63", "taps256"])
+def test_fir_f32_golden(ops, gold, name):
+    xr = np.ascontiguousarray(gold["x"].real)
+    y = run_blocks(ops.Fir(gold[name], complex_data=False), xr, [1000, 37, 1, 2048, 5])
+    assert rel_rms(y, gold[f"firf32_{name}"]) < 1e-6
+    assert np.array_equal(y, O.Fir(gold[name], complex_data=False, acc=O.ACC_FMA).process(xr))
+
+
+@pytest.mark.parametrize("ntaps", [1, 2, 3, 7, 8, 9, 31, 64, 255, 256, 257, 1000])
+def test_fir_tap_counts_bit_exact(ops, ntaps):
+    rng = np.random.default_rng(ntaps)
+    taps = rng.standard_normal(ntaps).astype(np.float32)
+    x = O.synth_iq(0, 5000, seed=ntaps)
+    y = run_blocks(ops.Fir(taps), x, [2049, 2951])
+    assert np.array_equal(y, O.Fir(taps, acc=O.ACC_FMA).process(x))
+
+
+def test_fir_device_path_and_block_invariance(ops, gold):
+    import torch
+
+    n = 300_000  # 37 tiles of 8192 / 147 tiles of 2048
+    x = O.synth_iq(0, n, seed=7)
+    want = O.Fir(gold["taps256"], acc=O.ACC_FMA).process(x)
+    f = ops.Fir(gold["taps256"])
+    y = f.process(dev(x))
+    torch.cuda.synchronize()
+    assert np.array_equal(y.cpu().numpy(), want)
+    # same stream in three device calls: history carries exactly
+    f2 = ops.Fir(gold["taps256"])
+    xs = dev(x)
+    parts = [f2.process(xs[:100_001]), f2.process(xs[100_001:100_101]), f2.process(xs[100_101:])]
+    assert np.array_equal(torch.cat(parts).cpu().numpy(), want)
+    assert rel_rms(want, O.Fir(gold["taps256"]).process(x)) < 1e-6 < TOL_RMS
+
+
+def test_fir_empty_and_reset_and_history(ops, gold):
+    f = ops.Fir(gold["taps63"])
+    assert len(f.process(np.zeros(0, np.complex64))) == 0
+    assert f.history_len == 62
+    x = gold["x"]
+    a = f.process(x[:500])
+    h = f.get_history()
+    assert np.array_equal(h, x[500 - 62:500])
+    f.reset()
+    assert not f.get_history().any()
+    b = f.process(x[:500])
+    assert np.array_equal(a, b)
+    # halo hand-off: a second filter seeded with the first one's tail continues the stream
+    g = ops.Fir(gold["taps63"])
+    g.set_history(x[1000 - 62:1000])
+    assert rel_rms(g.process(x[1000:2000]), gold["fir_taps63"][1000:2000]) < 1e-6
+
+
+def test_fir_set_taps_keeps_stream(ops, gold):
+    f = ops.Fir(gold["taps63"])
+    x = gold["x"]
+    f.process(x[:1000])
+    f.set_taps(gold["taps63"])  # same length: history must survive (updateWindow, filter.h:43-49)
+    y = f.process(x[1000:2000])
+    assert rel_rms(y, gold["fir_taps63"][1000:2000]) < 1e-6
+
+
+def test_fir_nan_inf_stay_local(ops):
+    """A NaN/Inf input sample only poisons the ntaps outputs whose window holds it."""
+    taps = np.linspace(0.1, 1.0, 10).astype(np.float32)
+    x = np.ones(4096, np.complex64)
+    x[2000] = np.inf
+    y = ops.Fir(taps).process(x)
+    bad = ~np.isfinite(y)
+    assert bad[2000:2010].all() and bad.sum() == 10
+
+
+# ------------------------------------------------------------------------------ resampler
+@pytest.mark.parametrize("LM", [(1, 2), (1, 8), (2, 1), (2, 3), (3, 7)])
+def test_resampler_golden(ops, gold, LM):
+    L, M = LM
+    taps = (gold["taps63"] * L).astype(np.float32)
+    y = run_blocks(ops.Resampler(taps, L, M), gold["x"], [1001, 64, 7, 2000])
+    want = gold[f"rs_{L}_{M}"]
+    assert len(y) == len(want)
+    assert rel_rms(y, want) < 2e-6
+
+
+def test_resampler_256_decim8_and_f32(ops, gold):
+    y = run_blocks(ops.Resampler(gold["taps256"], 1, 8), gold["x"], [1001, 64, 7, 2000])
+    assert rel_rms(y, gold["rs_1_8_t256"]) < 2e-6
+    xr = np.ascontiguousarray(gold["x"].real)
+    y = run_blocks(ops.Resampler(gold["taps63"], 1, 8, complex_data=False), xr, [1001, 64, 7, 2000])
+    assert rel_rms(y, gold["rsf32_1_8"]) < 2e-6
+
+
+@pytest.mark.parametrize("LM", [(1, 1), (1, 3), (1, 5), (1, 10), (1, 16), (1, 17), (1, 64), (5, 1), (7, 4), (160, 147), (3, 1000)])
+def test_resampler_ratios_vs_f64(ops, LM):
+    L, M = LM
+    rng = np.random.default_rng(L * 1000 + M)
+    ntaps = int(rng.integers(5, 300))
+    taps = rng.standard_normal(ntaps).astype(np.float32)
+    x = O.synth_iq(0, 20_000, seed=L + M)
+    sizes = [7001, 12_999]
+    y = run_blocks(ops.Resampler(taps, L, M), x, sizes)
+    w64 = run_blocks(O.Resampler(taps, L, M, acc=O.ACC_F64), x, sizes)
+    w32 = run_blocks(O.Resampler(taps, L, M), x, sizes)
+    assert len(y) == len(w64)
+    assert rel_rms(y, w64) < 1e-6 and rel_rms(y, w32) < 2e-6
+
+
+def test_resampler_both_kernels_agree(ops, gold, monkeypatch):
+    """interp == 1 runs the sliding-window core; QDSP_HIP_FORCE_ANY routes the same config
+    through the general kernel.  Two independent device implementations must agree."""
+    x = gold["x"]
+    a = run_blocks(ops.Resampler(gold["taps256"], 1, 8), x, [3000])
+    monkeypatch.setenv("QDSP_HIP_FORCE_ANY", "1")
+    r = ops.Resampler(gold["taps256"], 1, 8)
+    b = run_blocks(r, x, [3000])
+    assert r.last_kernel()["name"] == "resamp_any_kernel"
+    assert rel_rms(a, b) < 1e-6
+
+
+def test_resampler_zero_output_block_and_phase_restart(ops, gold):
+    r = ops.Resampler(gold["taps63"], 1, 8)
+    assert len(r.process(gold["x"][:7])) == 0   # history still advances
+    o = O.Resampler(gold["taps63"], 1, 8)
+    o.process(gold["x"][:7])
+    assert rel_rms(r.process(gold["x"][7:1007]), o.process(gold["x"][7:1007])) < 2e-6
+    assert np.array_equal(r.get_history(), gold["x"][1007 - 63:1007])
+
+
+# ------------------------------------------------------------------------------ NCO
+@pytest.mark.parametrize("i,fs,f", [(0, 2.4e6, 123456.0), (1, 48000.0, -7000.0)])
+def test_xlator_golden(ops, gold, i, fs, f):
+    sizes = [700, 512, 513, 1]
+    x = gold["x"]
+    xl = ops.Xlator(fs, f)
+    assert xl.phase_inc == (float(gold[f"xl{i}_delta"][0]), float(gold[f"xl{i}_delta"][1]))
+    y = run_blocks(xl, x, sizes)
+    # (a) the reference's recursive float phasor, short calls: float-rounding agreement
+    assert np.abs(y - gold[f"xl{i}_generic"]).max() < 3e-6
+    assert rel_rms(y, gold[f"xl{i}_generic"]) < 1e-6
+    # (b) ideal NCO (no VOLK magnitude sawtooth) against the FP64-phase yardstick
+    xl2 = ops.Xlator(fs, f)
+    xl2.set_volk_gain(False)
+    assert np.abs(run_blocks(xl2, x, sizes) - gold[f"xl{i}_exact"]).max() < 4e-7
+
+
+def test_xlator_long_stream_exact_phase(ops):
+    """1e6 samples in one call: the device NCO stays on the FP64-phase yardstick while the
+    reference's recursion drifts (asserted in tests/test_oracle.py)."""
+    import torch
+
+    n = 1_000_000
+    x = O.synth_iq(0, n, seed=3)
+    xl = ops.Xlator(48000.0, -7000.0)
+    y = xl.process(dev(x)).cpu().numpy()
+    want = O.Xlator(48000.0, -7000.0, exact=True, volk_gain=True).process(x)
+    assert np.abs(y - want).max() < 6e-7
+    # phase state carried like the reference's `phase` member
+    ph = xl.get_phase()
+    t = O.Xlator(48000.0, -7000.0, exact=True)
+    t.process(np.zeros(n, np.complex64))
+    assert abs(ph - np.exp(2j * np.pi * t.turns.value)) < 1e-6
+    # odd lengths / unaligned device pointers take the scalar path
+    xs = dev(x[:10_001])
+    xl3 = ops.Xlator(48000.0, -7000.0)
+    y3 = xl3.process(xs[1:]).cpu().numpy()
+    w3 = O.Xlator(48000.0, -7000.0, exact=True, volk_gain=True).process(x[1:10_001])
+    assert np.abs(y3 - w3).max() < 6e-7
+    torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------------------ fused VFO
+def test_vfo_golden(ops, gold):
+    L, M = (int(v) for v in gold["vfo_ratio"])
+    inc = (float(gold["vfo_delta"][0]), float(gold["vfo_delta"][1]))
+    sizes = [1000, 2000, 10, 2990]
+    v = ops.Vfo(gold["vfo_taps"], L, M, inc)
+    y = run_blocks(v, gold["x"], sizes)
+    assert len(y) == len(gold["vfo_generic"])
+    assert rel_rms(y, gold["vfo_generic"]) < 3e-6   # vs xlator(VOLK generic) -> resampler
+    v2 = ops.Vfo(gold["vfo_taps"], L, M, inc)
+    v2.set_volk_gain(False)
+    assert rel_rms(run_blocks(v2, gold["x"], sizes), gold["vfo_exact"]) < 2e-6
+
+
+def test_vfo_equals_xlator_then_resampler_on_device(ops, gold):
+    """Fusion changes nothing: fused kernel == xlate kernel -> decimator kernel."""
+    x = O.synth_iq(0, 200_000, seed=11)
+    inc = ops.phase_delta(2.4e6, -300e3)
+    for (L, M, taps) in ((1, 8, gold["taps256"]), (1, 10, gold["vfo_taps"]), (2, 3, (gold["taps63"] * 2).astype(np.float32))):
+        fused = np.array(ops.Vfo(taps, L, M, inc).process(x[:100_000]))
+        xl, rs = ops.Xlator(phase_inc=inc), ops.Resampler(taps, L, M)
+        two = np.array(rs.process(np.array(xl.process(x[:100_000]))))
+        assert rel_rms(fused, two) < 5e-7
+
+
+# ------------------------------------------------------------------------------ full-size properties
+def test_full_size_properties(ops, gold):
+    """BASELINE config 2 size (2^26 samples): properties that need no CPU reference run."""
+    import torch
+
+    n = 1 << 26
+    taps = gold["taps256"]
+    x = ops.synth_iq(n, seed=1234)
+    f = ops.Fir(taps)
+    y = f.process(x)
+    torch.cuda.synchronize()
+    # (1) spot windows against the oracle (input regenerated on the host from the same counter)
+    for start in (0, 12_345_678, n - 70_000):
+        lo = max(start - 255, 0)
+        xh = O.synth_iq(lo, 65_536 + (start - lo), seed=1234)
+        assert np.array_equal(x[lo:lo + len(xh)].cpu().numpy(), xh)
+        want = O.Fir(taps, acc=O.ACC_FMA).process(xh)[start - lo:]
+        got = y[start:start + 65_536].cpu().numpy()
+        if start == 0:
+            assert np.array_equal(got, want)
+        else:
+            assert np.array_equal(got[255:], want[255:])
+    # (2) linearity: F(2x) == 2 F(x) exactly (power-of-two scaling commutes with rounding)
+    f.reset()
+    y2 = f.process(x * 2)
+    assert torch.equal(y2, y * 2)
+    # (3) DC gain: constant input -> sum(taps) after the transient
+    f.reset()
+    yc = f.process(torch.full((1 << 20,), 1 + 1j, dtype=torch.complex64, device="cuda"))
+    assert abs(yc[4096].item() - complex(taps.sum(), taps.sum())) < 1e-5
+    # (4) chunk invariance at scale: two halves with carried history == one call
+    f.reset()
+    ya = f.process(x[: n // 2 + 3])
+    yb = f.process(x[n // 2 + 3:])
+    assert torch.equal(torch.cat([ya, yb]), y)
+    # (5) decimator == every 8th sample of the FIR with the resampler's extra sample of delay
+    r = ops.Resampler(taps, 1, 8)
+    yd = r.process(x)
+    torch.cuda.synchronize()
+    assert yd.numel() == n // 8
+    ref = y[7::8][: yd.numel() - 1]          # y_dec[n] = y_fir[8n - 1]
+    d = (yd[1:] - ref).abs().max().item()
+    assert d < 3e-6
