@@ -23,7 +23,8 @@
  *                        follow immediately (src/dsp/filter.h:69).
  *   - `*_process_dev`  : device pointers + a hipStream_t (as void*).  Asynchronous on that
  *                        stream; state (history, NCO phase) is advanced in stream order.
- *                        in/out must not alias.  `stream` NULL = the handle's own stream.
+ *                        in/out must not alias.  `stream` NULL = HIP's default stream.
+ *                        All calls on one handle must be stream-ordered by the caller.
  *   - one `process*` call == one `run()` of the reference block: history carries over
  *     exactly as the reference's memmove does, and the resampler's phase counter restarts
  *     at 0 (src/dsp/resampling.h:114,121).

@@ -72,7 +72,10 @@ struct CoreArgs {
     unsigned long long phase0;  // NCO phase of in[0]            (ROT only)
     unsigned long long dphase;  // NCO phase increment per sample (ROT only)
     double2 rot_nt;             // exp(j*2pi*NT*dphase)           (ROT only)
+    double2 rot_one;            // exp(j*2pi*dphase)              (ROT only)
+    double2 rot_2nt;            // exp(j*2pi*2*NT*dphase)         (ROT only)
     float gm1;                  // |phase_inc| - 1, 0 = ideal NCO  (ROT only)
+    int vec;                    // 1: `in` is 16-byte aligned -> float4 staging of interior tiles
 };
 
 template <int R> __device__ __forceinline__ int slot(int v) {
@@ -88,7 +91,8 @@ template <int R> __device__ __forceinline__ int slot(int v) {
 // Written as M interleaved branch filters (k = q*M + m) so every branch is a unit-stride
 // sliding window: lane t keeps R accumulators for outputs tR..tR+R-1 and a rotating window
 // of R samples; each tap costs one LDS read and R (complex: 2R) FMAs with the tap in an SGPR.
-template <int CH, int R, int NT, bool ROT>
+// MT = compile-time decimation (0: take a.M at run time) so the de-interleave is shifts.
+template <int CH, int R, int NT, bool ROT, int MT>
 __global__ __launch_bounds__(NT) void fir_core_kernel(const CoreArgs a) {
     using T = typename Smp<CH>::T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(NT) void fir_core_kernel(const CoreArgs a) {
     const int t = threadIdx.x;
     const T* __restrict__ in = static_cast<const T*>(a.in);
     const T* __restrict__ hist = static_cast<const T*>(a.hist);
-    const int H = a.H, M = a.M, Q = a.Q;
+    const int H = a.H, M = MT ? MT : a.M, Q = a.Q;
 
     if ((int)blockIdx.x == a.nblocks) {
         // History hand-over (filter.h:71 / resampling.h:129): the last H samples of
@@ -123,7 +127,40 @@ __global__ __launch_bounds__(NT) void fir_core_kernel(const CoreArgs a) {
     const int U = V * M;
 
     // ---- stage hist ++ in (rotated if ROT) into LDS, de-interleaved by branch -----------
-    {
+    auto put = [&](int u, T v) {
+        int m, vv;
+        if (M == 1) { m = 0; vv = u; }
+        else { vv = u / M; m = u - vv * M; }
+        lds[m * a.sb + slot<R>(vv)] = v;
+    };
+    bool staged = false;
+    if constexpr (CH == 2) {
+        // Interior tile (block-uniform test): no history, no end of stream -> unchecked
+        // 16-byte loads, two samples per lane, from the even sample at or below `base`.
+        if (a.vec && base >= 0 && base + U + 2 <= a.count) {
+            const int pre = (int)(base & 1);
+            const float4* __restrict__ in4 = reinterpret_cast<const float4*>(a.in) + ((base - pre) >> 1);
+            const int npairs = (U + pre + 1) >> 1;
+            double2 ph;
+            if (ROT) ph = phasor_fx(a.phase0 + (unsigned long long)(base - pre + 2 * t) * a.dphase);
+#pragma unroll 4
+            for (int j = t; j < npairs; j += NT) {
+                const float4 v = in4[j];
+                float2 s0 = make_float2(v.x, v.y), s1 = make_float2(v.z, v.w);
+                const int u0 = 2 * j - pre;
+                if (ROT) {
+                    const long long g0 = base + u0;
+                    s0 = rotate(s0, ph, g0, a.gm1);
+                    s1 = rotate(s1, cmul(ph, a.rot_one), g0 + 1, a.gm1);
+                    ph = cmul(ph, a.rot_2nt);
+                }
+                if (u0 >= 0) put(u0, s0);
+                if (u0 + 1 < U) put(u0 + 1, s1);
+            }
+            staged = true;
+        }
+    }
+    if (!staged) {
         double2 ph;
         if (ROT) ph = phasor_fx(a.phase0 + (unsigned long long)(base + t) * a.dphase);
         for (int u = t; u < U; u += NT) {
@@ -135,10 +172,7 @@ __global__ __launch_bounds__(NT) void fir_core_kernel(const CoreArgs a) {
                 v = in[g];
                 if (ROT) v = rotate(v, ph, g, a.gm1);
             }
-            int m, vv;
-            if (M == 1) { m = 0; vv = u; }
-            else { vv = u / M; m = u - vv * M; }
-            lds[m * a.sb + slot<R>(vv)] = v;
+            put(u, v);
             if (ROT) ph = cmul(ph, a.rot_nt);
         }
     }

@@ -238,7 +238,7 @@ void destroy(Engine* e) {
 // host copy of qk::slot (must match kernels.hip.h)
 inline int qk_slot_host(int R, int v) { return (R % 2 == 0) ? v + v / R : v; }
 
-template <int CH, int R, int NT, bool ROT>
+template <int CH, int R, int NT, bool ROT, int MT>
 int launch_core_t(Engine* e, qk::CoreArgs& a, hipStream_t s) {
     constexpr int TILE = NT * R;
     const int V = TILE + a.Q;
@@ -252,8 +252,13 @@ int launch_core_t(Engine* e, qk::CoreArgs& a, hipStream_t s) {
     const size_t lds = (size_t)a.M * sb * CH * sizeof(float);
     if (lds > (size_t)kMaxDynLds) return QDSP_HIP_EINVAL;
     a.nblocks = (int)((a.nout + TILE - 1) / TILE);
-    if (ROT) unit_of_fx(a.dphase, (long double)NT, &a.rot_nt.x, &a.rot_nt.y);
-    hipLaunchKernelGGL((qk::fir_core_kernel<CH, R, NT, ROT>), dim3(a.nblocks + 1), dim3(NT), lds, s, a);
+    a.vec = ((uintptr_t)a.in & 15) == 0;
+    if (ROT) {
+        unit_of_fx(a.dphase, (long double)NT, &a.rot_nt.x, &a.rot_nt.y);
+        unit_of_fx(a.dphase, 1.0L, &a.rot_one.x, &a.rot_one.y);
+        unit_of_fx(a.dphase, (long double)(2 * NT), &a.rot_2nt.x, &a.rot_2nt.y);
+    }
+    hipLaunchKernelGGL((qk::fir_core_kernel<CH, R, NT, ROT, MT>), dim3(a.nblocks + 1), dim3(NT), lds, s, a);
     HIPCHK(hipGetLastError());
     e->last.name = "fir_core_kernel";
     e->last.grid = a.nblocks + 1;
@@ -273,15 +278,19 @@ template <int CH, bool ROT> int launch_core(Engine* e, qk::CoreArgs& a, hipStrea
         else if (a.M <= 8) { R = 4; NT = 128; }
         else { R = 4; NT = 64; }
     }
-#define QK_CASE(r, nt) \
-    if (R == r && NT == nt) return launch_core_t<CH, r, nt, ROT>(e, a, s);
-    QK_CASE(8, 256)
-    QK_CASE(16, 256)
-    QK_CASE(4, 256)
-    QK_CASE(8, 128)
-    QK_CASE(4, 128)
-    QK_CASE(4, 64)
-    QK_CASE(2, 64)
+    const int mt = (a.M == 1 || a.M == 2 || a.M == 4 || a.M == 8) ? a.M : 0;
+#define QK_CASE(r, nt, m) \
+    if (R == r && NT == nt && mt == m) return launch_core_t<CH, r, nt, ROT, m>(e, a, s);
+#define QK_GEOM(r, nt) QK_CASE(r, nt, 0) QK_CASE(r, nt, 2) QK_CASE(r, nt, 4) QK_CASE(r, nt, 8)
+    QK_CASE(8, 256, 1)
+    QK_CASE(16, 256, 1)
+    QK_CASE(4, 256, 1)
+    QK_GEOM(8, 256)
+    QK_GEOM(4, 256)
+    QK_GEOM(8, 128)
+    QK_GEOM(4, 128)
+    QK_GEOM(4, 64)
+#undef QK_GEOM
 #undef QK_CASE
     return QDSP_HIP_EINVAL;
 }
@@ -335,7 +344,7 @@ int launch_xlate(Engine* e, const void* d_in, int64_t count, void* d_out, hipStr
 int64_t process_dev(Engine* e, const void* d_in, int64_t count, void* d_out, void* stream) {
     if (count < 0 || (count > 0 && (!d_in || !d_out))) return QDSP_HIP_EINVAL;
     HIPCHK(hipSetDevice(e->device));
-    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : e->stream;
+    hipStream_t s = static_cast<hipStream_t>(stream);  // NULL == HIP's default stream
     const int64_t nout = out_size(e, count);
     int rc = 0;
     if (!e->has_filter) {
@@ -445,7 +454,7 @@ int set_phase(Engine* e, float re, float im) {
 int time_process(Engine* e, const void* d_in, int64_t count, void* d_out, void* stream, int iters, float* ms) {
     if (iters <= 0 || !ms) return QDSP_HIP_EINVAL;
     HIPCHK(hipSetDevice(e->device));
-    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : e->stream;
+    hipStream_t s = static_cast<hipStream_t>(stream);
     HIPCHK(hipEventRecord(e->ev0, s));
     for (int i = 0; i < iters; i++) {
         int64_t r = process_dev(e, d_in, count, d_out, stream);

