@@ -82,6 +82,15 @@ int qdsp_hip_fir_cf32_process_dev(void* h, const void* d_in, int64_t count, void
 /* FIR<T>::updateWindow (filter.h:43-49): new taps; history is kept (resized, newest
  * samples preserved) as the reference keeps its buffer. */
 int qdsp_hip_fir_cf32_set_taps(void* h, const float* taps, int ntaps);
+/* Algorithm choice.  QDSP_HIP_FIR_DIRECT: direct form, taps accumulated in order 0..ntaps-1
+ * with one fused multiply-add each (bit-identical to a k-ordered fmaf chain).
+ * QDSP_HIP_FIR_FFT: 4096-point overlap-save fast convolution (~135 FLOP/sample instead of
+ * 4*ntaps; FP32 FFT rounding, ~3e-7 RMS relative to the direct form).  QDSP_HIP_FIR_AUTO
+ * (default): FFT for >= 48 taps on calls of >= 65536 samples, direct form otherwise. */
+#define QDSP_HIP_FIR_AUTO 0
+#define QDSP_HIP_FIR_DIRECT 1
+#define QDSP_HIP_FIR_FFT 2
+int qdsp_hip_fir_cf32_set_mode(void* h, int mode);
 int qdsp_hip_fir_cf32_reset(void* h);
 /* History access for the multi-GPU halo: `nsamples` = ntaps-1.
  * get/set copy through host memory; history_dev exposes the device buffer that the NEXT
@@ -98,6 +107,7 @@ int qdsp_hip_fir_f32_process(void* h, const float* in, int count, float* out);
 int qdsp_hip_fir_f32_process_dev(void* h, const void* d_in, int64_t count, void* d_out,
                                  void* hip_stream);
 int qdsp_hip_fir_f32_set_taps(void* h, const float* taps, int ntaps);
+int qdsp_hip_fir_f32_set_mode(void* h, int mode); /* accepted; FIR<float> always runs direct form */
 int qdsp_hip_fir_f32_reset(void* h);
 int qdsp_hip_fir_f32_history_len(void* h);
 int qdsp_hip_fir_f32_get_history(void* h, float* hist);

@@ -73,6 +73,7 @@ def load():
         sig(p + "_process", i32, vp, vp, i32, vp)
         sig(p + "_process_dev", i32, vp, vp, i64, vp, vp)
         sig(p + "_set_taps", i32, vp, fp, i32)
+        sig(p + "_set_mode", i32, vp, i32)
     for p in ("qdsp_hip_decim_cf32", "qdsp_hip_decim_f32"):
         sig(p + "_create", i32, pvp, i32, fp, i32, i32, i32, i32)
         sig(p + "_process", i32, vp, vp, i32, vp)

@@ -3,6 +3,7 @@
 // library: without a HIP device every entry point returns an error.
 #include "../../include/qdsp_hip.h"
 #include "kernels.hip.h"
+#include "fft_fir.hip.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -61,6 +62,13 @@ struct Engine {
     int max_block = 0;
     size_t out_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // overlap-save fast convolution (FIR<complex_t> with many taps), fft_fir.hip.h
+    int fir_mode = 0;           // 0 auto, 1 direct form, 2 overlap-save FFT
+    float2* d_fft_H = nullptr;  // spectrum of the reversed taps / F, digit-reversed
+    float2* d_fft_TA = nullptr;
+    float2* d_fft_TB = nullptr;
+    int fft_ntaps = -1;         // tap count d_fft_H was built for (-1: not built)
+    std::vector<float> taps_host;
     // tuning / introspection
     int R = 0, NT = 0;          // 0 = pick automatically
     Launch last;
@@ -143,6 +151,8 @@ int configure(Engine* e, const float* taps, int ntaps, int interp, int decim) {
     const int newH = (e->kind == KIND_FIR) ? ntaps - 1 : e->P;
     int rc = upload_taps(e, taps, ntaps);
     if (rc) return rc;
+    e->taps_host.assign(taps, taps + ntaps);
+    e->fft_ntaps = -1;
     const size_t bytes = (size_t)(newH > 0 ? newH : 1) * e->ch * sizeof(float);
     float* nh[2] = {nullptr, nullptr};
     for (int i = 0; i < 2; i++) {
@@ -222,6 +232,9 @@ void destroy(Engine* e) {
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     if (e->d_taps) (void)hipFree(e->d_taps);
+    if (e->d_fft_H) (void)hipFree(e->d_fft_H);
+    if (e->d_fft_TA) (void)hipFree(e->d_fft_TA);
+    if (e->d_fft_TB) (void)hipFree(e->d_fft_TB);
     for (int i = 0; i < 2; i++)
         if (e->d_hist[i]) (void)hipFree(e->d_hist[i]);
     if (e->d_in) (void)hipFree(e->d_in);
@@ -315,6 +328,86 @@ template <int CH, bool ROT> int launch_any(Engine* e, qk::AnyArgs& a, hipStream_
     return 0;
 }
 
+// ---- overlap-save FFT FIR -------------------------------------------------------------------
+constexpr int kFftMaxTaps = 2049;   // keeps >= 2048 valid outputs per 4096-point block
+
+bool fft_eligible(const Engine* e, int64_t count) {
+    if (e->kind != KIND_FIR || e->ch != 2) return false;
+    if (e->ntaps < 2 || e->ntaps > kFftMaxTaps) return false;
+    int mode = e->fir_mode ? e->fir_mode : env_int("QDSP_HIP_FIR_MODE", 0);
+    if (mode == 1) return false;
+    if (mode == 2) return true;
+    // auto: long filters on blocks big enough to fill the chip with 4096-point segments
+    return e->ntaps >= env_int("QDSP_HIP_FFT_MIN_TAPS", 48) && count >= env_int("QDSP_HIP_FFT_MIN_COUNT", 1 << 16);
+}
+
+int fft_prepare(Engine* e) {
+    if (e->fft_ntaps == e->ntaps && e->d_fft_H) return 0;
+    constexpr int F = qk::kFftN;
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    std::vector<long double> cs(F), sn(F);
+    for (int i = 0; i < F; i++) {
+        cs[i] = cosl(two_pi * (long double)i / F);
+        sn[i] = sinl(two_pi * (long double)i / F);
+    }
+    const int N = e->ntaps;
+    // g[j] = taps[N-1-j]:  y[n] = sum_j g[j] s[n-j];  Hf[k] = sum_j g[j] exp(-j 2pi jk/F) / F
+    std::vector<float2> Hp(F), TA(256 * 16), TB(16 * 16);
+    for (int k = 0; k < F; k++) {
+        long double re = 0.0L, im = 0.0L;
+        for (int j = 0; j < N; j++) {
+            const long double gj = (long double)e->taps_host[N - 1 - j];
+            const int idx = (int)(((long long)j * k) % F);
+            re += gj * cs[idx];
+            im -= gj * sn[idx];
+        }
+        const int k0 = k & 15, k1 = (k >> 4) & 15, k2 = k >> 8;
+        Hp[(k0 * 16 + k1) * 16 + k2] = make_float2((float)(re / F), (float)(im / F));
+    }
+    for (int t = 0; t < 256; t++)
+        for (int k = 0; k < 16; k++) TA[t * 16 + k] = make_float2((float)cs[(t * k) % F], (float)(-sn[(t * k) % F]));
+    for (int lo = 0; lo < 16; lo++)
+        for (int k = 0; k < 16; k++) TB[lo * 16 + k] = make_float2((float)cs[(16 * lo * k) % F], (float)(-sn[(16 * lo * k) % F]));
+    if (!e->d_fft_H) {
+        HIPCHK(hipMalloc(&e->d_fft_H, sizeof(float2) * F));
+        HIPCHK(hipMalloc(&e->d_fft_TA, sizeof(float2) * 256 * 16));
+        HIPCHK(hipMalloc(&e->d_fft_TB, sizeof(float2) * 16 * 16));
+        HIPCHK(hipMemcpy(e->d_fft_TA, TA.data(), sizeof(float2) * TA.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(e->d_fft_TB, TB.data(), sizeof(float2) * TB.size(), hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMemcpy(e->d_fft_H, Hp.data(), sizeof(float2) * F, hipMemcpyHostToDevice));
+    e->fft_ntaps = N;
+    return 0;
+}
+
+int launch_fft(Engine* e, const void* d_in, int64_t count, void* d_out, hipStream_t s) {
+    int rc = fft_prepare(e);
+    if (rc) return rc;
+    qk::FftArgs a;
+    a.in = static_cast<const float2*>(d_in);
+    a.out = static_cast<float2*>(d_out);
+    a.hist = reinterpret_cast<const float2*>(e->d_hist[e->cur]);
+    a.hist_next = reinterpret_cast<float2*>(e->d_hist[e->cur ^ 1]);
+    a.Hf = e->d_fft_H;
+    a.TA = e->d_fft_TA;
+    a.TB = e->d_fft_TB;
+    a.count = count;
+    a.H = e->H;
+    a.L = qk::kFftN - e->H;
+    a.nblocks = (int)((count + a.L - 1) / a.L);
+    const int per_cu = env_int("QDSP_HIP_FFT_WG_PER_CU", 3);
+    int nwg = 256 * per_cu;
+    if (nwg > a.nblocks) nwg = a.nblocks;
+    a.nwg = nwg;
+    hipLaunchKernelGGL(qk::fir_fft_kernel, dim3(nwg + 1), dim3(qk::kFftNT), 0, s, a);
+    HIPCHK(hipGetLastError());
+    e->last.name = "fir_fft_kernel";
+    e->last.grid = nwg + 1;
+    e->last.block = qk::kFftNT;
+    e->last.lds = (int)(qk::kFftLdsElems * sizeof(float2));
+    return 0;
+}
+
 int launch_xlate(Engine* e, const void* d_in, int64_t count, void* d_out, hipStream_t s) {
     constexpr int NT = 256;
     if (count <= 0) return 0;
@@ -349,6 +442,9 @@ int64_t process_dev(Engine* e, const void* d_in, int64_t count, void* d_out, voi
     int rc = 0;
     if (!e->has_filter) {
         rc = launch_xlate(e, d_in, count, d_out, s);
+    } else if (fft_eligible(e, count)) {
+        rc = launch_fft(e, d_in, count, d_out, s);
+        if (rc == 0) e->cur ^= 1;
     } else if (use_core(e)) {
         qk::CoreArgs a;
         memset(&a, 0, sizeof(a));
@@ -575,6 +671,12 @@ int qdsp_hip_device_sync(int device) { HIPCHK(hipSetDevice(device)); HIPCHK(hipD
     int prefix##_set_taps(void* h, const float* taps, int ntaps) {                                \
         Engine* e = as_engine(h, KIND_FIR);                                                       \
         return e ? configure(e, taps, ntaps, 1, 1) : QDSP_HIP_EINVAL;                             \
+    }                                                                                             \
+    int prefix##_set_mode(void* h, int mode) {                                                    \
+        Engine* e = as_engine(h, KIND_FIR);                                                       \
+        if (!e || mode < 0 || mode > 2) return QDSP_HIP_EINVAL;                                   \
+        e->fir_mode = mode;                                                                       \
+        return 0;                                                                                 \
     }                                                                                             \
     QDSP_FILTER_COMMON(prefix, KIND_FIR)
 

@@ -124,11 +124,13 @@ def test_fir_device_path_and_block_invariance(ops, gold):
     x = O.synth_iq(0, n, seed=7)
     want = O.Fir(gold["taps256"], acc=O.ACC_FMA).process(x)
     f = ops.Fir(gold["taps256"])
+    f.set_mode(f.DIRECT)
     y = f.process(dev(x))
     torch.cuda.synchronize()
     assert np.array_equal(y.cpu().numpy(), want)
     # same stream in three device calls: history carries exactly
     f2 = ops.Fir(gold["taps256"])
+    f2.set_mode(f2.DIRECT)
     xs = dev(x)
     parts = [f2.process(xs[:100_001]), f2.process(xs[100_001:100_101]), f2.process(xs[100_101:])]
     assert np.array_equal(torch.cat(parts).cpu().numpy(), want)
@@ -170,6 +172,79 @@ def test_fir_nan_inf_stay_local(ops):
     y = ops.Fir(taps).process(x)
     bad = ~np.isfinite(y)
     assert bad[2000:2010].all() and bad.sum() == 10
+
+
+# ------------------------------------------------------------------------------ FIR, overlap-save FFT path
+TOL_FFT = 2e-6  # measured ~3e-7; FP32 4096-point FFT pair vs k-ordered FP32 sum
+
+
+@pytest.mark.parametrize("ntaps", [2, 3, 24, 63, 64, 255, 256, 257, 1000, 2049])
+def test_fft_fir_vs_oracle(ops, ntaps):
+    rng = np.random.default_rng(100 + ntaps)
+    taps = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    n = 50_000
+    x = O.synth_iq(0, n, seed=ntaps)
+    f = ops.Fir(taps)
+    f.set_mode(f.FFT)
+    sizes = [20_001, 4097, 1, 3000, 22_901]   # ragged calls: partial blocks, calls shorter than the history
+    y = run_blocks(f, x, sizes)
+    assert f.last_kernel()["name"] == "fir_fft_kernel"
+    w64 = O.Fir(taps, acc=O.ACC_F64).process(x)
+    w32 = O.Fir(taps).process(x)
+    assert rel_rms(y, w64) < TOL_FFT and rel_rms(y, w32) < TOL_FFT < TOL_RMS
+    assert np.abs(y - w64).max() < 2e-5 * np.abs(w64).max()
+    assert np.array_equal(f.get_history(), x[n - (ntaps - 1):]) if ntaps > 1 else True
+
+
+def test_fft_fir_golden_and_auto_mode(ops, gold):
+    import torch
+
+    n = 400_000
+    x = O.synth_iq(0, n, seed=21)
+    taps = gold["taps256"]
+    f = ops.Fir(taps)           # AUTO: 256 taps, >= 65536 samples per call -> FFT
+    y = f.process(dev(x))
+    torch.cuda.synchronize()
+    assert f.last_kernel()["name"] == "fir_fft_kernel"
+    want = O.Fir(taps).process(x)
+    assert rel_rms(y.cpu().numpy(), want) < TOL_FFT
+    # small calls stay on the direct form (bit-exact) and share the same history
+    y2 = f.process(dev(x[:1000]))
+    assert f.last_kernel()["name"] == "fir_core_kernel"
+    o = O.Fir(taps, acc=O.ACC_FMA)
+    o.process(x)
+    assert np.array_equal(y2.cpu().numpy(), o.process(x[:1000]))
+    # impulse response through the FFT path == taps reversed in time (newest sample * taps[N-1])
+    imp = np.zeros(70_000, np.complex64)
+    imp[5000] = 1.0
+    g = ops.Fir(taps)
+    g.set_mode(g.FFT)
+    r = g.process(imp)
+    assert np.abs(r[5000:5256].real - taps[::-1]).max() < 1e-7
+    assert np.abs(r[:5000]).max() < 1e-8 and np.abs(r[5256:]).max() < 1e-8
+
+
+def test_fft_fir_chunk_invariance_and_linearity(ops, gold):
+    import torch
+
+    n = 1 << 22
+    x = ops.synth_iq(n, seed=5)
+    f = ops.Fir(gold["taps256"])
+    f.set_mode(f.FFT)
+    y = f.process(x)
+    f.reset()
+    ya = f.process(x[: n // 2 + 3])
+    yb = f.process(x[n // 2 + 3:])
+    d = (torch.cat([ya, yb]) - y).abs().max().item()
+    assert d < 2e-6   # different block alignment -> different rounding, same filter
+    f.reset()
+    assert torch.equal(f.process(x * 2), y * 2)      # power-of-two scaling is exact
+    d2 = ops.Fir(gold["taps256"])
+    d2.set_mode(d2.DIRECT)
+    yd = d2.process(x)
+    num = (y - yd).abs().pow(2).mean().sqrt().item()
+    den = yd.abs().pow(2).mean().sqrt().item()
+    assert num / den < TOL_FFT
 
 
 # ------------------------------------------------------------------------------ resampler
@@ -308,6 +383,7 @@ def test_full_size_properties(ops, gold):
     taps = gold["taps256"]
     x = ops.synth_iq(n, seed=1234)
     f = ops.Fir(taps)
+    f.set_mode(f.DIRECT)
     y = f.process(x)
     torch.cuda.synchronize()
     # (1) spot windows against the oracle (input regenerated on the host from the same counter)
