@@ -1,0 +1,106 @@
+// dsp/filter.h -- dsp::FIR<T>, HIP-backed.
+//
+// Drop-in for the reference block (src/dsp/filter.h:9-88): same constructors, init(),
+// setInput(), updateWindow(), run() and public `out`.  What run() does between
+// `_in->read()` and `out.swap()` -- the per-sample VOLK dot products over a history-prefixed
+// buffer (filter.h:55-71) -- is one call into libqdsp_hip (qdsp_hip_fir_{cf32,f32}_process):
+// the block's history lives on the GPU, the stream buffers are pinned so the call DMAs
+// straight from readBuf and into writeBuf.  T = complex_t or float.
+#pragma once
+#include <cstdio>
+#include <type_traits>
+#include <vector>
+
+#include "block.h"
+#include "window.h"
+
+namespace dsp {
+
+namespace detail {
+inline int hipDeviceForBlocks() {
+    const char* s = getenv("QDSP_HIP_DEVICE");
+    return s ? atoi(s) : 0;
+}
+// Blocks have no error channel (reference: int >= 0 / -1 only, block.h:55-57); a failing
+// GPU call is reported once on stderr and ends the worker loop like a stop would.
+inline int hipBlockFail(const char* who, int rc) {
+    fprintf(stderr, "[qdsp_hip] %s: %s (%d)\n", who, qdsp_hip_error_string(rc), rc);
+    return -1;
+}
+}  // namespace detail
+
+template <class T>
+class FIR : public generic_block<FIR<T>> {
+    static_assert(std::is_same<T, complex_t>::value || std::is_same<T, float>::value, "FIR<T>: T is complex_t or float");
+    using base = generic_block<FIR<T>>;
+    static constexpr bool kComplex = std::is_same<T, complex_t>::value;
+
+public:
+    FIR() {}
+    FIR(stream<T>* in, dsp::filter_window::generic_window* window) { init(in, window); }
+
+    ~FIR() {
+        base::stop();
+        if (handle) { kComplex ? qdsp_hip_fir_cf32_destroy(handle) : qdsp_hip_fir_f32_destroy(handle); }
+    }
+
+    void init(stream<T>* in, dsp::filter_window::generic_window* window) {
+        _in = in;
+        loadTaps(window);
+        const int dev = detail::hipDeviceForBlocks();
+        const int rc = kComplex ? qdsp_hip_fir_cf32_create(&handle, dev, taps.data(), (int)taps.size(), STREAM_BUFFER_SIZE)
+                                : qdsp_hip_fir_f32_create(&handle, dev, taps.data(), (int)taps.size(), STREAM_BUFFER_SIZE);
+        if (rc != 0) { handle = nullptr; detail::hipBlockFail("FIR::init", rc); }
+        base::registerInput(_in);
+        base::registerOutput(&out);
+    }
+
+    void setInput(stream<T>* in) {
+        std::lock_guard<std::mutex> lck(base::ctrlMtx);
+        base::tempStop();
+        base::unregisterInput(_in);
+        _in = in;
+        base::registerInput(_in);
+        base::tempStart();
+    }
+
+    // As in the reference, the caller stops the block around this (filter.h:43-49 takes no lock).
+    void updateWindow(dsp::filter_window::generic_window* window) {
+        loadTaps(window);
+        if (!handle) { return; }
+        const int rc = kComplex ? qdsp_hip_fir_cf32_set_taps(handle, taps.data(), (int)taps.size())
+                                : qdsp_hip_fir_f32_set_taps(handle, taps.data(), (int)taps.size());
+        if (rc != 0) { detail::hipBlockFail("FIR::updateWindow", rc); }
+    }
+
+    int run() override {
+        const int count = _in->read();
+        if (count < 0) { return -1; }
+        if (!handle) { return -1; }
+        const int rc = kComplex
+            ? qdsp_hip_fir_cf32_process(handle, reinterpret_cast<const float*>(_in->readBuf), count, reinterpret_cast<float*>(out.writeBuf))
+            : qdsp_hip_fir_f32_process(handle, reinterpret_cast<const float*>(_in->readBuf), count, reinterpret_cast<float*>(out.writeBuf));
+        _in->flush();
+        if (rc != 0) { return detail::hipBlockFail("FIR::run", rc); }
+        if (!out.swap(count)) { return -1; }
+        return count;
+    }
+
+    stream<T> out;
+
+private:
+    void loadTaps(dsp::filter_window::generic_window* window) {
+        _window = window;
+        const int n = window->getTapCount();
+        taps.assign(n > 0 ? (size_t)n + 1 : 1, 0.0f);  // +1: RRCTaps may write taps[n] for even n
+        window->createTaps(taps.data(), n);
+        taps.resize(n > 0 ? n : 0);
+    }
+
+    stream<T>* _in = nullptr;
+    dsp::filter_window::generic_window* _window = nullptr;
+    std::vector<float> taps;
+    void* handle = nullptr;
+};
+
+}  // namespace dsp

@@ -1,0 +1,127 @@
+// dsp/stream.h -- the two-buffer hand-off channel between blocks.
+//
+// Same public surface and protocol as the reference's dsp::stream<T>
+// (src/dsp/stream.h:10-19 untyped_steam, :21-125 stream<T>):
+//     producer: fill writeBuf[0..n) ; swap(n)   -- blocks until the consumer flushed the
+//               previous block, exchanges the two buffers, wakes the consumer; false = stopping
+//     consumer: n = read()                      -- blocks for data; -1 = stopping
+//               ... use readBuf[0..n) ... ; flush()
+// Exactly one block is in flight per stream; capacity is STREAM_BUFFER_SIZE elements per
+// buffer.  What differs from the reference is only where the buffers live: they are pinned
+// host memory (qdsp_hip_host_alloc) instead of volk_malloc, so a HIP-backed block can DMA
+// straight out of readBuf and into writeBuf; when no HIP runtime is usable they fall back
+// to ordinary aligned memory (the channel itself needs no GPU).
+#pragma once
+#include <condition_variable>
+#include <cstdlib>
+#include <mutex>
+
+#include "qdsp_hip.h"
+
+#define STREAM_BUFFER_SIZE 1000000
+
+namespace dsp {
+
+// (sic) the reference spells it this way; blocks register streams through this base.
+class untyped_steam {
+public:
+    virtual ~untyped_steam() {}
+    virtual bool swap(int size) { (void)size; return false; }
+    virtual int read() { return -1; }
+    virtual void flush() {}
+    virtual void stopWriter() {}
+    virtual void clearWriteStop() {}
+    virtual void stopReader() {}
+    virtual void clearReadStop() {}
+};
+
+namespace detail {
+struct stream_mem {
+    static void* get(size_t bytes, bool& pinned) {
+        void* p = nullptr;
+        if (qdsp_hip_host_alloc(&p, bytes) == 0 && p) { pinned = true; return p; }
+        pinned = false;
+        if (posix_memalign(&p, 64, bytes) != 0) { return nullptr; }
+        return p;
+    }
+    static void put(void* p, bool pinned) {
+        if (!p) { return; }
+        if (pinned) { qdsp_hip_host_free(p); } else { free(p); }
+    }
+};
+}  // namespace detail
+
+template <class T>
+class stream : public untyped_steam {
+public:
+    stream() {
+        writeBuf = static_cast<T*>(detail::stream_mem::get(sizeof(T) * STREAM_BUFFER_SIZE, pinnedW));
+        readBuf = static_cast<T*>(detail::stream_mem::get(sizeof(T) * STREAM_BUFFER_SIZE, pinnedR));
+    }
+
+    ~stream() {
+        // the two pointers have been exchanged an unknown number of times; each carries its flag
+        detail::stream_mem::put(writeBuf, pinnedW);
+        detail::stream_mem::put(readBuf, pinnedR);
+    }
+
+    stream(const stream&) = delete;
+    stream& operator=(const stream&) = delete;
+
+    bool swap(int size) override {
+        std::unique_lock<std::mutex> lk(mtx);
+        cv.wait(lk, [this] { return slotFree || writerStopped; });
+        if (writerStopped) { return false; }
+        T* t = writeBuf; writeBuf = readBuf; readBuf = t;
+        bool p = pinnedW; pinnedW = pinnedR; pinnedR = p;
+        pending = size;
+        slotFree = false;
+        hasData = true;
+        lk.unlock();
+        cv.notify_all();
+        return true;
+    }
+
+    int read() override {
+        std::unique_lock<std::mutex> lk(mtx);
+        cv.wait(lk, [this] { return hasData || readerStopped; });
+        return readerStopped ? -1 : pending;
+    }
+
+    void flush() override {
+        {
+            std::lock_guard<std::mutex> lk(mtx);
+            hasData = false;
+            slotFree = true;
+        }
+        cv.notify_all();
+    }
+
+    void stopWriter() override { setFlag(writerStopped, true); }
+    void clearWriteStop() override { setFlag(writerStopped, false); }
+    void stopReader() override { setFlag(readerStopped, true); }
+    void clearReadStop() override { setFlag(readerStopped, false); }
+
+    T* writeBuf;
+    T* readBuf;
+
+private:
+    void setFlag(bool& f, bool v) {
+        {
+            std::lock_guard<std::mutex> lk(mtx);
+            f = v;
+        }
+        cv.notify_all();
+    }
+
+    std::mutex mtx;
+    std::condition_variable cv;
+    bool slotFree = true;      // consumer has released the read buffer (reference: canSwap)
+    bool hasData = false;      // a swapped block is waiting to be read (reference: dataReady)
+    bool writerStopped = false;
+    bool readerStopped = false;
+    int pending = 0;
+    bool pinnedW = false, pinnedR = false;
+};
+
+}  // namespace dsp

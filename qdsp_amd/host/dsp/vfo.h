@@ -1,0 +1,184 @@
+// dsp/vfo.h -- dsp::VFO: frequency-translate by -offset, low-pass, resample.
+//
+// Same public surface as the reference (src/dsp/vfo.h:15-101): init(), start()/stop(), the
+// rate / offset / bandwidth setters and `stream<complex_t>* out`.  The reference builds it
+// from two blocks on two threads, FrequencyXlator -> (stream hop) -> PolyphaseResampler
+// (vfo.h:28-35); here ONE block runs ONE fused kernel (qdsp_hip_xlate_fir_decim_cf32_*):
+// the rotation is applied while the tile is staged into LDS, then the polyphase dot
+// products run.  Filter design is the reference's: BlackmanWindow with cutoff =
+// transition = min(bandWidth, inSR, outSR)/2 at sample rate inSR*interp (vfo.h:26-33).
+//
+// (The reference never sets its `running` flag, so its VFO::stop() is a no-op and its
+// setters never pause the blocks; this one tracks the flag properly.)
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+#include <vector>
+
+#include "block.h"
+#include "filter.h"
+#include "window.h"
+
+namespace dsp {
+
+namespace detail {
+// The fused worker: reads IQ, writes translated + resampled IQ.
+class XlatingResampler : public generic_block<XlatingResampler> {
+    using base = generic_block<XlatingResampler>;
+
+public:
+    XlatingResampler() {}
+    ~XlatingResampler() {
+        base::stop();
+        if (handle) { qdsp_hip_xlate_fir_decim_cf32_destroy(handle); }
+    }
+
+    void init(stream<complex_t>* in, const std::vector<float>& taps, int interp, int decim, float dRe, float dIm) {
+        _in = in;
+        const int rc = qdsp_hip_xlate_fir_decim_cf32_create(&handle, hipDeviceForBlocks(), taps.data(), (int)taps.size(), interp,
+                                                            decim, dRe, dIm, STREAM_BUFFER_SIZE);
+        if (rc != 0) { handle = nullptr; hipBlockFail("VFO::init", rc); }
+        base::registerInput(_in);
+        base::registerOutput(&out);
+    }
+
+    void configure(const std::vector<float>& taps, int interp, int decim) {
+        std::lock_guard<std::mutex> lck(base::ctrlMtx);
+        base::tempStop();
+        if (handle) {
+            const int rc = qdsp_hip_xlate_fir_decim_cf32_configure(handle, taps.data(), (int)taps.size(), interp, decim);
+            if (rc != 0) { hipBlockFail("VFO::configure", rc); }
+        }
+        base::tempStart();
+    }
+
+    void setPhaseInc(float dRe, float dIm) {
+        if (handle) { qdsp_hip_xlate_fir_decim_cf32_set_phase_inc(handle, dRe, dIm); }
+    }
+
+    int run() override {
+        const int count = _in->read();
+        if (count < 0) { return -1; }
+        if (!handle) { return -1; }
+        const int outCount = qdsp_hip_xlate_fir_decim_cf32_process(handle, reinterpret_cast<const float*>(_in->readBuf), count,
+                                                                   reinterpret_cast<float*>(out.writeBuf));
+        _in->flush();
+        if (outCount < 0) { return hipBlockFail("VFO::run", outCount); }
+        if (!out.swap(outCount)) { return -1; }
+        return count;
+    }
+
+    stream<complex_t> out;
+
+private:
+    stream<complex_t>* _in = nullptr;
+    void* handle = nullptr;
+};
+}  // namespace detail
+
+class VFO {
+public:
+    VFO() {}
+    ~VFO() { stop(); }
+
+    VFO(stream<complex_t>* in, float offset, float inSampleRate, float outSampleRate, float bandWidth) {
+        init(in, offset, inSampleRate, outSampleRate, bandWidth);
+    }
+
+    void init(stream<complex_t>* in, float offset, float inSampleRate, float outSampleRate, float bandWidth) {
+        _in = in;
+        _offset = offset;
+        _inSampleRate = inSampleRate;
+        _outSampleRate = outSampleRate;
+        _bandWidth = bandWidth;
+        // the reference's first design pass (win at inSR) only serves to size things; the
+        // taps that run come from the second one at inSR*interp (vfo.h:29-33)
+        redesign();
+        float dRe, dIm;
+        delta(dRe, dIm);
+        core.init(_in, taps, _interp, _decim, dRe, dIm);
+        out = &core.out;
+    }
+
+    void start() {
+        if (running) { return; }
+        core.start();
+        running = true;
+    }
+
+    void stop() {
+        if (!running) { return; }
+        core.stop();
+        running = false;
+    }
+
+    void setInSampleRate(float inSampleRate) {
+        _inSampleRate = inSampleRate;
+        redesign();
+        float dRe, dIm;
+        delta(dRe, dIm);
+        core.setPhaseInc(dRe, dIm);
+        core.configure(taps, _interp, _decim);
+    }
+
+    void setOutSampleRate(float outSampleRate) {
+        _outSampleRate = outSampleRate;
+        redesign();
+        core.configure(taps, _interp, _decim);
+    }
+
+    void setOutSampleRate(float outSampleRate, float bandWidth) {
+        _outSampleRate = outSampleRate;
+        _bandWidth = bandWidth;
+        redesign();
+        core.configure(taps, _interp, _decim);
+    }
+
+    void setOffset(float offset) {
+        _offset = offset;
+        float dRe, dIm;
+        delta(dRe, dIm);
+        core.setPhaseInc(dRe, dIm);
+    }
+
+    void setBandwidth(float bandWidth) {
+        _bandWidth = bandWidth;
+        redesign();
+        core.configure(taps, _interp, _decim);
+    }
+
+    int getInterpolation() const { return _interp; }
+    int getDecimation() const { return _decim; }
+    const std::vector<float>& getTaps() const { return taps; }
+
+    stream<complex_t>* out = nullptr;
+
+private:
+    void redesign() {
+        const int g = std::gcd((int)_inSampleRate, (int)_outSampleRate);  // resampling.h:28-30
+        _interp = _outSampleRate / g;
+        _decim = _inSampleRate / g;
+        const float realCutoff = std::min<float>(_bandWidth, std::min<float>(_inSampleRate, _outSampleRate)) / 2.0f;
+        win.init(realCutoff, realCutoff, _inSampleRate * _interp);
+        const int n = win.getTapCount();
+        taps.assign((size_t)n, 0.0f);
+        win.createTaps(taps.data(), n, _interp);
+    }
+
+    void delta(float& dRe, float& dIm) const {
+        const float theta = (-_offset / _inSampleRate) * 2.0f * FL_M_PI;  // xlator.init(_in, inSR, -offset), vfo.h:28
+        dRe = std::cos(theta);
+        dIm = std::sin(theta);
+    }
+
+    bool running = false;
+    float _offset = 0, _inSampleRate = 1, _outSampleRate = 1, _bandWidth = 1;
+    int _interp = 1, _decim = 1;
+    filter_window::BlackmanWindow win;
+    std::vector<float> taps;
+    stream<complex_t>* _in = nullptr;
+    detail::XlatingResampler core;
+};
+
+}  // namespace dsp

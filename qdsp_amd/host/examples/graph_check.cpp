@@ -1,0 +1,264 @@
+// graph_check -- drives the C++ block graph (qdsp_amd/host/dsp) from the command line so
+// the tests can compare what comes out of a real source -> block -> sink graph with the
+// CPU oracle.  Not part of the product; a harness.
+//
+//   graph_check taps   <out.f32>                      window designers -> tap tables (no GPU)
+//   graph_check stream                                stream/block protocol self-test (no GPU)
+//   graph_check fir    <in.cf32> <out.cf32> <block> <taps.f32>
+//   graph_check fir63  <in.cf32> <out.cf32> <block>   BlackmanWindow(0.1 fs, 4 fs/63, fs=1)
+//   graph_check firf   <in.f32>  <out.f32>  <block> <taps.f32>          (FIR<float>)
+//   graph_check resamp <in.cf32> <out.cf32> <block> <inSR> <outSR> <cutoff> <trans>
+//   graph_check xlate  <in.cf32> <out.cf32> <block> <sampleRate> <freq>
+//   graph_check vfo    <in.cf32> <out.cf32> <block> <offset> <inSR> <outSR> <bw>
+//   graph_check wavfir <in.wav>  <out.cf32> <block>   config 1: int16 IQ WAV -> 63-tap FIR
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <dsp/filter.h>
+#include <dsp/processing.h>
+#include <dsp/resampling.h>
+#include <dsp/sink.h>
+#include <dsp/source.h>
+#include <dsp/vfo.h>
+#include <wavreader.h>
+
+using namespace dsp;
+
+template <class T> static std::vector<T> readAll(const char* path) {
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f) { fprintf(stderr, "cannot open %s\n", path); exit(2); }
+    const size_t bytes = (size_t)f.tellg();
+    f.seekg(0);
+    std::vector<T> v(bytes / sizeof(T));
+    f.read(reinterpret_cast<char*>(v.data()), (std::streamsize)(v.size() * sizeof(T)));
+    return v;
+}
+
+// taps handed in through the reference's own extension point (window.h:7-11)
+class FileTaps : public filter_window::generic_window {
+public:
+    explicit FileTaps(const char* path) : t(readAll<float>(path)) {}
+    int getTapCount() override { return (int)t.size(); }
+    void createTaps(float* taps, int tapCount, float factor = 1.0f) override {
+        for (int i = 0; i < tapCount; i++) { taps[i] = t[i] * factor; }
+    }
+private:
+    std::vector<float> t;
+};
+
+template <class T> struct Feed {
+    std::vector<T> data;
+    size_t pos = 0;
+    int block = 1;
+    static int pull(T* dst, void* ctx) {
+        Feed* f = static_cast<Feed*>(ctx);
+        if (f->pos >= f->data.size()) { return -1; }
+        const size_t n = std::min<size_t>((size_t)f->block, f->data.size() - f->pos);
+        memcpy(dst, f->data.data() + f->pos, n * sizeof(T));
+        f->pos += n;
+        return (int)n;
+    }
+};
+
+template <class T> struct Collect {
+    std::vector<T> data;
+    std::atomic<long> blocks{0};
+    static void push(T* src, int count, void* ctx) {
+        Collect* c = static_cast<Collect*>(ctx);
+        c->data.insert(c->data.end(), src, src + count);
+        c->blocks++;
+    }
+};
+
+// source -> BLOCK -> sink; waits until every input block has come out the far end.
+template <class T, class MAKE> static int runGraph(const char* inPath, const char* outPath, int block, MAKE make) {
+    Feed<T> feed;
+    feed.data = readAll<T>(inPath);
+    feed.block = block;
+    const long nblocks = (long)((feed.data.size() + block - 1) / block);
+    Collect<T> sinkData;
+    HandlerSource<T> src(Feed<T>::pull, &feed);
+    auto* blk = make(&src.out);
+    HandlerSink<T> sink(&blk->out, Collect<T>::push, &sinkData);
+    sink.start();
+    blk->start();
+    src.start();
+    const auto t0 = std::chrono::steady_clock::now();
+    while (sinkData.blocks.load() < nblocks) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) { fprintf(stderr, "graph timed out\n"); return 3; }
+    }
+    src.stop();
+    blk->stop();
+    sink.stop();
+    delete blk;
+    std::ofstream o(outPath, std::ios::binary);
+    o.write(reinterpret_cast<const char*>(sinkData.data.data()), (std::streamsize)(sinkData.data.size() * sizeof(T)));
+    printf("graph ok: %zu in, %zu out, %ld blocks\n", feed.data.size(), sinkData.data.size(), nblocks);
+    return 0;
+}
+
+static int dumpTaps(const char* outPath) {
+    std::ofstream o(outPath, std::ios::binary);
+    auto dump = [&](filter_window::generic_window& w, float factor) {
+        const int n = w.getTapCount();
+        std::vector<float> t((size_t)n + 1, 0.0f);
+        w.createTaps(t.data(), n, factor);
+        const float fn = (float)n;
+        o.write(reinterpret_cast<const char*>(&fn), 4);
+        o.write(reinterpret_cast<const char*>(t.data()), 4 * n);
+    };
+    filter_window::BlackmanWindow a(0.1f, 4.0f / 63.0f, 1.0f);
+    dump(a, 1.0f);
+    filter_window::BlackmanBandpassWindow b(0.05f, 4.0f / 63.0f, 0.2f, 1.0f);
+    dump(b, 1.0f);
+    RRCTaps c(31, 4.0f, 1.0f, 0.35f);
+    dump(c, 1.0f);
+    // the VFO's design for 2.4 Msps -> 240 ksps, bw 200 kHz (vfo.h:26-33): 97 taps at gain 1
+    filter_window::BlackmanWindow d(100e3f, 100e3f, 2.4e6f);
+    dump(d, 1.0f);
+    filter_window::BlackmanWindow e(0.1f, 4.0f / 63.0f, 1.0f);
+    dump(e, 3.0f);  // interp gain
+    return 0;
+}
+
+// stream / block protocol, no GPU involved
+static int streamSelfTest() {
+    // 1. data integrity + exactly-one-in-flight over many blocks
+    {
+        stream<int> s;
+        std::atomic<bool> bad{false};
+        std::thread prod([&] {
+            for (int b = 0; b < 2000; b++) {
+                const int n = 1 + (b * 37) % 5000;
+                for (int i = 0; i < n; i++) { s.writeBuf[i] = b * 10000 + i; }
+                if (!s.swap(n)) { bad = true; return; }
+            }
+        });
+        for (int b = 0; b < 2000; b++) {
+            const int n = s.read();
+            if (n != 1 + (b * 37) % 5000) { bad = true; }
+            for (int i = 0; i < n; i++) { if (s.readBuf[i] != b * 10000 + i) { bad = true; } }
+            s.flush();
+        }
+        prod.join();
+        if (bad) { printf("FAIL stream integrity\n"); return 1; }
+    }
+    // 2. stopReader wakes a blocked read with -1; stopWriter wakes a blocked swap with false
+    {
+        stream<float> s;
+        int r = 0;
+        std::thread t([&] { r = s.read(); });
+        std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        s.stopReader();
+        t.join();
+        if (r != -1) { printf("FAIL stopReader\n"); return 1; }
+        s.clearReadStop();
+        if (!s.swap(3)) { printf("FAIL first swap\n"); return 1; }  // slot free -> immediate
+        bool ok = true;
+        std::thread w([&] { ok = s.swap(4); });                     // blocks: consumer never flushed
+        std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        s.stopWriter();
+        w.join();
+        if (ok) { printf("FAIL stopWriter\n"); return 1; }
+        s.clearWriteStop();
+        if (s.read() != 3) { printf("FAIL pending size\n"); return 1; }
+    }
+    // 3. generic_block lifecycle: source -> sink, stop() joins both, restart works
+    {
+        struct Ctx { int n = 0; } ctx;
+        HandlerSource<float> src([](float* d, void* c) { static_cast<Ctx*>(c)->n++; d[0] = 1.0f; return 1; }, &ctx);
+        std::atomic<long> got{0};
+        HandlerSink<float> sink(&src.out, [](float*, int n, void* c) { *static_cast<std::atomic<long>*>(c) += n; }, &got);
+        for (int round = 0; round < 2; round++) {
+            sink.start();
+            src.start();
+            while (got.load() < 1000 * (round + 1)) { std::this_thread::yield(); }
+            src.stop();
+            sink.stop();
+        }
+        NullSink<float> ns(&src.out);
+        ns.start();
+        src.start();
+        std::this_thread::sleep_for(std::chrono::milliseconds(5));
+        src.stop();
+        ns.stop();
+    }
+    // 4. window parity facts the kernels rely on
+    {
+        filter_window::BlackmanWindow w(0.1f, 4.0f / 63.0f, 1.0f);
+        if (w.getTapCount() != 63) { printf("FAIL tap count %d\n", w.getTapCount()); return 1; }
+    }
+    static_assert(STREAM_BUFFER_SIZE == 1000000, "stream capacity is part of the contract");
+    printf("stream/block self-test ok\n");
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) { fprintf(stderr, "usage: see header of graph_check.cpp\n"); return 2; }
+    const std::string mode = argv[1];
+    if (mode == "taps" && argc >= 3) { return dumpTaps(argv[2]); }
+    if (mode == "stream") { return streamSelfTest(); }
+    if (argc < 5) { fprintf(stderr, "missing arguments\n"); return 2; }
+    const char* in = argv[2];
+    const char* out = argv[3];
+    const int block = atoi(argv[4]);
+    if (block <= 0 || block > STREAM_BUFFER_SIZE) { fprintf(stderr, "bad block size\n"); return 2; }
+
+    if (mode == "fir" && argc >= 6) {
+        FileTaps taps(argv[5]);
+        return runGraph<complex_t>(in, out, block, [&](stream<complex_t>* s) { return new FIR<complex_t>(s, &taps); });
+    }
+    if (mode == "fir63") {
+        filter_window::BlackmanWindow win(0.1f, 4.0f / 63.0f, 1.0f);
+        return runGraph<complex_t>(in, out, block, [&](stream<complex_t>* s) { return new FIR<complex_t>(s, &win); });
+    }
+    if (mode == "firf" && argc >= 6) {
+        FileTaps taps(argv[5]);
+        return runGraph<float>(in, out, block, [&](stream<float>* s) { return new FIR<float>(s, &taps); });
+    }
+    if (mode == "resamp" && argc >= 9) {
+        filter_window::BlackmanWindow win((float)atof(argv[7]), (float)atof(argv[8]), (float)atof(argv[5]));
+        const float inSR = (float)atof(argv[5]), outSR = (float)atof(argv[6]);
+        return runGraph<complex_t>(in, out, block, [&](stream<complex_t>* s) { return new PolyphaseResampler<complex_t>(s, &win, inSR, outSR); });
+    }
+    if (mode == "xlate" && argc >= 7) {
+        const float sr = (float)atof(argv[5]), f = (float)atof(argv[6]);
+        return runGraph<complex_t>(in, out, block, [&](stream<complex_t>* s) { return new FrequencyXlator<complex_t>(s, sr, f); });
+    }
+    if (mode == "vfo" && argc >= 9) {
+        // VFO exposes `stream<complex_t>* out`; adapt it to the harness' blk->out shape
+        struct VfoBox {
+            VFO v;
+            stream<complex_t>& out;
+            VfoBox(stream<complex_t>* s, float off, float inSR, float outSR, float bw) : v(s, off, inSR, outSR, bw), out(*v.out) {}
+            void start() { v.start(); }
+            void stop() { v.stop(); }
+        };
+        const float off = (float)atof(argv[5]), inSR = (float)atof(argv[6]), outSR = (float)atof(argv[7]), bw = (float)atof(argv[8]);
+        return runGraph<complex_t>(in, out, block, [&](stream<complex_t>* s) { return new VfoBox(s, off, inSR, outSR, bw); });
+    }
+    if (mode == "wavfir") {
+        // BASELINE config 1: int16 stereo (I,Q) WAV -> complex (s / 32768.0f) -> 63-tap FIR.
+        WavReader rd(in);
+        if (!rd.isValid() || rd.getBitDepth() != 16 || rd.getChannelCount() != 2) { fprintf(stderr, "need a 16-bit 2-channel WAV\n"); return 2; }
+        const size_t frames = rd.hdr.dataSize / 4;
+        std::vector<int16_t> pcm(frames * 2);
+        rd.readSamples(pcm.data(), pcm.size() * 2);
+        std::vector<complex_t> iq(frames);
+        for (size_t i = 0; i < frames; i++) { iq[i] = {pcm[2 * i] / 32768.0f, pcm[2 * i + 1] / 32768.0f}; }
+        const std::string tmp = std::string(out) + ".in.cf32";
+        { std::ofstream o(tmp, std::ios::binary); o.write(reinterpret_cast<const char*>(iq.data()), (std::streamsize)(iq.size() * 8)); }
+        filter_window::BlackmanWindow win(0.1f * rd.getSampleRate(), 4.0f * rd.getSampleRate() / 63.0f, (float)rd.getSampleRate());
+        return runGraph<complex_t>(tmp.c_str(), out, block, [&](stream<complex_t>* s) { return new FIR<complex_t>(s, &win); });
+    }
+    fprintf(stderr, "unknown mode %s\n", mode.c_str());
+    return 2;
+}

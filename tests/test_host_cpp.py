@@ -1,0 +1,168 @@
+"""The C++ block-graph mirror (qdsp_amd/host/dsp): CPU checks of the parts that need no GPU
+(window designers vs the oracle's restatement of src/dsp/window.h, stream/block protocol),
+and -- marked gpu -- whole source -> block -> sink graphs against the oracle."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle as O
+from conftest import rel_rms
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "qdsp_amd", "host")
+BIN = os.path.join(HOST, "build", "graph_check")
+
+
+@pytest.fixture(scope="module")
+def harness():
+    if not os.path.exists(BIN):
+        subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL, timeout=300)
+    return BIN
+
+
+def run(args, timeout=180):
+    return subprocess.run(args, check=True, timeout=timeout, capture_output=True, text=True)
+
+
+def test_window_designers_match_oracle_bit_for_bit(harness, tmp_path):
+    out = tmp_path / "taps.f32"
+    run([harness, "taps", str(out)])
+    raw = np.fromfile(out, dtype=np.float32)
+    tables, i = [], 0
+    while i < len(raw):
+        n = int(raw[i])
+        tables.append(raw[i + 1:i + 1 + n])
+        i += 1 + n
+    assert [len(t) for t in tables] == [63, 63, 31, 97, 63]
+    assert np.array_equal(tables[0], O.blackman_taps(0.1, 1.0, 63))
+    assert np.array_equal(tables[1], O.blackman_bandpass_taps(0.05, 0.2, 1.0, 63))
+    assert np.array_equal(tables[2], O.rrc_taps(31, 4.0, 1.0, 0.35))
+    L, M, vt = O.vfo_design(2.4e6, 240e3, 200e3)
+    assert (L, M) == (1, 10) and np.array_equal(tables[3], vt)
+    assert np.array_equal(tables[4], O.blackman_taps(0.1, 1.0, 63, factor=3.0))
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "vectors.npz"))
+    assert np.array_equal(tables[0], gold["taps63"]) and np.array_equal(tables[3], gold["vfo_taps"])
+
+
+def test_stream_and_block_protocol(harness):
+    r = run([harness, "stream"], timeout=60)
+    assert "self-test ok" in r.stdout
+
+
+def test_headers_keep_the_reference_surface():
+    """Names a graph written against the reference uses must exist in the mirror."""
+    need = {
+        "dsp/stream.h": ["untyped_steam", "class stream", "bool swap(int size)", "int read()", "void flush()", "stopWriter", "clearWriteStop",
+                         "stopReader", "clearReadStop", "T* writeBuf", "T* readBuf", "STREAM_BUFFER_SIZE 1000000"],
+        "dsp/block.h": ["generic_unnamed_block", "class generic_block", "generic_hier_block", "registerInput", "registerOutput", "unregisterInput",
+                        "tempStart", "tempStop", "ctrlMtx", "friend BLOCK", "calcOutSize"],
+        "dsp/filter.h": ["class FIR", "updateWindow", "setInput", "stream<T> out"],
+        "dsp/resampling.h": ["class PolyphaseResampler", "setInSampleRate", "setOutSampleRate", "getInterpolation", "getDecimation", "updateWindow",
+                             "calcOutSize", "stream<T> out"],
+        "dsp/processing.h": ["class FrequencyXlator", "setInputSize", "setSampleRate", "getSampleRate", "setFrequency", "getFrequency"],
+        "dsp/vfo.h": ["class VFO", "setInSampleRate", "setOutSampleRate(float outSampleRate, float bandWidth)", "setOffset", "setBandwidth",
+                      "stream<complex_t>* out"],
+        "dsp/window.h": ["generic_window", "BlackmanWindow", "BlackmanBandpassWindow", "RRCTaps", "getTapCount", "createTaps"],
+        "dsp/types.h": ["struct complex_t", "struct stereo_t", "FL_M_PI 3.1415926535f", "fastPhase", "fastAmplitude", "conj()"],
+        "wav.h": ["class WavWriter", "writeSamples"], "wavreader.h": ["class WavReader", "readSamples", "getSampleRate", "isValid"],
+    }
+    for f, names in need.items():
+        txt = open(os.path.join(HOST, f)).read()
+        for n in names:
+            assert n in txt, (f, n)
+
+
+# ------------------------------------------------------------------------------------ GPU graphs
+gpu = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def data(tmp_path_factory):
+    d = tmp_path_factory.mktemp("graph")
+    x = O.synth_iq(0, 300_000, seed=99)
+    x.tofile(d / "x.cf32")
+    np.ascontiguousarray(x.real).tofile(d / "x.f32")
+    return d, x
+
+
+def blocks(op, x, b):
+    return np.concatenate([op.process(x[i:i + b]) for i in range(0, len(x), b)])
+
+
+@gpu
+def test_graph_fir63(harness, data):
+    d, x = data
+    run([harness, "fir63", str(d / "x.cf32"), str(d / "y.cf32"), "65536"])
+    y = np.fromfile(d / "y.cf32", dtype=np.complex64)
+    want = blocks(O.Fir(O.blackman_taps(0.1, 1.0, 63)), x, 65536)
+    assert len(y) == len(want) and rel_rms(y, want) < 2e-6
+
+
+@gpu
+def test_graph_fir256_custom_window_and_float(harness, data):
+    d, x = data
+    taps = O.lowpass_taps_f64(256, 1 / 16)
+    taps.tofile(d / "t256.f32")
+    run([harness, "fir", str(d / "x.cf32"), str(d / "y.cf32"), "100000", str(d / "t256.f32")])
+    y = np.fromfile(d / "y.cf32", dtype=np.complex64)
+    assert rel_rms(y, O.Fir(taps).process(x)) < 2e-6          # 100000-sample blocks -> FFT path
+    run([harness, "fir", str(d / "x.cf32"), str(d / "y2.cf32"), "4096", str(d / "t256.f32")])
+    y2 = np.fromfile(d / "y2.cf32", dtype=np.complex64)
+    assert np.array_equal(y2, O.Fir(taps, acc=O.ACC_FMA).process(x))  # small blocks -> direct form, bit-exact
+    run([harness, "firf", str(d / "x.f32"), str(d / "yf.f32"), "50000", str(d / "t256.f32")])
+    yf = np.fromfile(d / "yf.f32", dtype=np.float32)
+    assert np.array_equal(yf, O.Fir(taps, complex_data=False, acc=O.ACC_FMA).process(np.ascontiguousarray(x.real)))
+
+
+@gpu
+def test_graph_resampler_xlator_vfo(harness, data):
+    d, x = data
+    b = 50_000
+    # PolyphaseResampler(BlackmanWindow(cutoff 12k, trans 6k, 48k), 48k -> 32k): L=2, M=3
+    run([harness, "resamp", str(d / "x.cf32"), str(d / "yr.cf32"), str(b), "48000", "32000", "12000", "6000"])
+    yr = np.fromfile(d / "yr.cf32", dtype=np.complex64)
+    L, M = O.resamp_ratio(48000.0, 32000.0)
+    n = O.blackman_tap_count(12000.0, 6000.0, 48000.0)
+    taps = O.blackman_taps(12000.0, 48000.0, n, factor=float(L))
+    want = blocks(O.Resampler(taps, L, M), x, b)
+    assert (L, M) == (2, 3) and len(yr) == len(want) and rel_rms(yr, want) < 2e-6
+    # FrequencyXlator(2.4 MHz, 123456 Hz)
+    run([harness, "xlate", str(d / "x.cf32"), str(d / "yx.cf32"), "4096", "2400000", "123456"])
+    yx = np.fromfile(d / "yx.cf32", dtype=np.complex64)
+    wx = blocks(O.Xlator(2.4e6, 123456.0, exact=True, volk_gain=True), x, 4096)
+    assert np.abs(yx - wx).max() < 6e-7
+    # VFO(offset 300k, 2.4M -> 240k, bw 200k)
+    run([harness, "vfo", str(d / "x.cf32"), str(d / "yv.cf32"), str(b), "300000", "2400000", "240000", "200000"])
+    yv = np.fromfile(d / "yv.cf32", dtype=np.complex64)
+    wv = blocks(O.Vfo(300e3, 2.4e6, 240e3, 200e3, exact_nco=True, volk_gain=True), x, b)
+    assert len(yv) == len(wv) and rel_rms(yv, wv) < 2e-6
+
+
+@gpu
+def test_graph_wav_config1(harness, tmp_path):
+    """BASELINE configs[0]: 16-bit stereo (I,Q) WAV -> 63-tap lowpass FIR (SURVEY 8d config 1:
+    two tones + uniform noise, mt19937(1234), 2.4 Msps, 2^20 frames, blocks of 65536)."""
+    fs, n = 2_400_000, 1 << 20
+    rng = np.random.Generator(np.random.MT19937(1234))
+    t = np.arange(n) / fs
+    sig = 0.35 * np.exp(2j * np.pi * 100e3 * t) + 0.25 * np.exp(-2j * np.pi * 700e3 * t) + 0.1 * (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n))
+    pcm = np.empty(2 * n, dtype=np.int16)
+    pcm[0::2] = np.clip(np.round(sig.real * 32767), -32768, 32767)
+    pcm[1::2] = np.clip(np.round(sig.imag * 32767), -32768, 32767)
+    hdr = struct.pack("<4sI4s4sIHHIIHH4sI", b"RIFF", pcm.nbytes + 36, b"WAVE", b"fmt ", 16, 1, 2, fs, fs * 4, 4, 16, b"data", pcm.nbytes)
+    wav = tmp_path / "iq.wav"
+    wav.write_bytes(hdr + pcm.tobytes())
+    run([harness, "wavfir", str(wav), str(tmp_path / "y.cf32"), "65536"])
+    y = np.fromfile(tmp_path / "y.cf32", dtype=np.complex64)
+    iq = (pcm[0::2].astype(np.float32) / np.float32(32768.0) + 1j * (pcm[1::2].astype(np.float32) / np.float32(32768.0))).astype(np.complex64)
+    ntaps = O.blackman_tap_count(0.1 * fs, 4.0 * fs / 63.0, float(fs))
+    taps = O.blackman_taps(0.1 * fs, float(fs), ntaps)
+    want = blocks(O.Fir(taps), iq, 65536)
+    assert ntaps == 63 and len(y) == n and rel_rms(y, want) < 2e-6
+    # the 700 kHz tone is outside the 240 kHz passband, the 100 kHz tone inside
+    spec = np.abs(np.fft.fft(y[4096:4096 + 65536] * np.hanning(65536)))
+    f = np.fft.fftfreq(65536, 1 / fs)
+    assert spec[np.argmin(np.abs(f - 100e3))] > 30 * spec[np.argmin(np.abs(f + 700e3))]
