@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (on the GPU box): scripts/pmc.sh <workload> <outdir> -- collects SQ/LDS/GRBM counters in separate passes
-W=$1; OUT=$2; R=${GRAFT_REPO_ROOT:-$PWD}
+W=$1; R=${GRAFT_REPO_ROOT:-$PWD}; OUT=$R/$2
 export TMPDIR=/tmp
 mkdir -p $OUT
 cd /tmp
