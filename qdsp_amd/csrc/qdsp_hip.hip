@@ -395,12 +395,12 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, void* d_out, hipStrea
     a.H = e->H;
     a.L = qk::kFftN - e->H;
     a.nblocks = (int)((count + a.L - 1) / a.L);
-    const int per_cu = env_int("QDSP_HIP_FFT_WG_PER_CU", 3);
+    const int per_cu = env_int("QDSP_HIP_FFT_WG_PER_CU", 4);  // = occupancy: 126 VGPRs, 36.9 KB LDS
     int nwg = 256 * per_cu;
     if (nwg > a.nblocks) nwg = a.nblocks;
     a.nwg = nwg;
-    hipLaunchKernelGGL(qk::fir_fft_kernel, dim3(nwg + 1), dim3(qk::kFftNT), 0, s, a);
-    HIPCHK(hipGetLastError());
+    rc = qk::launch_fir_fft(a, nwg + 1, s);
+    if (rc) return rc;
     e->last.name = "fir_fft_kernel";
     e->last.grid = nwg + 1;
     e->last.block = qk::kFftNT;
