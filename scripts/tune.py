@@ -20,7 +20,9 @@ GEOMS = {
 
 
 def main():
-    names = sys.argv[1:] or list(GEOMS)
+    names = [a for a in sys.argv[1:] if a in GEOMS]
+    if not sys.argv[1:]:
+        names = list(GEOMS)
     n = 1 << 27
     x = ops.synth_iq(n, seed=1234)
     for name in names:
@@ -45,7 +47,7 @@ def main():
     for ntaps in (32, 63, 128, 256, 512, 1024):
         taps = bench.lowpass_taps(ntaps, 1.0 / 16.0)
         out = torch.empty(n, dtype=torch.complex64, device="cuda")
-        for mode, wg in ((1, 0), (2, 2), (2, 3), (2, 4)):
+        for mode, wg in ((1, 0), (2, 2), (2, 3), (2, 4), (2, 8)):
             if wg:
                 os.environ["QDSP_HIP_FFT_WG_PER_CU"] = str(wg)
             op = ops.Fir(taps, max_block=0)
