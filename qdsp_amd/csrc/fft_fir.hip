@@ -54,6 +54,16 @@ template <bool INV> __device__ __forceinline__ void fft16(float2 (&v)[16]) {
 }
 
 // y[n] = sum_k taps[k] * s[n - H + k], s = hist ++ in, by overlap-save (see file header).
+// NT: stream the samples with non-temporal loads/stores (each is touched once; keeps the
+// tables and the 255-sample overlap, not the stream, in L2 / Infinity Cache).
+template <bool NT> __device__ __forceinline__ float2 ld_stream(const float2* p) {
+    return NT ? __builtin_nontemporal_load(p) : *p;
+}
+template <bool NT> __device__ __forceinline__ void st_stream(float2* p, float2 v) {
+    if (NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+
+template <bool NT>
 __global__ __launch_bounds__(kFftNT, 4) void fir_fft_kernel(const FftArgs a) {
     __shared__ __attribute__((aligned(16))) float2 lds[kFftLdsElems + 16 * 17];
     float2* tbl = lds + kFftLdsElems;  // pass-B twiddles W256^(lo*k), rows padded to 17
@@ -87,7 +97,7 @@ __global__ __launch_bounds__(kFftNT, 4) void fir_fft_kernel(const FftArgs a) {
         if (seg0 >= 0 && seg0 + kFftN <= a.count) {
             const float2* __restrict__ p = a.in + seg0 + t;
 #pragma unroll
-            for (int n2 = 0; n2 < 16; n2++) v[n2] = p[n2 * 256];
+            for (int n2 = 0; n2 < 16; n2++) v[n2] = ld_stream<NT>(p + n2 * 256);
         } else {
 #pragma unroll
             for (int n2 = 0; n2 < 16; n2++) {
@@ -144,7 +154,7 @@ __global__ __launch_bounds__(kFftNT, 4) void fir_fft_kernel(const FftArgs a) {
         if (seg0 >= 0 && seg0 + kFftN <= a.count) {
 #pragma unroll
             for (int n2 = 0; n2 < 16; n2++)
-                if (n2 * 256 + t >= H) a.out[o0 + n2 * 256] = v[rev16(n2)];
+                if (n2 * 256 + t >= H) st_stream<NT>(a.out + o0 + n2 * 256, v[rev16(n2)]);
         } else {
 #pragma unroll
             for (int n2 = 0; n2 < 16; n2++) {
@@ -157,7 +167,8 @@ __global__ __launch_bounds__(kFftNT, 4) void fir_fft_kernel(const FftArgs a) {
 
 
 int launch_fir_fft(const FftArgs& a, int grid, hipStream_t stream) {
-    hipLaunchKernelGGL(fir_fft_kernel, dim3(grid), dim3(kFftNT), 0, stream, a);
+    if (a.nt) hipLaunchKernelGGL(fir_fft_kernel<true>, dim3(grid), dim3(kFftNT), 0, stream, a);
+    else hipLaunchKernelGGL(fir_fft_kernel<false>, dim3(grid), dim3(kFftNT), 0, stream, a);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }

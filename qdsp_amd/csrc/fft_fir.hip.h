@@ -37,6 +37,7 @@ struct FftArgs {
     int L;                    // valid outputs per block = F - H
     int nblocks;              // ceil(count / L)
     int nwg;                  // persistent workgroups (grid = nwg + 1; the last one hands over history)
+    int nt;                   // 1: non-temporal loads/stores for the sample stream
 };
 
 // Defined in fft_fir.hip (its own translation unit: built with -fno-slp-vectorize, see there).

@@ -338,7 +338,7 @@ bool fft_eligible(const Engine* e, int64_t count) {
     if (mode == 1) return false;
     if (mode == 2) return true;
     // auto: long filters on blocks big enough to fill the chip with 4096-point segments
-    return e->ntaps >= env_int("QDSP_HIP_FFT_MIN_TAPS", 48) && count >= env_int("QDSP_HIP_FFT_MIN_COUNT", 1 << 16);
+    return e->ntaps >= env_int("QDSP_HIP_FFT_MIN_TAPS", 24) && count >= env_int("QDSP_HIP_FFT_MIN_COUNT", 1 << 16);
 }
 
 int fft_prepare(Engine* e) {
@@ -399,6 +399,7 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, void* d_out, hipStrea
     int nwg = 256 * per_cu;
     if (nwg > a.nblocks) nwg = a.nblocks;
     a.nwg = nwg;
+    a.nt = env_int("QDSP_HIP_FFT_NT", 0);
     rc = qk::launch_fir_fft(a, nwg + 1, s);
     if (rc) return rc;
     e->last.name = "fir_fft_kernel";

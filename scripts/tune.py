@@ -44,10 +44,11 @@ def main():
     os.environ.pop("QDSP_HIP_R", None)
     os.environ.pop("QDSP_HIP_NT", None)
     # FIR algorithm: direct form vs overlap-save FFT, per tap count
-    for ntaps in (32, 63, 128, 256, 512, 1024):
+    for ntaps in [int(a) for a in os.environ.get("TUNE_TAPS", "32,63,128,256,512,1024").split(",")]:
         taps = bench.lowpass_taps(ntaps, 1.0 / 16.0)
         out = torch.empty(n, dtype=torch.complex64, device="cuda")
-        for mode, wg in ((1, 0), (2, 2), (2, 3), (2, 4), (2, 8)):
+        for mode, wg, nt in ((1, 0, 0), (2, 4, 0), (2, 8, 0), (2, 16, 0), (2, 4, 1), (2, 8, 1), (2, 16, 1)):
+            os.environ["QDSP_HIP_FFT_NT"] = str(nt)
             if wg:
                 os.environ["QDSP_HIP_FFT_WG_PER_CU"] = str(wg)
             op = ops.Fir(taps, max_block=0)
@@ -55,7 +56,7 @@ def main():
             op.process(x, out)
             torch.cuda.synchronize()
             ms = min(op.time_dev(x, out, 10) for _ in range(3))
-            print(f"fir ntaps={ntaps:5d} mode={'direct' if mode == 1 else 'fft wg/cu=' + str(wg):12s} {ms:8.4f} ms "
+            print(f"fir ntaps={ntaps:5d} mode={'direct' if mode == 1 else 'fft wg/cu=' + str(wg) + ' nt=' + str(nt):18s} {ms:8.4f} ms "
                   f"{n / ms / 1e6:8.1f} Gs/s  {16 * n / ms / 1e6:7.1f} GB/s", flush=True)
             op.close()
 
