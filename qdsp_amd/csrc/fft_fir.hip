@@ -56,11 +56,23 @@ template <bool INV> __device__ __forceinline__ void fft16(float2 (&v)[16]) {
 // y[n] = sum_k taps[k] * s[n - H + k], s = hist ++ in, by overlap-save (see file header).
 // NT: stream the samples with non-temporal loads/stores (each is touched once; keeps the
 // tables and the 255-sample overlap, not the stream, in L2 / Infinity Cache).
+typedef float v2f_t __attribute__((ext_vector_type(2)));
 template <bool NT> __device__ __forceinline__ float2 ld_stream(const float2* p) {
-    return NT ? __builtin_nontemporal_load(p) : *p;
+    if (NT) {
+        const v2f_t r = __builtin_nontemporal_load(reinterpret_cast<const v2f_t*>(p));
+        return make_float2(r.x, r.y);
+    }
+    return *p;
 }
 template <bool NT> __device__ __forceinline__ void st_stream(float2* p, float2 v) {
-    if (NT) __builtin_nontemporal_store(v, p); else *p = v;
+    if (NT) {
+        v2f_t r;
+        r.x = v.x;
+        r.y = v.y;
+        __builtin_nontemporal_store(r, reinterpret_cast<v2f_t*>(p));
+    } else {
+        *p = v;
+    }
 }
 
 template <bool NT>
