@@ -132,6 +132,10 @@ int64_t qdsp_hip_decim_cf32_process_dev(void* h, const void* d_in, int64_t count
 /* updateWindow / setInSampleRate / setOutSampleRate (resampling.h:53-93) all funnel here. */
 int qdsp_hip_decim_cf32_configure(void* h, const float* taps, int ntaps, int interp, int decim);
 int64_t qdsp_hip_decim_cf32_out_size(void* h, int64_t count); /* calcOutSize, :95-97 */
+/* QDSP_HIP_FIR_AUTO / _DIRECT / _FFT as for the FIR.  The overlap-save path serves
+ * interp == 1 with decim in {2, 4, 8, 16} (pruned inverse transform); everything else is
+ * direct form whatever the mode. */
+int qdsp_hip_decim_cf32_set_mode(void* h, int mode);
 int qdsp_hip_decim_cf32_reset(void* h);
 int qdsp_hip_decim_cf32_history_len(void* h); /* = taps per phase */
 int qdsp_hip_decim_cf32_get_history(void* h, float* hist_iq);
@@ -147,6 +151,7 @@ int64_t qdsp_hip_decim_f32_process_dev(void* h, const void* d_in, int64_t count,
                                        void* hip_stream);
 int qdsp_hip_decim_f32_configure(void* h, const float* taps, int ntaps, int interp, int decim);
 int64_t qdsp_hip_decim_f32_out_size(void* h, int64_t count);
+int qdsp_hip_decim_f32_set_mode(void* h, int mode); /* accepted; real data always runs direct form */
 int qdsp_hip_decim_f32_reset(void* h);
 int qdsp_hip_decim_f32_history_len(void* h);
 int qdsp_hip_decim_f32_get_history(void* h, float* hist);
@@ -200,6 +205,7 @@ int qdsp_hip_xlate_fir_decim_cf32_set_phase(void* h, float phase_re, float phase
 int qdsp_hip_xlate_fir_decim_cf32_advance(void* h, int64_t nsamples);
 int qdsp_hip_xlate_fir_decim_cf32_set_volk_gain(void* h, int on);
 int64_t qdsp_hip_xlate_fir_decim_cf32_out_size(void* h, int64_t count);
+int qdsp_hip_xlate_fir_decim_cf32_set_mode(void* h, int mode);
 int qdsp_hip_xlate_fir_decim_cf32_reset(void* h);
 int qdsp_hip_xlate_fir_decim_cf32_history_len(void* h);
 int qdsp_hip_xlate_fir_decim_cf32_get_history(void* h, float* hist_iq);

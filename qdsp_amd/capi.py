@@ -80,6 +80,7 @@ def load():
         sig(p + "_process_dev", i64, vp, vp, i64, vp, vp)
         sig(p + "_configure", i32, vp, fp, i32, i32, i32)
         sig(p + "_out_size", i64, vp, i64)
+        sig(p + "_set_mode", i32, vp, i32)
     sig("qdsp_hip_xlate_cf32_create", i32, pvp, i32, C.c_float, C.c_float, i32)
     sig("qdsp_hip_xlate_cf32_process", i32, vp, vp, i32, vp)
     sig("qdsp_hip_xlate_cf32_process_dev", i32, vp, vp, i64, vp, vp)
@@ -90,6 +91,7 @@ def load():
     sig(p + "_process_dev", i64, vp, vp, i64, vp, vp)
     sig(p + "_configure", i32, vp, fp, i32, i32, i32)
     sig(p + "_out_size", i64, vp, i64)
+    sig(p + "_set_mode", i32, vp, i32)
     for p in ("qdsp_hip_xlate_cf32", "qdsp_hip_xlate_fir_decim_cf32"):
         sig(p + "_set_phase_inc", i32, vp, C.c_float, C.c_float)
         sig(p + "_get_phase", i32, vp, fp, fp)

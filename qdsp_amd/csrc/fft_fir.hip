@@ -53,41 +53,53 @@ template <bool INV> __device__ __forceinline__ void fft16(float2 (&v)[16]) {
     for (int k0 = 0; k0 < 4; k0++) fft4<INV>(v[4 * k0], v[4 * k0 + 1], v[4 * k0 + 2], v[4 * k0 + 3]);
 }
 
-// y[n] = sum_k taps[k] * s[n - H + k], s = hist ++ in, by overlap-save (see file header).
-// NT: stream the samples with non-temporal loads/stores (each is touched once; keeps the
-// tables and the 255-sample overlap, not the stream, in L2 / Infinity Cache).
-typedef float v2f_t __attribute__((ext_vector_type(2)));
-template <bool NT> __device__ __forceinline__ float2 ld_stream(const float2* p) {
-    if (NT) {
-        const v2f_t r = __builtin_nontemporal_load(reinterpret_cast<const v2f_t*>(p));
-        return make_float2(r.x, r.y);
-    }
-    return *p;
+// ---- NCO helpers (same definitions as kernels.hip.h; this TU is built separately) ------
+__device__ __forceinline__ double2 fx_phasor(unsigned long long ph) {
+    const double t = (double)(ph >> 11) * (1.0 / 9007199254740992.0);
+    double s, c;
+    sincospi(2.0 * t, &s, &c);
+    return make_double2(c, s);
 }
-template <bool NT> __device__ __forceinline__ void st_stream(float2* p, float2 v) {
-    if (NT) {
-        v2f_t r;
-        r.x = v.x;
-        r.y = v.y;
-        __builtin_nontemporal_store(r, reinterpret_cast<v2f_t*>(p));
-    } else {
-        *p = v;
-    }
+__device__ __forceinline__ double2 dcmul(double2 a, double2 b) {
+    return make_double2(fma(a.x, b.x, -a.y * b.y), fma(a.x, b.y, a.y * b.x));
 }
 
-template <bool NT>
+// Overlap-save block filter (see fft_fir.hip.h):
+//   DEC == 1 : FIR<complex_t>            y[n]  = sum_k taps[k] s[n - (N-1) + k]
+//   DEC  > 1 : PolyphaseResampler, interp 1, decim DEC (DEC | 16)
+//                                         y[n'] = sum_k taps[k] s[n'*DEC - P + k]
+//   ROT      : FrequencyXlator applied to `in` while loading (the fused VFO)
+// s = hist ++ in.  Segment b starts at stream position b*L - seg_shift; its elements
+// i >= ov are valid filter outputs (position p = seg0 + i).  For DEC > 1 the segments are
+// placed so that the wanted positions (p == -1 mod DEC) are the elements with i == 0 mod DEC,
+// i.e. the last radix-16 digit n0 is a multiple of DEC: the inverse transform keeps only
+// those 16/DEC values of n0, and passes B'/A' run on 256/DEC lanes.
+template <int DEC, bool ROT>
 __global__ __launch_bounds__(kFftNT, 4) void fir_fft_kernel(const FftArgs a) {
     __shared__ __attribute__((aligned(16))) float2 lds[kFftLdsElems + 16 * 17];
     float2* tbl = lds + kFftLdsElems;  // pass-B twiddles W256^(lo*k), rows padded to 17
     const int t = threadIdx.x;
     const int hi = t >> 4, lo = t & 15;
     const int H = a.H;
+    constexpr int NS = 16 / DEC;       // kept values of n0: 0, DEC, 2*DEC, ...
+    constexpr int NACT = 256 / DEC;    // lanes active in the pruned inverse passes
 
     if ((int)blockIdx.x == a.nwg) {
-        // history hand-over (filter.h:71): last H samples of hist ++ in -> the other buffer
+        // history hand-over (filter.h:71 / resampling.h:129): last H samples of hist ++ in
         for (int i = t; i < H; i += kFftNT) {
             const long long g = a.count - H + i;
-            a.hist_next[i] = (g < 0) ? a.hist[g + H] : a.in[g];
+            float2 v;
+            if (g < 0) {
+                v = a.hist[g + H];
+            } else {
+                v = a.in[g];
+                if (ROT) {
+                    const double2 p = fx_phasor(a.phase0 + (unsigned long long)g * a.dphase);
+                    const float gain = fmaf((float)(int)(g & 511), a.gm1, 1.0f);
+                    v = cmulc<false>(v, make_float2((float)p.x * gain, (float)p.y * gain));
+                }
+            }
+            a.hist_next[i] = v;
         }
         return;
     }
@@ -96,26 +108,56 @@ __global__ __launch_bounds__(kFftNT, 4) void fir_fft_kernel(const FftArgs a) {
     float2 ta[16], hf[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        ta[k] = a.TA[t * 16 + k];
         hf[k] = a.Hf[t * 16 + k];
+        ta[k] = a.TA[t * 16 + k];
+    }
+    float2 ta2[16];  // pass-A' twiddles of the pruned inverse: lane w = n1*NS + s <-> element n1*16 + s*DEC
+    if (DEC > 1) {
+        const int e = (t / NS) * 16 + (t % NS) * DEC;
+#pragma unroll
+        for (int k = 0; k < 16; k++) ta2[k] = a.TA[(e & 255) * 16 + k];
     }
     tbl[(t >> 4) * 17 + (t & 15)] = a.TB[t];
     const float2* tb = tbl + lo * 17;
 
+    float2 pl = make_float2(1.0f, 0.0f);   // exp(j 2pi t dphase)
+    double2 pb = make_double2(1.0, 0.0);   // exp(j 2pi (phase0 + seg0 dphase)) of the current block
+    if (ROT) {
+        const double2 p = fx_phasor((unsigned long long)t * a.dphase);
+        pl = make_float2((float)p.x, (float)p.y);
+        pb = fx_phasor(a.phase0 + (unsigned long long)((long long)blockIdx.x * a.L - a.seg_shift) * a.dphase);
+    }
+
     for (int b = blockIdx.x; b < a.nblocks; b += a.nwg) {
-        const long long seg0 = (long long)b * a.L - H;  // stream index of segment element 0
+        const long long seg0 = (long long)b * a.L - a.seg_shift;  // stream position of element 0
+        const bool interior = seg0 >= 0 && seg0 + kFftN <= a.count;
         float2 v[16];
         // ---- load: lane t takes elements n2*256 + t ------------------------------------
-        if (seg0 >= 0 && seg0 + kFftN <= a.count) {
+        if (interior) {
             const float2* __restrict__ p = a.in + seg0 + t;
 #pragma unroll
-            for (int n2 = 0; n2 < 16; n2++) v[n2] = ld_stream<NT>(p + n2 * 256);
+            for (int n2 = 0; n2 < 16; n2++) v[n2] = p[n2 * 256];
         } else {
 #pragma unroll
             for (int n2 = 0; n2 < 16; n2++) {
                 const long long g = seg0 + n2 * 256 + t;
-                v[n2] = (g < 0) ? a.hist[g + H] : (g < a.count ? a.in[g] : make_float2(0.0f, 0.0f));
+                float2 x = make_float2(0.0f, 0.0f);
+                if (g < 0) { if (g + H >= 0) x = a.hist[g + H]; }
+                else if (g < a.count) x = a.in[g];
+                v[n2] = x;
             }
+        }
+        if (ROT) {
+            const float2 q = cmulc<false>(make_float2((float)pb.x, (float)pb.y), pl);
+#pragma unroll
+            for (int n2 = 0; n2 < 16; n2++) {
+                const long long g = seg0 + n2 * 256 + t;
+                const float gain = fmaf((float)(int)(g & 511), a.gm1, 1.0f);
+                float2 ph = (n2 == 0) ? q : cmulc<false>(q, a.wtab[n2]);
+                ph = make_float2(ph.x * gain, ph.y * gain);
+                if (interior || g >= 0) v[n2] = cmulc<false>(v[n2], ph);   // history is already rotated
+            }
+            pb = dcmul(pb, a.rot_step);
         }
         // ---- pass A (over n2) + twiddle W4096^(t*k0) -----------------------------------
         fft16<false>(v);
@@ -136,51 +178,96 @@ __global__ __launch_bounds__(kFftNT, 4) void fir_fft_kernel(const FftArgs a) {
         for (int j = 0; j < 16; j++) v[j] = lds[t * kFftRow2 + j];
         // ---- pass C (over n0), spectrum * Hf, pass C' (over k2) ----------------------------
         fft16<false>(v);
-        {
-            float2 y[16];
+        float2 y[16];
 #pragma unroll
-            for (int k = 0; k < 16; k++) y[k] = cmulc<false>(v[rev16(k)], hf[k]);
-            fft16<true>(y);
-            __syncthreads();
+        for (int k = 0; k < 16; k++) y[k] = cmulc<false>(v[rev16(k)], hf[k]);
+        fft16<true>(y);
+        __syncthreads();
+        if constexpr (DEC == 1) {
 #pragma unroll
             for (int j = 0; j < 16; j++)
                 lds[t * kFftRow2 + j] = (j == 0) ? y[rev16(0)] : cmulc<true>(y[rev16(j)], tb[j]);
-        }
-        __syncthreads();
+            __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 16; j++) v[j] = lds[(hi * 16 + j) * kFftRow2 + lo];
-        // ---- pass B' (over k1) -------------------------------------------------------------
-        fft16<true>(v);
-        __syncthreads();
+            for (int j = 0; j < 16; j++) v[j] = lds[(hi * 16 + j) * kFftRow2 + lo];
+            // ---- pass B' (over k1) ---------------------------------------------------------
+            fft16<true>(v);
+            __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 16; j++) lds[hi * kFftRow1 + j * 16 + lo] = v[rev16(j)];
-        __syncthreads();
+            for (int j = 0; j < 16; j++) lds[hi * kFftRow1 + j * 16 + lo] = v[rev16(j)];
+            __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const float2 e = lds[k * kFftRow1 + t];
-            v[k] = (k == 0) ? e : cmulc<true>(e, ta[k]);
-        }
-        // ---- pass A' (over k0) and store the L valid outputs ------------------------------
-        fft16<true>(v);
-        const long long o0 = (long long)b * a.L - H + t;  // output index of element t (n2 = 0)
-        if (seg0 >= 0 && seg0 + kFftN <= a.count) {
+            for (int k = 0; k < 16; k++) {
+                const float2 e = lds[k * kFftRow1 + t];
+                v[k] = (k == 0) ? e : cmulc<true>(e, ta[k]);
+            }
+            // ---- pass A' (over k0) and store the L valid outputs --------------------------
+            fft16<true>(v);
+            const long long o0 = seg0 + t;  // output index == stream position (element n2*256 + t)
+            if (interior) {
 #pragma unroll
-            for (int n2 = 0; n2 < 16; n2++)
-                if (n2 * 256 + t >= H) st_stream<NT>(a.out + o0 + n2 * 256, v[rev16(n2)]);
+                for (int n2 = 0; n2 < 16; n2++)
+                    if (n2 * 256 + t >= a.ov) a.out[o0 + n2 * 256] = v[rev16(n2)];
+            } else {
+#pragma unroll
+                for (int n2 = 0; n2 < 16; n2++) {
+                    const long long n = o0 + n2 * 256;
+                    if (n2 * 256 + t >= a.ov && n < a.nout) a.out[n] = v[rev16(n2)];
+                }
+            }
         } else {
+            // ---- pruned inverse: keep n0 = s*DEC only ---------------------------------------
+            // lane (k0 = hi, k1 = lo) -> row (k0*NS + s), column k1
 #pragma unroll
-            for (int n2 = 0; n2 < 16; n2++) {
-                const long long n = o0 + n2 * 256;
-                if (n2 * 256 + t >= H && n < a.count) a.out[n] = v[rev16(n2)];
+            for (int s = 0; s < NS; s++) {
+                const int n0 = s * DEC;
+                lds[(hi * NS + s) * kFftRow2 + lo] = (n0 == 0) ? y[rev16(0)] : cmulc<true>(y[rev16(n0)], tb[n0]);
+            }
+            __syncthreads();
+            if (t < NACT) {  // lane u = k0*NS + s : pass B' over k1
+#pragma unroll
+                for (int j = 0; j < 16; j++) v[j] = lds[t * kFftRow2 + j];
+                fft16<true>(v);
+            }
+            __syncthreads();
+            if (t < NACT) {  // -> row (n1*NS + s), column k0
+                const int k0 = t / NS, s = t % NS;
+#pragma unroll
+                for (int j = 0; j < 16; j++) lds[(j * NS + s) * kFftRow2 + k0] = v[rev16(j)];
+            }
+            __syncthreads();
+            if (t < NACT) {  // lane w = n1*NS + s : twiddle, pass A' over k0, store
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const float2 e = lds[t * kFftRow2 + k];
+                    v[k] = (k == 0) ? e : cmulc<true>(e, ta2[k]);
+                }
+                fft16<true>(v);
+                const int e0 = (t / NS) * 16 + (t % NS) * DEC;         // element index for n2 = 0
+                const long long nb = ((long long)b * a.L - a.ov) / DEC;  // (b*L + i - ov)/DEC at i = 0
+#pragma unroll
+                for (int n2 = 0; n2 < 16; n2++) {
+                    const int i = n2 * 256 + e0;
+                    const long long n = nb + i / DEC;
+                    if (i >= a.ov && n < a.nout) a.out[n] = v[rev16(n2)];
+                }
             }
         }
     }
 }
 
-
 int launch_fir_fft(const FftArgs& a, int grid, hipStream_t stream) {
-    if (a.nt) hipLaunchKernelGGL(fir_fft_kernel<true>, dim3(grid), dim3(kFftNT), 0, stream, a);
-    else hipLaunchKernelGGL(fir_fft_kernel<false>, dim3(grid), dim3(kFftNT), 0, stream, a);
+#define QK_FFT(dec, rot) hipLaunchKernelGGL((fir_fft_kernel<dec, rot>), dim3(grid), dim3(kFftNT), 0, stream, a)
+    const bool r = a.rot != 0;
+    switch (a.dec) {
+        case 1: if (r) return -1; QK_FFT(1, false); break;
+        case 2: if (r) QK_FFT(2, true); else QK_FFT(2, false); break;
+        case 4: if (r) QK_FFT(4, true); else QK_FFT(4, false); break;
+        case 8: if (r) QK_FFT(8, true); else QK_FFT(8, false); break;
+        case 16: if (r) QK_FFT(16, true); else QK_FFT(16, false); break;
+        default: return -1;
+    }
+#undef QK_FFT
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }

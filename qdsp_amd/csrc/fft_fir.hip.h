@@ -27,17 +27,26 @@ constexpr int kFftLdsElems = 16 * kFftRow1;  // 4352 >= 256*17 = 4352
 struct FftArgs {
     const float2* in;
     float2* out;
-    const float2* hist;       // H samples
+    const float2* hist;       // H samples (already rotated for the fused VFO)
     float2* hist_next;
     const float2* Hf;         // [256][16]: Hf[(k0*16+k1)*16 + k2] = FFT(taps reversed)[k0 + 16 k1 + 256 k2] / F
     const float2* TA;         // [256][16]: exp(-j 2pi t k / 4096)
     const float2* TB;         // [16][16] : exp(-j 2pi lo k / 256)
-    long long count;
-    int H;                    // ntaps - 1
-    int L;                    // valid outputs per block = F - H
-    int nblocks;              // ceil(count / L)
+    long long count;          // input samples of this call
+    long long nout;           // outputs of this call
+    int H;                    // history length (ntaps-1 for the FIR, taps per phase for the resampler)
+    int dec;                  // 1, 2, 4, 8, 16
+    int rot;                  // 1: rotate `in` by the NCO while loading
+    int ov;                   // leading invalid elements of a segment (multiple of dec)
+    int seg_shift;            // segment b starts at stream position b*L - seg_shift
+    int L;                    // stream positions covered per segment = 4096 - ov
+    int nblocks;
     int nwg;                  // persistent workgroups (grid = nwg + 1; the last one hands over history)
-    int nt;                   // 1: non-temporal loads/stores for the sample stream
+    // NCO (rot only)
+    unsigned long long phase0, dphase;
+    double2 rot_step;         // exp(j 2pi nwg*L*dphase): block b -> b + nwg
+    float2 wtab[16];          // exp(j 2pi 256*n2*dphase)
+    float gm1;                // |phase_inc| - 1 (VOLK magnitude sawtooth), 0 = off
 };
 
 // Defined in fft_fir.hip (its own translation unit: built with -fno-slp-vectorize, see there).

@@ -331,14 +331,23 @@ template <int CH, bool ROT> int launch_any(Engine* e, qk::AnyArgs& a, hipStream_
 // ---- overlap-save FFT FIR -------------------------------------------------------------------
 constexpr int kFftMaxTaps = 2049;   // keeps >= 2048 valid outputs per 4096-point block
 
+// DEC the overlap-save kernel would run with for this engine, 0 if it cannot.
+int fft_dec(const Engine* e) {
+    if (e->ch != 2 || e->L != 1 || e->ntaps < 2 || e->ntaps > kFftMaxTaps) return 0;
+    if (e->kind == KIND_FIR) return 1;
+    if (e->kind == KIND_DECIM || e->kind == KIND_VFO) {
+        if (e->M == 2 || e->M == 4 || e->M == 8 || e->M == 16) return e->M;
+    }
+    return 0;
+}
+
 bool fft_eligible(const Engine* e, int64_t count) {
-    if (e->kind != KIND_FIR || e->ch != 2) return false;
-    if (e->ntaps < 2 || e->ntaps > kFftMaxTaps) return false;
+    if (!fft_dec(e)) return false;
     int mode = e->fir_mode ? e->fir_mode : env_int("QDSP_HIP_FIR_MODE", 0);
     if (mode == 1) return false;
     if (mode == 2) return true;
-    // auto: long filters on blocks big enough to fill the chip with 4096-point segments
-    return e->ntaps >= env_int("QDSP_HIP_FFT_MIN_TAPS", 24) && count >= env_int("QDSP_HIP_FFT_MIN_COUNT", 1 << 16);
+    // auto: long filters on calls big enough to fill the chip with 4096-point segments
+    return e->ntaps >= env_int("QDSP_HIP_FFT_MIN_TAPS", 24) * (e->M > 1 ? e->M / 2 : 1) && count >= env_int("QDSP_HIP_FFT_MIN_COUNT", 1 << 16);
 }
 
 int fft_prepare(Engine* e) {
@@ -351,7 +360,8 @@ int fft_prepare(Engine* e) {
         sn[i] = sinl(two_pi * (long double)i / F);
     }
     const int N = e->ntaps;
-    // g[j] = taps[N-1-j]:  y[n] = sum_j g[j] s[n-j];  Hf[k] = sum_j g[j] exp(-j 2pi jk/F) / F
+    // g[j] = taps[N-1-j]:  c[p] = sum_j g[j] s[p-j] = sum_k taps[k] s[p-(N-1)+k];
+    // Hf[k] = sum_j g[j] exp(-j 2pi jk/F) / F
     std::vector<float2> Hp(F), TA(256 * 16), TB(16 * 16);
     for (int k = 0; k < F; k++) {
         long double re = 0.0L, im = 0.0L;
@@ -380,10 +390,11 @@ int fft_prepare(Engine* e) {
     return 0;
 }
 
-int launch_fft(Engine* e, const void* d_in, int64_t count, void* d_out, hipStream_t s) {
+int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d_out, hipStream_t s) {
     int rc = fft_prepare(e);
     if (rc) return rc;
     qk::FftArgs a;
+    memset(&a, 0, sizeof(a));
     a.in = static_cast<const float2*>(d_in);
     a.out = static_cast<float2*>(d_out);
     a.hist = reinterpret_cast<const float2*>(e->d_hist[e->cur]);
@@ -392,20 +403,44 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, void* d_out, hipStrea
     a.TA = e->d_fft_TA;
     a.TB = e->d_fft_TB;
     a.count = count;
+    a.nout = nout;
     a.H = e->H;
-    a.L = qk::kFftN - e->H;
-    a.nblocks = (int)((count + a.L - 1) / a.L);
-    const int per_cu = env_int("QDSP_HIP_FFT_WG_PER_CU", 4);  // = occupancy: 126 VGPRs, 36.9 KB LDS
+    a.dec = fft_dec(e);
+    a.rot = e->rotate ? 1 : 0;
+    if (a.dec == 1) {
+        a.ov = e->ntaps - 1;        // FIR: out index == stream position
+        a.seg_shift = a.ov;
+        a.L = qk::kFftN - a.ov;
+        a.nblocks = (int)((count + a.L - 1) / a.L);
+    } else {
+        // resampler: y[n'] sits at stream position n'*dec - 1; segments start one sample early
+        a.ov = ((e->ntaps - 1 + a.dec - 1) / a.dec) * a.dec;
+        a.seg_shift = a.ov + 1;
+        a.L = qk::kFftN - a.ov;
+        const int per_block = a.L / a.dec;
+        a.nblocks = (int)((nout + per_block - 1) / per_block);
+    }
+    const int per_cu = env_int("QDSP_HIP_FFT_WG_PER_CU", 16);  // 4 resident per CU (124 VGPRs, 37 KB LDS); the rest queue
     int nwg = 256 * per_cu;
     if (nwg > a.nblocks) nwg = a.nblocks;
     a.nwg = nwg;
-    a.nt = env_int("QDSP_HIP_FFT_NT", 0);
+    if (a.rot) {
+        a.phase0 = e->phase;
+        a.dphase = e->dphase;
+        a.gm1 = e->volk_gain ? e->gm1 : 0.0f;
+        unit_of_fx(e->dphase, (long double)nwg * (long double)a.L, &a.rot_step.x, &a.rot_step.y);
+        for (int n2 = 0; n2 < 16; n2++) {
+            double c, sn;
+            unit_of_fx(e->dphase, (long double)(256 * n2), &c, &sn);
+            a.wtab[n2] = make_float2((float)c, (float)sn);
+        }
+    }
     rc = qk::launch_fir_fft(a, nwg + 1, s);
     if (rc) return rc;
     e->last.name = "fir_fft_kernel";
     e->last.grid = nwg + 1;
     e->last.block = qk::kFftNT;
-    e->last.lds = (int)(qk::kFftLdsElems * sizeof(float2));
+    e->last.lds = (int)((qk::kFftLdsElems + 16 * 17) * sizeof(float2));
     return 0;
 }
 
@@ -444,7 +479,7 @@ int64_t process_dev(Engine* e, const void* d_in, int64_t count, void* d_out, voi
     if (!e->has_filter) {
         rc = launch_xlate(e, d_in, count, d_out, s);
     } else if (fft_eligible(e, count)) {
-        rc = launch_fft(e, d_in, count, d_out, s);
+        rc = launch_fft(e, d_in, count, nout, d_out, s);
         if (rc == 0) e->cur ^= 1;
     } else if (use_core(e)) {
         qk::CoreArgs a;
@@ -715,6 +750,12 @@ QDSP_FIR_API(qdsp_hip_fir_f32, 1)
         Engine* e = as_engine(h, KIND_DECIM);                                                     \
         return e ? out_size(e, count) : QDSP_HIP_EINVAL;                                          \
     }                                                                                             \
+    int prefix##_set_mode(void* h, int mode) {                                                    \
+        Engine* e = as_engine(h, KIND_DECIM);                                                     \
+        if (!e || mode < 0 || mode > 2) return QDSP_HIP_EINVAL;                                   \
+        e->fir_mode = mode;                                                                       \
+        return 0;                                                                                 \
+    }                                                                                             \
     QDSP_FILTER_COMMON(prefix, KIND_DECIM)
 
 QDSP_DECIM_API(qdsp_hip_decim_cf32, 2)
@@ -823,6 +864,12 @@ int qdsp_hip_xlate_fir_decim_cf32_set_volk_gain(void* h, int on) {
     Engine* e = as_engine(h, KIND_VFO);
     if (!e) return QDSP_HIP_EINVAL;
     e->volk_gain = on != 0;
+    return 0;
+}
+int qdsp_hip_xlate_fir_decim_cf32_set_mode(void* h, int mode) {
+    Engine* e = as_engine(h, KIND_VFO);
+    if (!e || mode < 0 || mode > 2) return QDSP_HIP_EINVAL;
+    e->fir_mode = mode;
     return 0;
 }
 int64_t qdsp_hip_xlate_fir_decim_cf32_out_size(void* h, int64_t count) {

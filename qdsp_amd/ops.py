@@ -132,6 +132,12 @@ class _Op:
 
 
 class _HistMixin:
+    AUTO, DIRECT, FFT = 0, 1, 2
+
+    def set_mode(self, mode: int):
+        """AUTO / DIRECT (direct form) / FFT (overlap-save fast convolution), *_set_mode."""
+        capi.check(self._fn("set_mode")(self._h, int(mode)))
+
     def reset(self):
         capi.check(self._fn("reset")(self._h))
 
@@ -184,15 +190,9 @@ class Fir(_Op, _HistMixin):
         self._taps, p = _taps_ptr(taps)
         capi.check(self._fn("create")(C.byref(self._h), device, p, len(self._taps), max_block), self._prefix + "_create")
 
-    AUTO, DIRECT, FFT = 0, 1, 2
-
     def set_taps(self, taps):
         self._taps, p = _taps_ptr(taps)
         capi.check(self._fn("set_taps")(self._h, p, len(self._taps)))
-
-    def set_mode(self, mode: int):
-        """AUTO / DIRECT (k-ordered fmaf chain) / FFT (overlap-save), qdsp_hip_fir_cf32_set_mode."""
-        capi.check(self._fn("set_mode")(self._h, int(mode)))
 
 
 class Resampler(_Op, _HistMixin):

@@ -247,6 +247,54 @@ def test_fft_fir_chunk_invariance_and_linearity(ops, gold):
     assert num / den < TOL_FFT
 
 
+@pytest.mark.parametrize("dec", [2, 4, 8, 16])
+@pytest.mark.parametrize("ntaps", [17, 64, 255, 256, 257, 700])
+def test_fft_decimator_vs_oracle(ops, dec, ntaps):
+    """Overlap-save with pruned inverse (interp 1, decim in {2,4,8,16}), ragged calls."""
+    rng = np.random.default_rng(dec * 1000 + ntaps)
+    taps = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    n = 60_000
+    x = O.synth_iq(0, n, seed=dec + ntaps)
+    r = ops.Resampler(taps, 1, dec)
+    r.set_mode(r.FFT)
+    sizes = [20_003, 4097, 5, 3000, 32_895]   # count % dec != 0 -> per-call phase restart (SURVEY H4)
+    y = run_blocks(r, x, sizes)
+    assert r.last_kernel()["name"] == "fir_fft_kernel"
+    w64 = run_blocks(O.Resampler(taps, 1, dec, acc=O.ACC_F64), x, sizes)
+    w32 = run_blocks(O.Resampler(taps, 1, dec), x, sizes)
+    assert len(y) == len(w64)
+    assert rel_rms(y, w64) < TOL_FFT and rel_rms(y, w32) < TOL_FFT
+    assert np.array_equal(r.get_history(), x[n - ntaps:])
+    d = ops.Resampler(taps, 1, dec)
+    d.set_mode(d.DIRECT)
+    assert rel_rms(y, run_blocks(d, x, sizes)) < TOL_FFT
+
+
+@pytest.mark.parametrize("dec", [2, 8, 16])
+def test_fft_fused_vfo_vs_oracle(ops, gold, dec):
+    """NCO applied while loading the segment + overlap-save decimator, vs xlator -> resampler."""
+    taps = gold["taps256"]
+    n = 150_000
+    x = O.synth_iq(0, n, seed=40 + dec)
+    inc = ops.phase_delta(1.0, 0.1234)
+    sizes = [65_536, 30_001, 54_463]           # middle call not a multiple of 512: VOLK cadence restarts per call
+    for vg in (True, False):
+        v = ops.Vfo(taps, 1, dec, inc)
+        v.set_mode(v.FFT)
+        v.set_volk_gain(vg)
+        y = run_blocks(v, x, sizes)
+        assert v.last_kernel()["name"] == "fir_fft_kernel"
+        xl, rs = O.Xlator(1.0, 0.1234, exact=True, volk_gain=vg), O.Resampler(taps, 1, dec, acc=O.ACC_F64)
+        want = np.concatenate([rs.process(xl.process(x[a:b])) for a, b in ((0, 65_536), (65_536, 95_537), (95_537, n))])
+        assert len(y) == len(want) and rel_rms(y, want) < TOL_FFT
+    # carried NCO phase == the direct-form fused kernel's
+    d = ops.Vfo(taps, 1, dec, inc)
+    d.set_mode(d.DIRECT)
+    yd = run_blocks(d, x, sizes)
+    assert rel_rms(y, yd) < 1e-5   # (vg False vs True differ by the ~1e-5 sawtooth)
+    assert abs(v.get_phase() - d.get_phase()) < 1e-6
+
+
 # ------------------------------------------------------------------------------ resampler
 @pytest.mark.parametrize("LM", [(1, 2), (1, 8), (2, 1), (2, 3), (3, 7)])
 def test_resampler_golden(ops, gold, LM):
