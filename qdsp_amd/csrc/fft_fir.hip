@@ -75,7 +75,7 @@ __device__ __forceinline__ double2 dcmul(double2 a, double2 b) {
 // i.e. the last radix-16 digit n0 is a multiple of DEC: the inverse transform keeps only
 // those 16/DEC values of n0, and passes B'/A' run on 256/DEC lanes.
 template <int DEC, bool ROT>
-__global__ __launch_bounds__(kFftNT, 4) void fir_fft_kernel(const FftArgs a) {
+__global__ __launch_bounds__(kFftNT, DEC == 1 ? 4 : 3) void fir_fft_kernel(const FftArgs a) {
     __shared__ __attribute__((aligned(16))) float2 lds[kFftLdsElems + 16 * 17];
     float2* tbl = lds + kFftLdsElems;  // pass-B twiddles W256^(lo*k), rows padded to 17
     const int t = threadIdx.x;
@@ -105,18 +105,19 @@ __global__ __launch_bounds__(kFftNT, 4) void fir_fft_kernel(const FftArgs a) {
     }
 
     // per-lane constants, loaded once
+    // DEC == 1 keeps both tables in VGPRs (124 in all).  The pruned-inverse variants need a
+    // few more live values, so they re-read the pass-A twiddles from the L2-resident table
+    // every block (opaque pointer below) rather than spill.
     float2 ta[16], hf[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         hf[k] = a.Hf[t * 16 + k];
-        ta[k] = a.TA[t * 16 + k];
+        if (DEC == 1) ta[k] = a.TA[t * 16 + k];
     }
-    float2 ta2[16];  // pass-A' twiddles of the pruned inverse: lane w = n1*NS + s <-> element n1*16 + s*DEC
-    if (DEC > 1) {
-        const int e = (t / NS) * 16 + (t % NS) * DEC;
-#pragma unroll
-        for (int k = 0; k < 16; k++) ta2[k] = a.TA[(e & 255) * 16 + k];
-    }
+    // pass-A' twiddles of the pruned inverse: lane w = n1*NS + s <-> element n1*16 + s*DEC.
+    // Re-read from the (L2-resident) table every block by the 256/DEC active lanes instead of
+    // living in 32 more VGPRs: keeps the kernel at 128 VGPRs = 4 waves/SIMD without spills.
+    const int e0 = ((t / NS) * 16 + (t % NS) * DEC) & 255;
     tbl[(t >> 4) * 17 + (t & 15)] = a.TB[t];
     const float2* tb = tbl + lo * 17;
 
@@ -161,6 +162,12 @@ __global__ __launch_bounds__(kFftNT, 4) void fir_fft_kernel(const FftArgs a) {
         }
         // ---- pass A (over n2) + twiddle W4096^(t*k0) -----------------------------------
         fft16<false>(v);
+        if constexpr (DEC > 1) {
+            const float2* tap = a.TA + t * 16;
+            asm volatile("" : "+v"(tap) : "v"(v[0].x));  // opaque + ordered after the butterflies
+#pragma unroll
+            for (int k = 1; k < 16; k++) ta[k] = tap[k];
+        }
         __syncthreads();  // previous block's last LDS reads are done
 #pragma unroll
         for (int k = 0; k < 16; k++) lds[k * kFftRow1 + t] = (k == 0) ? v[rev16(0)] : cmulc<false>(v[rev16(k)], ta[k]);
@@ -237,13 +244,14 @@ __global__ __launch_bounds__(kFftNT, 4) void fir_fft_kernel(const FftArgs a) {
             }
             __syncthreads();
             if (t < NACT) {  // lane w = n1*NS + s : twiddle, pass A' over k0, store
+                const float2* ta2 = a.TA + e0 * 16;
+                asm volatile("" : "+v"(ta2) : "v"(v[0].x));  // opaque: not hoisted out of the block loop, not issued early
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
                     const float2 e = lds[t * kFftRow2 + k];
                     v[k] = (k == 0) ? e : cmulc<true>(e, ta2[k]);
                 }
                 fft16<true>(v);
-                const int e0 = (t / NS) * 16 + (t % NS) * DEC;         // element index for n2 = 0
                 const long long nb = ((long long)b * a.L - a.ov) / DEC;  // (b*L + i - ov)/DEC at i = 0
 #pragma unroll
                 for (int n2 = 0; n2 < 16; n2++) {
