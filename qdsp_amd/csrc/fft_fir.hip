@@ -264,12 +264,193 @@ __global__ __launch_bounds__(kFftNT, DEC == 1 ? 4 : 3) void fir_fft_kernel(const
     }
 }
 
+// Decimating variant, grouped: one workgroup runs the forward half (load [+NCO], passes
+// A, B, C, spectrum product, pass C') of DEC consecutive segments, each leaving only its
+// 16/DEC wanted values of n0 per lane in an LDS staging area; then ONE full-width inverse
+// (passes B', A' on all 256 lanes) finishes the DEC segments together.  Compared with
+// pruning inside a single segment (256/DEC active lanes, latency-bound) every pass runs on
+// all lanes and the inverse costs 1/DEC per segment.  The next segment's samples are
+// prefetched into registers while the current one is in passes B and C.
+// LDS: exchange buffer + staging = 2 x 34 KB -> 2 workgroups per CU.
+template <int DEC, bool ROT>
+__global__ __launch_bounds__(kFftNT, 2) void fir_fft_dec_kernel(const FftArgs a) {
+    __shared__ __attribute__((aligned(16))) float2 lds[2 * kFftLdsElems + 16 * 17];
+    float2* stage = lds + kFftLdsElems;      // [DEC*NACT rows][17]
+    float2* tbl = lds + 2 * kFftLdsElems;    // pass-B twiddles
+    const int t = threadIdx.x;
+    const int hi = t >> 4, lo = t & 15;
+    const int H = a.H;
+    constexpr int NS = 16 / DEC;
+    constexpr int NACT = 256 / DEC;
+
+    if ((int)blockIdx.x == a.nwg) {
+        for (int i = t; i < H; i += kFftNT) {
+            const long long g = a.count - H + i;
+            float2 v;
+            if (g < 0) {
+                v = a.hist[g + H];
+            } else {
+                v = a.in[g];
+                if (ROT) {
+                    const double2 p = fx_phasor(a.phase0 + (unsigned long long)g * a.dphase);
+                    const float gain = fmaf((float)(int)(g & 511), a.gm1, 1.0f);
+                    v = cmulc<false>(v, make_float2((float)p.x * gain, (float)p.y * gain));
+                }
+            }
+            a.hist_next[i] = v;
+        }
+        return;
+    }
+
+    // per-lane constants kept in registers: forward twiddles and the lane's spectrum slice; the
+    // inverse-pass twiddles (used once per group) are re-read from the L2-resident table
+    float2 ta[16], hf[16];
+    // inverse-pass lane w = bb*NACT + n1*NS + s  <->  element e0 = n1*16 + s*DEC of segment bb
+    const int wbb = t / NACT, wr = t % NACT;
+    const int e0 = (wr / NS) * 16 + (wr % NS) * DEC;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        hf[k] = a.Hf[t * 16 + k];
+        ta[k] = a.TA[t * 16 + k];
+    }
+    tbl[(t >> 4) * 17 + (t & 15)] = a.TB[t];
+    const float2* tb = tbl + lo * 17;
+
+    float2 pl = make_float2(1.0f, 0.0f);
+    if (ROT) {
+        const double2 p = fx_phasor((unsigned long long)t * a.dphase);
+        pl = make_float2((float)p.x, (float)p.y);
+    }
+
+    auto load_segment = [&](int b, float2 (&v)[16]) {
+        const long long seg0 = (long long)b * a.L - a.seg_shift;
+        if (b < a.nblocks && seg0 >= 0 && seg0 + kFftN <= a.count) {
+            const float2* __restrict__ p = a.in + seg0 + t;
+#pragma unroll
+            for (int n2 = 0; n2 < 16; n2++) v[n2] = p[n2 * 256];
+        } else {
+#pragma unroll
+            for (int n2 = 0; n2 < 16; n2++) {
+                const long long g = seg0 + n2 * 256 + t;
+                float2 x = make_float2(0.0f, 0.0f);
+                if (b < a.nblocks) {
+                    if (g < 0) { if (g + H >= 0) x = a.hist[g + H]; }
+                    else if (g < a.count) x = a.in[g];
+                }
+                v[n2] = x;
+            }
+        }
+    };
+
+    const int ngroups = (a.nblocks + DEC - 1) / DEC;
+#pragma unroll 1
+    for (int grp = blockIdx.x; grp < ngroups; grp += a.nwg) {
+        const int b0 = grp * DEC;
+        // NCO phasor of the group's first segment from the exact fixed-point phase (one FP64
+        // sincos per group and lane); later segments follow by an FP64 rotation of L samples.
+        double2 pb = make_double2(1.0, 0.0);
+        if (ROT) pb = fx_phasor(a.phase0 + (unsigned long long)((long long)b0 * a.L - a.seg_shift) * a.dphase);
+        float2 v[16], vn[16];
+        load_segment(b0, v);
+#pragma unroll 1
+        for (int bb = 0; bb < DEC; bb++) {
+            const int b = b0 + bb;
+            const long long seg0 = (long long)b * a.L - a.seg_shift;
+            if (ROT) {
+                const float2 q = cmulc<false>(make_float2((float)pb.x, (float)pb.y), pl);
+                pb = dcmul(pb, a.rot_step);
+#pragma unroll
+                for (int n2 = 0; n2 < 16; n2++) {
+                    const long long g = seg0 + n2 * 256 + t;
+                    const float gain = fmaf((float)(int)(g & 511), a.gm1, 1.0f);
+                    float2 ph = (n2 == 0) ? q : cmulc<false>(q, a.wtab[n2]);
+                    ph = make_float2(ph.x * gain, ph.y * gain);
+                    if (g >= 0) v[n2] = cmulc<false>(v[n2], ph);   // history is already rotated
+                }
+            }
+            // ---- pass A + twiddle ----------------------------------------------------------
+            fft16<false>(v);
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 16; k++) lds[k * kFftRow1 + t] = (k == 0) ? v[rev16(0)] : cmulc<false>(v[rev16(k)], ta[k]);
+            if (bb + 1 < DEC) load_segment(b + 1, vn);   // prefetch: lands during passes B and C
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; j++) v[j] = lds[hi * kFftRow1 + j * 16 + lo];
+            // ---- pass B + twiddle ----------------------------------------------------------
+            fft16<false>(v);
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                lds[(hi * 16 + k) * kFftRow2 + lo] = (k == 0) ? v[rev16(0)] : cmulc<false>(v[rev16(k)], tb[k]);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; j++) v[j] = lds[t * kFftRow2 + j];
+            // ---- pass C, spectrum product, pass C', keep n0 = s*DEC ---------------------------
+            fft16<false>(v);
+            float2 y[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) y[k] = cmulc<false>(v[rev16(k)], hf[k]);
+            fft16<true>(y);
+            // staging is only read after the group's last segment (barrier below): no hazard here
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                const int n0 = s * DEC;
+                stage[(bb * NACT + hi * NS + s) * kFftRow2 + lo] = (n0 == 0) ? y[rev16(0)] : cmulc<true>(y[rev16(n0)], tb[n0]);
+            }
+            if (bb + 1 < DEC) {
+#pragma unroll
+                for (int n2 = 0; n2 < 16; n2++) v[n2] = vn[n2];
+            }
+        }
+        __syncthreads();
+        // ---- inverse for the whole group: pass B' (lane u = bb*NACT + k0*NS + s, over k1) --------
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] = stage[t * kFftRow2 + j];
+        fft16<true>(v);
+        {   // -> row (bb*NACT + n1*NS + s), column k0, in the exchange buffer (free since pass C)
+            const int ubb = t / NACT, ur = t % NACT;
+            const int k0 = ur / NS, s = ur % NS;
+#pragma unroll
+            for (int j = 0; j < 16; j++) lds[(ubb * NACT + j * NS + s) * kFftRow2 + k0] = v[rev16(j)];
+        }
+        __syncthreads();
+        // ---- pass A' (lane w = bb*NACT + n1*NS + s, over k0) and store -----------------------------
+        {
+            const float2* ta2 = a.TA + e0 * 16;
+            asm volatile("" : "+v"(ta2) : "v"(v[0].x));  // opaque: re-read per group, after pass B'
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const float2 e = lds[t * kFftRow2 + k];
+                v[k] = (k == 0) ? e : cmulc<true>(e, ta2[k]);
+            }
+        }
+        fft16<true>(v);
+        const int b = b0 + wbb;
+        const long long nb = ((long long)b * a.L - a.ov) / DEC;  // (b*L + i - ov)/DEC at i = 0 (ov, L multiples of DEC)
+#pragma unroll
+        for (int n2 = 0; n2 < 16; n2++) {
+            const int i = n2 * 256 + e0;
+            const long long n = nb + i / DEC;
+            if (b < a.nblocks && i >= a.ov && n < a.nout) a.out[n] = v[rev16(n2)];
+        }
+        // next group's pass-A write to `lds` is behind that group's first barrier; its staging
+        // writes are behind several more: no extra barrier needed here.
+    }
+}
+
 int launch_fir_fft(const FftArgs& a, int grid, hipStream_t stream) {
-#define QK_FFT(dec, rot) hipLaunchKernelGGL((fir_fft_kernel<dec, rot>), dim3(grid), dim3(kFftNT), 0, stream, a)
+#define QK_FFT(dec, rot) hipLaunchKernelGGL((fir_fft_dec_kernel<dec, rot>), dim3(grid), dim3(kFftNT), 0, stream, a)
     const bool r = a.rot != 0;
     switch (a.dec) {
-        case 1: if (r) return -1; QK_FFT(1, false); break;
-        case 2: if (r) QK_FFT(2, true); else QK_FFT(2, false); break;
+        case 1:
+            if (r) return -1;
+            hipLaunchKernelGGL((fir_fft_kernel<1, false>), dim3(grid), dim3(kFftNT), 0, stream, a);
+            break;
+        case 2:  // half the outputs are kept: the per-segment pruned inverse (128 active lanes) is enough
+            if (r) hipLaunchKernelGGL((fir_fft_kernel<2, true>), dim3(grid), dim3(kFftNT), 0, stream, a);
+            else hipLaunchKernelGGL((fir_fft_kernel<2, false>), dim3(grid), dim3(kFftNT), 0, stream, a);
+            break;
         case 4: if (r) QK_FFT(4, true); else QK_FFT(4, false); break;
         case 8: if (r) QK_FFT(8, true); else QK_FFT(8, false); break;
         case 16: if (r) QK_FFT(16, true); else QK_FFT(16, false); break;

@@ -420,15 +420,21 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
         const int per_block = a.L / a.dec;
         a.nblocks = (int)((nout + per_block - 1) / per_block);
     }
-    const int per_cu = env_int("QDSP_HIP_FFT_WG_PER_CU", 16);  // 4 resident per CU (124 VGPRs, 37 KB LDS); the rest queue
+    // FIR: 4 workgroups resident per CU (124 VGPRs, 37 KB LDS), 16 queued per CU for balance.
+    // Decimators work in groups of `dec` segments, 2 resident per CU (70 KB LDS).
+    const bool grouped = a.dec >= 4;
+    const int per_cu = env_int("QDSP_HIP_FFT_WG_PER_CU", grouped ? 4 : 16);
+    const int units = grouped ? (a.nblocks + a.dec - 1) / a.dec : a.nblocks;
     int nwg = 256 * per_cu;
-    if (nwg > a.nblocks) nwg = a.nblocks;
+    if (nwg > units) nwg = units;
     a.nwg = nwg;
     if (a.rot) {
         a.phase0 = e->phase;
         a.dphase = e->dphase;
         a.gm1 = e->volk_gain ? e->gm1 : 0.0f;
-        unit_of_fx(e->dphase, (long double)nwg * (long double)a.L, &a.rot_step.x, &a.rot_step.y);
+        // segment -> next segment handled by the same workgroup: L samples (grouped kernel),
+        // nwg*L samples (per-segment kernel)
+        unit_of_fx(e->dphase, grouped ? (long double)a.L : (long double)nwg * (long double)a.L, &a.rot_step.x, &a.rot_step.y);
         for (int n2 = 0; n2 < 16; n2++) {
             double c, sn;
             unit_of_fx(e->dphase, (long double)(256 * n2), &c, &sn);
@@ -440,7 +446,7 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
     e->last.name = "fir_fft_kernel";
     e->last.grid = nwg + 1;
     e->last.block = qk::kFftNT;
-    e->last.lds = (int)((qk::kFftLdsElems + 16 * 17) * sizeof(float2));
+    e->last.lds = (int)(((grouped ? 2 : 1) * qk::kFftLdsElems + 16 * 17) * sizeof(float2));
     return 0;
 }
 
