@@ -99,6 +99,9 @@ int qdsp_hip_fir_cf32_history_len(void* h);
 int qdsp_hip_fir_cf32_get_history(void* h, float* hist_iq);
 int qdsp_hip_fir_cf32_set_history(void* h, const float* hist_iq);
 int qdsp_hip_fir_cf32_history_dev(void* h, void** d_hist);
+/* Copy `history_len` samples from device memory into the history the next call reads,
+ * asynchronously on `hip_stream` (e.g. from the buffer an RCCL recv just filled). */
+int qdsp_hip_fir_cf32_set_history_dev(void* h, const void* d_hist, void* hip_stream);
 void qdsp_hip_fir_cf32_destroy(void* h);
 
 /* ---- FIR<float> : src/dsp/filter.h:58-62 (volk_32f_x2_dot_prod_32f) -------------------- */
@@ -113,6 +116,7 @@ int qdsp_hip_fir_f32_history_len(void* h);
 int qdsp_hip_fir_f32_get_history(void* h, float* hist);
 int qdsp_hip_fir_f32_set_history(void* h, const float* hist);
 int qdsp_hip_fir_f32_history_dev(void* h, void** d_hist);
+int qdsp_hip_fir_f32_set_history_dev(void* h, const void* d_hist, void* hip_stream);
 void qdsp_hip_fir_f32_destroy(void* h);
 
 /* ---- PolyphaseResampler<complex_t> : src/dsp/resampling.h:99-132 ----------------------- */
@@ -141,6 +145,7 @@ int qdsp_hip_decim_cf32_history_len(void* h); /* = taps per phase */
 int qdsp_hip_decim_cf32_get_history(void* h, float* hist_iq);
 int qdsp_hip_decim_cf32_set_history(void* h, const float* hist_iq);
 int qdsp_hip_decim_cf32_history_dev(void* h, void** d_hist);
+int qdsp_hip_decim_cf32_set_history_dev(void* h, const void* d_hist, void* hip_stream);
 void qdsp_hip_decim_cf32_destroy(void* h);
 
 /* ---- PolyphaseResampler<float> : src/dsp/resampling.h:113-119 -------------------------- */
@@ -157,6 +162,7 @@ int qdsp_hip_decim_f32_history_len(void* h);
 int qdsp_hip_decim_f32_get_history(void* h, float* hist);
 int qdsp_hip_decim_f32_set_history(void* h, const float* hist);
 int qdsp_hip_decim_f32_history_dev(void* h, void** d_hist);
+int qdsp_hip_decim_f32_set_history_dev(void* h, const void* d_hist, void* hip_stream);
 void qdsp_hip_decim_f32_destroy(void* h);
 
 /* ---- FrequencyXlator<complex_t> : src/dsp/processing.h:55-70 --------------------------- */
@@ -211,7 +217,30 @@ int qdsp_hip_xlate_fir_decim_cf32_history_len(void* h);
 int qdsp_hip_xlate_fir_decim_cf32_get_history(void* h, float* hist_iq);
 int qdsp_hip_xlate_fir_decim_cf32_set_history(void* h, const float* hist_iq);
 int qdsp_hip_xlate_fir_decim_cf32_history_dev(void* h, void** d_hist);
+int qdsp_hip_xlate_fir_decim_cf32_set_history_dev(void* h, const void* d_hist, void* hip_stream);
 void qdsp_hip_xlate_fir_decim_cf32_destroy(void* h);
+
+/* ---- channelizer: Splitter -> N x VFO (src/dsp/routing.h:47-57 + src/dsp/vfo.h), batched ---- */
+/* N frequency-translating decimators on ONE input stream: channel c is exactly
+ * xlate_fir_decim_cf32 with phase increment (phase_inc_re[c], phase_inc_im[c]); all channels
+ * share taps / interp / decim.  Output is channel-major: channel c's samples start at
+ * out + c*out_stride (complex samples).  process* return the per-channel output count.
+ * This round runs one fused kernel per channel on the same stream (the input stays in
+ * L2 / Infinity Cache across channels); a shared-forward-transform kernel is the planned
+ * replacement and will keep this ABI. */
+int qdsp_hip_chan_cf32_create(void** h, int device, const float* taps, int ntaps, int interp,
+                              int decim, int nchan, const float* phase_inc_re,
+                              const float* phase_inc_im, int max_block);
+int qdsp_hip_chan_cf32_process(void* h, const float* in_iq, int count, float* out_iq, int out_stride);
+int64_t qdsp_hip_chan_cf32_process_dev(void* h, const void* d_in, int64_t count, void* d_out,
+                                       int64_t out_stride, void* hip_stream);
+int64_t qdsp_hip_chan_cf32_out_size(void* h, int64_t count);
+int qdsp_hip_chan_cf32_set_phase_inc(void* h, int chan, float phase_inc_re, float phase_inc_im);
+int qdsp_hip_chan_cf32_set_mode(void* h, int mode);
+int qdsp_hip_chan_cf32_set_volk_gain(void* h, int on);
+int qdsp_hip_chan_cf32_reset(void* h);
+int qdsp_hip_chan_cf32_channels(void* h);
+void qdsp_hip_chan_cf32_destroy(void* h);
 
 /* ---- synthetic IQ source (measurement harness) ------------------------------ */
 /* Counter-based uniform [-1,1) per float component, generated on device so benchmarks are

@@ -105,7 +105,19 @@ def load():
         sig(p + "_get_history", i32, vp, vp)
         sig(p + "_set_history", i32, vp, vp)
         sig(p + "_history_dev", i32, vp, pvp)
+        sig(p + "_set_history_dev", i32, vp, vp, vp)
         sig(p + "_destroy", None, vp)
+    p = "qdsp_hip_chan_cf32"
+    sig(p + "_create", i32, pvp, i32, fp, i32, i32, i32, i32, fp, fp, i32)
+    sig(p + "_process", i32, vp, vp, i32, vp, i32)
+    sig(p + "_process_dev", i64, vp, vp, i64, vp, i64, vp)
+    sig(p + "_out_size", i64, vp, i64)
+    sig(p + "_set_phase_inc", i32, vp, i32, C.c_float, C.c_float)
+    sig(p + "_set_mode", i32, vp, i32)
+    sig(p + "_set_volk_gain", i32, vp, i32)
+    sig(p + "_reset", i32, vp)
+    sig(p + "_channels", i32, vp)
+    sig(p + "_destroy", None, vp)
     sig("qdsp_hip_synth_iq_dev", i32, i32, vp, i64, i64, C.c_uint32, vp)
     sig("qdsp_hip_last_kernel", i32, vp, C.c_char_p, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32))
     sig("qdsp_hip_time_process_dev", i32, vp, vp, i64, vp, vp, i32, fp)

@@ -23,7 +23,7 @@ namespace {
 
 constexpr int kMaxDynLds = 64 * 1024;  // default dynamic-LDS ceiling; tiles are sized under it
 
-enum Kind : int { KIND_FIR = 1, KIND_DECIM = 2, KIND_XLATE = 3, KIND_VFO = 4 };
+enum Kind : int { KIND_FIR = 1, KIND_DECIM = 2, KIND_XLATE = 3, KIND_VFO = 4, KIND_CHAN = 5 };
 constexpr uint32_t kMagic = 0x51445350u;  // "QDSP"
 
 struct Launch {
@@ -575,6 +575,15 @@ int set_history(Engine* e, const float* hist) {
     return 0;
 }
 
+int set_history_dev(Engine* e, const void* d_hist, void* stream) {
+    if (!d_hist) return QDSP_HIP_EINVAL;
+    HIPCHK(hipSetDevice(e->device));
+    if (e->H > 0)
+        HIPCHK(hipMemcpyAsync(e->d_hist[e->cur], d_hist, (size_t)e->H * e->ch * sizeof(float), hipMemcpyDeviceToDevice,
+                              static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 int get_phase(Engine* e, float* re, float* im) {
     if (!re || !im) return QDSP_HIP_EINVAL;
     double c, s;
@@ -609,6 +618,46 @@ int time_process(Engine* e, const void* d_in, int64_t count, void* d_out, void* 
 Engine* any_engine(void* h) {
     Engine* e = static_cast<Engine*>(h);
     return (e && e->magic == kMagic) ? e : nullptr;
+}
+
+// ---- channelizer: N fused VFOs on one input (Splitter -> N x VFO in the reference) ----------
+constexpr uint32_t kChanMagic = 0x4348414eu;  // "CHAN"
+struct Chan {
+    uint32_t magic = kChanMagic;
+    int device = 0;
+    int nchan = 0;
+    std::vector<Engine*> vfo;      // one fused xlate+FIR+decimate engine per channel
+    hipStream_t stream = nullptr;  // host-pointer path
+    void* d_in = nullptr;
+    void* d_out = nullptr;
+    int max_block = 0;
+    size_t out_cap = 0;            // samples per channel
+};
+Chan* as_chan(void* h) {
+    Chan* c = static_cast<Chan*>(h);
+    return (c && c->magic == kChanMagic) ? c : nullptr;
+}
+void chan_destroy(Chan* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (Engine* e : c->vfo) destroy(e);
+    if (c->d_in) (void)hipFree(c->d_in);
+    if (c->d_out) (void)hipFree(c->d_out);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    c->magic = 0;
+    delete c;
+}
+int64_t chan_process_dev(Chan* c, const void* d_in, int64_t count, void* d_out, int64_t out_stride, void* stream) {
+    if (count < 0 || c->vfo.empty()) return QDSP_HIP_EINVAL;
+    const int64_t nout = out_size(c->vfo[0], count);
+    if (out_stride < nout) return QDSP_HIP_EINVAL;
+    for (int i = 0; i < c->nchan; i++) {
+        float2* o = static_cast<float2*>(d_out) + (size_t)i * out_stride;
+        const int64_t r = process_dev(c->vfo[i], d_in, count, o, stream);
+        if (r < 0) return r;
+    }
+    return nout;
 }
 
 }  // namespace
@@ -685,6 +734,10 @@ int qdsp_hip_device_sync(int device) { HIPCHK(hipSetDevice(device)); HIPCHK(hipD
         if (!e || !d) return QDSP_HIP_EINVAL;                                                     \
         *d = e->d_hist[e->cur];                                                                   \
         return 0;                                                                                 \
+    }                                                                                             \
+    int prefix##_set_history_dev(void* h, const void* d, void* s) {                               \
+        Engine* e = as_engine(h, KIND);                                                           \
+        return e ? set_history_dev(e, d, s) : QDSP_HIP_EINVAL;                                    \
     }                                                                                             \
     void prefix##_destroy(void* h) { Engine* e = as_engine(h, KIND); if (e) destroy(e); }
 
@@ -883,6 +936,86 @@ int64_t qdsp_hip_xlate_fir_decim_cf32_out_size(void* h, int64_t count) {
     return e ? out_size(e, count) : QDSP_HIP_EINVAL;
 }
 QDSP_FILTER_COMMON(qdsp_hip_xlate_fir_decim_cf32, KIND_VFO)
+
+// ---- channelizer ------------------------------------------------------------------------------
+int qdsp_hip_chan_cf32_create(void** h, int device, const float* taps, int ntaps, int interp, int decim, int nchan,
+                              const float* phase_inc_re, const float* phase_inc_im, int max_block) {
+    if (!h || nchan <= 0 || !phase_inc_re || !phase_inc_im) return QDSP_HIP_EINVAL;
+    *h = nullptr;
+    Chan* c = new (std::nothrow) Chan();
+    if (!c) return QDSP_HIP_ENOMEM;
+    c->device = device;
+    c->nchan = nchan;
+    int rc = 0;
+    for (int i = 0; i < nchan && rc == 0; i++) {
+        void* eh = nullptr;
+        rc = qdsp_hip_xlate_fir_decim_cf32_create(&eh, device, taps, ntaps, interp, decim, phase_inc_re[i], phase_inc_im[i], 0);
+        if (rc == 0) c->vfo.push_back(static_cast<Engine*>(eh));
+    }
+    if (rc == 0 && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) rc = QDSP_HIP_ENOMEM;
+    if (rc == 0 && max_block > 0) {
+        const size_t oc = (size_t)out_size(c->vfo[0], max_block) + 1;
+        if (hipMalloc(&c->d_in, (size_t)max_block * 8) != hipSuccess || hipMalloc(&c->d_out, oc * 8 * nchan) != hipSuccess) rc = QDSP_HIP_ENOMEM;
+        c->max_block = max_block;
+        c->out_cap = oc;
+    }
+    if (rc) { chan_destroy(c); return rc; }
+    *h = c;
+    return 0;
+}
+int64_t qdsp_hip_chan_cf32_out_size(void* h, int64_t count) {
+    Chan* c = as_chan(h);
+    return c ? out_size(c->vfo[0], count) : QDSP_HIP_EINVAL;
+}
+int64_t qdsp_hip_chan_cf32_process_dev(void* h, const void* d_in, int64_t count, void* d_out, int64_t out_stride, void* s) {
+    Chan* c = as_chan(h);
+    if (!c) return QDSP_HIP_EINVAL;
+    HIPCHK(hipSetDevice(c->device));
+    return chan_process_dev(c, d_in, count, d_out, out_stride, s);
+}
+int qdsp_hip_chan_cf32_process(void* h, const float* in, int count, float* out, int out_stride) {
+    Chan* c = as_chan(h);
+    if (!c || count < 0 || count > c->max_block) return c ? QDSP_HIP_ESIZE : QDSP_HIP_EINVAL;
+    HIPCHK(hipSetDevice(c->device));
+    if (count) HIPCHK(hipMemcpyAsync(c->d_in, in, (size_t)count * 8, hipMemcpyHostToDevice, c->stream));
+    const int64_t nout = chan_process_dev(c, c->d_in, count, c->d_out, (int64_t)c->out_cap, c->stream);
+    if (nout < 0) return (int)nout;
+    if (out_stride < nout) return QDSP_HIP_EINVAL;
+    if (nout)
+        HIPCHK(hipMemcpy2DAsync(out, (size_t)out_stride * 8, c->d_out, c->out_cap * 8, (size_t)nout * 8, c->nchan,
+                                hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return (int)nout;
+}
+int qdsp_hip_chan_cf32_set_phase_inc(void* h, int chan, float re, float im) {
+    Chan* c = as_chan(h);
+    if (!c || chan < 0 || chan >= c->nchan || (re == 0.0f && im == 0.0f)) return QDSP_HIP_EINVAL;
+    set_inc(c->vfo[chan], re, im);
+    return 0;
+}
+int qdsp_hip_chan_cf32_set_mode(void* h, int mode) {
+    Chan* c = as_chan(h);
+    if (!c || mode < 0 || mode > 2) return QDSP_HIP_EINVAL;
+    for (Engine* e : c->vfo) e->fir_mode = mode;
+    return 0;
+}
+int qdsp_hip_chan_cf32_set_volk_gain(void* h, int on) {
+    Chan* c = as_chan(h);
+    if (!c) return QDSP_HIP_EINVAL;
+    for (Engine* e : c->vfo) e->volk_gain = on != 0;
+    return 0;
+}
+int qdsp_hip_chan_cf32_reset(void* h) {
+    Chan* c = as_chan(h);
+    if (!c) return QDSP_HIP_EINVAL;
+    for (Engine* e : c->vfo) { int rc = reset(e); if (rc) return rc; }
+    return 0;
+}
+int qdsp_hip_chan_cf32_channels(void* h) {
+    Chan* c = as_chan(h);
+    return c ? c->nchan : QDSP_HIP_EINVAL;
+}
+void qdsp_hip_chan_cf32_destroy(void* h) { Chan* c = as_chan(h); if (c) chan_destroy(c); }
 
 // ---- harness ----------------------------------------------------------------------------------
 int qdsp_hip_synth_iq_dev(int device, void* d_out, int64_t first_sample, int64_t count, uint32_t seed, void* stream) {

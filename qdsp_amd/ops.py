@@ -161,6 +161,15 @@ class _HistMixin:
         capi.check(self._fn("history_dev")(self._h, C.byref(p)))
         return p.value or 0
 
+    def set_history_dev(self, t):
+        """Device-to-device copy of `history_len` samples from torch tensor `t` into the history
+        the next call reads, on torch's current stream (*_set_history_dev)."""
+        import torch
+
+        assert t.is_cuda and t.is_contiguous() and t.numel() == self.history_len
+        stream = torch.cuda.current_stream(t.device).cuda_stream
+        capi.check(self._fn("set_history_dev")(self._h, t.data_ptr(), stream))
+
     def history_dev_tensor(self):
         """The device history buffer the NEXT process call reads, as a torch view (no copy):
         an RCCL recv of the neighbour's tail can land here directly (multi-GPU halo)."""
@@ -267,6 +276,69 @@ class Vfo(_Op, _HistMixin, _NcoMixin):
         return int(capi.check(self._fn("out_size")(self._h, n)))
 
 
+class Channelizer:
+    """Splitter -> N x VFO (src/dsp/routing.h:47-57, src/dsp/vfo.h) as one operator:
+    qdsp_hip_chan_cf32_*.  process() returns an (nchan, outCount) array / tensor."""
+
+    AUTO, DIRECT, FFT = 0, 1, 2
+
+    def __init__(self, taps, interp: int, decim: int, phase_incs, device: int = 0, max_block: int = 1_000_000):
+        self._L = capi.load()
+        self._h = C.c_void_p()
+        self.device = device
+        self._taps, p = _taps_ptr(taps)
+        incs = np.asarray(phase_incs, dtype=np.float32).reshape(-1, 2)
+        self.nchan = len(incs)
+        re, im = np.ascontiguousarray(incs[:, 0]), np.ascontiguousarray(incs[:, 1])
+        fp = C.POINTER(C.c_float)
+        capi.check(self._L.qdsp_hip_chan_cf32_create(C.byref(self._h), device, p, len(self._taps), int(interp), int(decim),
+                                                     self.nchan, re.ctypes.data_as(fp), im.ctypes.data_as(fp), max_block),
+                   "qdsp_hip_chan_cf32_create")
+
+    def close(self):
+        if self._h:
+            self._L.qdsp_hip_chan_cf32_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_mode(self, mode: int):
+        capi.check(self._L.qdsp_hip_chan_cf32_set_mode(self._h, int(mode)))
+
+    def set_volk_gain(self, on: bool):
+        capi.check(self._L.qdsp_hip_chan_cf32_set_volk_gain(self._h, int(bool(on))))
+
+    def reset(self):
+        capi.check(self._L.qdsp_hip_chan_cf32_reset(self._h))
+
+    def out_size(self, n: int) -> int:
+        return int(capi.check(self._L.qdsp_hip_chan_cf32_out_size(self._h, n)))
+
+    def process(self, x, out=None):
+        if _is_torch(x):
+            import torch
+
+            assert x.is_cuda and x.is_contiguous() and x.dtype == torch.complex64
+            n, no = x.numel(), self.out_size(x.numel())
+            if out is None:
+                out = torch.empty((self.nchan, max(no, 1)), dtype=torch.complex64, device=x.device)
+            assert out.is_contiguous() and out.shape[0] == self.nchan and out.shape[1] >= no
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            rc = self._L.qdsp_hip_chan_cf32_process_dev(self._h, x.data_ptr(), n, out.data_ptr(), out.shape[1], stream)
+            capi.check(int(rc), "qdsp_hip_chan_cf32_process_dev")
+            return out[:, :no]
+        a = np.ascontiguousarray(x, dtype=np.complex64)
+        no = self.out_size(a.size)
+        y = np.empty((self.nchan, max(no, 1)), dtype=np.complex64)
+        rc = self._L.qdsp_hip_chan_cf32_process(self._h, a.ctypes.data, a.size, y.ctypes.data, y.shape[1])
+        capi.check(rc, "qdsp_hip_chan_cf32_process")
+        return y[:, :no]
+
+
 def synth_iq(count: int, first_sample: int = 0, seed: int = 1234, device: int = 0, out=None):
     """Counter-based uniform IQ generated on the device (measurement input)."""
     import torch
@@ -286,4 +358,4 @@ def device_info(device: int = 0) -> dict:
     return {"name": name.value.decode(), "arch": arch.value.decode(), "compute_units": cus.value}
 
 
-__all__ = ["Fir", "Resampler", "Xlator", "Vfo", "synth_iq", "phase_delta", "device_info"]
+__all__ = ["Fir", "Resampler", "Xlator", "Vfo", "Channelizer", "synth_iq", "phase_delta", "device_info"]

@@ -466,3 +466,34 @@ def test_full_size_properties(ops, gold):
     ref = y[7::8][: yd.numel() - 1]          # y_dec[n] = y_fir[8n - 1]
     d = (yd[1:] - ref).abs().max().item()
     assert d < 3e-6
+
+
+# ------------------------------------------------------------------------------ channelizer (BASELINE configs[4])
+@pytest.mark.parametrize("dec", [8, 64])
+def test_channelizer_64_channels(ops, gold, dec):
+    """64 frequency-translating decimators on one stream == Splitter -> 64 x VFO
+    (src/dsp/routing.h:47-57 + src/dsp/vfo.h): offsets (c - 31.5) fs/64, 256 taps."""
+    taps = gold["taps256"]
+    nch, fs = 64, 1.0
+    n = 131_072 if dec == 8 else 65_536
+    x = O.synth_iq(0, n, seed=64 + dec)
+    offs = [(c - 31.5) * fs / nch for c in range(nch)]
+    incs = [ops.phase_delta(fs, -f) for f in offs]          # VFO: xlator(-offset), vfo.h:28
+    ch = ops.Channelizer(taps, 1, dec, incs)
+    sizes = [n // 2, n // 2]
+    ys = [np.array(ch.process(x[:sizes[0]])), np.array(ch.process(x[sizes[0]:]))]   # host-pointer path, 2 calls
+    y = np.concatenate(ys, axis=1)
+    assert y.shape == (nch, n // dec)
+    for c in (0, 1, 17, 31, 32, 63):
+        xl = O.Xlator(fs, -offs[c], exact=True, volk_gain=True)
+        rs = O.Resampler(taps, 1, dec, acc=O.ACC_F64)
+        want = np.concatenate([rs.process(xl.process(x[:sizes[0]])), rs.process(xl.process(x[sizes[0]:]))])
+        assert rel_rms(y[c], want) < 2e-6, c
+    # device path, one call, same numbers as the per-channel fused operator
+    import torch
+
+    ch2 = ops.Channelizer(taps, 1, dec, incs)
+    yd = ch2.process(dev(x)).cpu().numpy()
+    v = ops.Vfo(taps, 1, dec, incs[17])
+    assert np.array_equal(yd[17], np.array(v.process(x)))
+    torch.cuda.synchronize()
