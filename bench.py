@@ -267,7 +267,7 @@ def main():
     torch.cuda.synchronize()
 
     # Halo check (outside the timed region, no oracle): a fresh operator fed the predecessor's
-    # regenerated tail + my head must reproduce my head bit for bit.
+    # regenerated tail + my head must reproduce my head.
     if world > 1 and H and not w["rot"]:
         step()
         torch.cuda.synchronize()
@@ -277,8 +277,11 @@ def main():
         chk.set_history(prev_tail.cpu().numpy())
         ref = chk.process(x[:m])
         torch.cuda.synchronize()
-        if not torch.equal(ref, out[: ref.numel()]):
-            raise SystemExit(f"rank {rank}: halo exchange produced different outputs than the unsharded filter")
+        # (not bit-equal by construction: the short reference call ends in a zero-padded FFT
+        # segment where the full chunk has real samples; a wrong halo is an O(1) error)
+        err = (ref - out[: ref.numel()]).abs().max().item()
+        if not err < 2e-6 * max(ref.abs().max().item(), 1e-30):
+            raise SystemExit(f"rank {rank}: halo exchange produced different outputs than the unsharded filter (max err {err:.3e})")
         chk.close()
 
     if world > 1:
