@@ -198,6 +198,10 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    def dbg(msg):
+        if os.environ.get("QDSP_BENCH_DEBUG"):
+            print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
+
     w = WORKLOADS[args.workload]
     n = 1 << args.log2n
     op = make_op(ops, args.workload, local_rank)
@@ -260,6 +264,7 @@ def main():
             if args.workload in ("xlate", "xlate_fir_decim8") and world > 1:
                 op.advance((world - 1) * n)
             torch.cuda.synchronize()
+    dbg("spinup done")
     for _ in range(args.warmup):
         step()
         if args.workload in ("xlate", "xlate_fir_decim8") and world > 1:
@@ -284,6 +289,7 @@ def main():
             raise SystemExit(f"rank {rank}: halo exchange produced different outputs than the unsharded filter (max err {err:.3e})")
         chk.close()
 
+    dbg("halo check done")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -300,11 +306,13 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    dbg("timed loop done")
     ms_per_step = dt / args.steps * 1e3
     value = world * n / (dt / args.steps) / 1e6
 
     # Dominant kernel, timed with HIP events on the stream it is launched on.
     kms = op.time_dev(x, out, args.kernel_iters)
+    dbg("kernel timing done")
     kinfo = op.last_kernel()
     torch.cuda.synchronize()
     achieved_gbs = w["bytes"] * n / (kms * 1e-3) / 1e9
