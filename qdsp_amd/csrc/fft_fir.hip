@@ -53,6 +53,12 @@ template <bool INV> __device__ __forceinline__ void fft16(float2 (&v)[16]) {
     for (int k0 = 0; k0 < 4; k0++) fft4<INV>(v[4 * k0], v[4 * k0 + 1], v[4 * k0 + 2], v[4 * k0 + 3]);
 }
 
+// Column of element e in LDS layout 1 ([k0][element], row pitch kFftRow1 = 272): even elements
+// first, odd elements from column 136.  Keeps the pass-A writes (lanes own elements 2l', then
+// 2l'+1) contiguous and the pass-B reads (16 consecutive elements per 16 lanes) conflict-free:
+// evens on banks 16j.., odds +16, the next k0 row (+544 dwords) +32.
+__host__ __device__ constexpr int pos1(int e) { return (e >> 1) + 136 * (e & 1); }
+
 // ---- NCO helpers (same definitions as kernels.hip.h; this TU is built separately) ------
 __device__ __forceinline__ double2 fx_phasor(unsigned long long ph) {
     const double t = (double)(ph >> 11) * (1.0 / 9007199254740992.0);
@@ -81,6 +87,12 @@ __global__ __launch_bounds__(kFftNT, DEC == 1 ? 4 : 3) void fir_fft_kernel(const
     const int t = threadIdx.x;
     const int hi = t >> 4, lo = t & 15;
     const int H = a.H;
+    // Element of the segment this lane owns in passes A / A' (all 16 rows n2 of it).  Lanes l and
+    // l+32 of a wave own the adjacent elements 2l', 2l'+1 so that one 16-byte load/store covers
+    // both: each lane moves float4s for half the rows and trades halves with v_permlane32_swap.
+    const int te = (t & ~63) | ((t & 31) << 1) | ((t >> 5) & 1);
+    const int half = (t >> 5) & 1;
+    const int pte = pos1(te);
     constexpr int NS = 16 / DEC;       // kept values of n0: 0, DEC, 2*DEC, ...
     constexpr int NACT = 256 / DEC;    // lanes active in the pruned inverse passes
 
@@ -112,7 +124,7 @@ __global__ __launch_bounds__(kFftNT, DEC == 1 ? 4 : 3) void fir_fft_kernel(const
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         hf[k] = a.Hf[t * 16 + k];
-        if (DEC == 1) ta[k] = a.TA[t * 16 + k];
+        if (DEC == 1) ta[k] = a.TA[te * 16 + k];
     }
     // pass-A' twiddles of the pruned inverse: lane w = n1*NS + s <-> element n1*16 + s*DEC.
     // Re-read from the (L2-resident) table every block by the 256/DEC active lanes instead of
@@ -124,7 +136,7 @@ __global__ __launch_bounds__(kFftNT, DEC == 1 ? 4 : 3) void fir_fft_kernel(const
     float2 pl = make_float2(1.0f, 0.0f);   // exp(j 2pi t dphase)
     double2 pb = make_double2(1.0, 0.0);   // exp(j 2pi (phase0 + seg0 dphase)) of the current block
     if (ROT) {
-        const double2 p = fx_phasor((unsigned long long)t * a.dphase);
+        const double2 p = fx_phasor((unsigned long long)te * a.dphase);
         pl = make_float2((float)p.x, (float)p.y);
         pb = fx_phasor(a.phase0 + (unsigned long long)((long long)blockIdx.x * a.L - a.seg_shift) * a.dphase);
     }
@@ -133,15 +145,28 @@ __global__ __launch_bounds__(kFftNT, DEC == 1 ? 4 : 3) void fir_fft_kernel(const
         const long long seg0 = (long long)b * a.L - a.seg_shift;  // stream position of element 0
         const bool interior = seg0 >= 0 && seg0 + kFftN <= a.count;
         float2 v[16];
-        // ---- load: lane t takes elements n2*256 + t ------------------------------------
-        if (interior) {
-            const float2* __restrict__ p = a.in + seg0 + t;
+        // ---- load: the lane ends up with elements n2*256 + te, n2 = 0..15 ------------------
+        if (interior && a.vec) {
+            // rows half*8 + r, elements (te & ~1, +1); row pitch 256 samples = 128 float4
+            const float4* __restrict__ p4 = reinterpret_cast<const float4*>(a.in + seg0 + (te & ~1)) + half * 8 * 128;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const float4 q4 = p4[r * 128];
+                // x/y regs: lanes 32-63 <-> z/w regs of lanes 0-31: afterwards (x,y) = row r and
+                // (z,w) = row 8+r of the lane's OWN element, for every lane
+                const auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(q4.x), __float_as_uint(q4.z), false, false);
+                const auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(q4.y), __float_as_uint(q4.w), false, false);
+                v[r] = make_float2(__uint_as_float(sx[0]), __uint_as_float(sy[0]));
+                v[8 + r] = make_float2(__uint_as_float(sx[1]), __uint_as_float(sy[1]));
+            }
+        } else if (interior) {
+            const float2* __restrict__ p = a.in + seg0 + te;
 #pragma unroll
             for (int n2 = 0; n2 < 16; n2++) v[n2] = p[n2 * 256];
         } else {
 #pragma unroll
             for (int n2 = 0; n2 < 16; n2++) {
-                const long long g = seg0 + n2 * 256 + t;
+                const long long g = seg0 + n2 * 256 + te;
                 float2 x = make_float2(0.0f, 0.0f);
                 if (g < 0) { if (g + H >= 0) x = a.hist[g + H]; }
                 else if (g < a.count) x = a.in[g];
@@ -152,7 +177,7 @@ __global__ __launch_bounds__(kFftNT, DEC == 1 ? 4 : 3) void fir_fft_kernel(const
             const float2 q = cmulc<false>(make_float2((float)pb.x, (float)pb.y), pl);
 #pragma unroll
             for (int n2 = 0; n2 < 16; n2++) {
-                const long long g = seg0 + n2 * 256 + t;
+                const long long g = seg0 + n2 * 256 + te;
                 const float gain = fmaf((float)(int)(g & 511), a.gm1, 1.0f);
                 float2 ph = (n2 == 0) ? q : cmulc<false>(q, a.wtab[n2]);
                 ph = make_float2(ph.x * gain, ph.y * gain);
@@ -163,17 +188,17 @@ __global__ __launch_bounds__(kFftNT, DEC == 1 ? 4 : 3) void fir_fft_kernel(const
         // ---- pass A (over n2) + twiddle W4096^(t*k0) -----------------------------------
         fft16<false>(v);
         if constexpr (DEC > 1) {
-            const float2* tap = a.TA + t * 16;
+            const float2* tap = a.TA + te * 16;
             asm volatile("" : "+v"(tap) : "v"(v[0].x));  // opaque + ordered after the butterflies
 #pragma unroll
             for (int k = 1; k < 16; k++) ta[k] = tap[k];
         }
         __syncthreads();  // previous block's last LDS reads are done
 #pragma unroll
-        for (int k = 0; k < 16; k++) lds[k * kFftRow1 + t] = (k == 0) ? v[rev16(0)] : cmulc<false>(v[rev16(k)], ta[k]);
+        for (int k = 0; k < 16; k++) lds[k * kFftRow1 + pte] = (k == 0) ? v[rev16(0)] : cmulc<false>(v[rev16(k)], ta[k]);
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 16; j++) v[j] = lds[hi * kFftRow1 + j * 16 + lo];
+        for (int j = 0; j < 16; j++) v[j] = lds[hi * kFftRow1 + pos1(j * 16 + lo)];
         // ---- pass B (over n1) + twiddle W256^(n0*k1) -----------------------------------
         fft16<false>(v);
         __syncthreads();
@@ -201,25 +226,36 @@ __global__ __launch_bounds__(kFftNT, DEC == 1 ? 4 : 3) void fir_fft_kernel(const
             fft16<true>(v);
             __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 16; j++) lds[hi * kFftRow1 + j * 16 + lo] = v[rev16(j)];
+            for (int j = 0; j < 16; j++) lds[hi * kFftRow1 + pos1(j * 16 + lo)] = v[rev16(j)];
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < 16; k++) {
-                const float2 e = lds[k * kFftRow1 + t];
+                const float2 e = lds[k * kFftRow1 + pte];
                 v[k] = (k == 0) ? e : cmulc<true>(e, ta[k]);
             }
             // ---- pass A' (over k0) and store the L valid outputs --------------------------
             fft16<true>(v);
-            const long long o0 = seg0 + t;  // output index == stream position (element n2*256 + t)
-            if (interior) {
+            const long long o0 = seg0 + te;  // output index == stream position (element n2*256 + te)
+            if (interior && a.vec) {
+                float4* __restrict__ o4 = reinterpret_cast<float4*>(a.out + seg0 + (te & ~1)) + half * 8 * 128;
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const float2 lo_row = v[rev16(r)], hi_row = v[rev16(8 + r)];
+                    const auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo_row.x), __float_as_uint(hi_row.x), false, false);
+                    const auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo_row.y), __float_as_uint(hi_row.y), false, false);
+                    // now (x,y | z,w) = elements (te & ~1, +1) of row half*8 + r
+                    if ((half * 8 + r) * 256 + (te & ~1) >= a.ov)   // ov is even: both elements or neither
+                        o4[r * 128] = make_float4(__uint_as_float(sx[0]), __uint_as_float(sy[0]), __uint_as_float(sx[1]), __uint_as_float(sy[1]));
+                }
+            } else if (interior) {
 #pragma unroll
                 for (int n2 = 0; n2 < 16; n2++)
-                    if (n2 * 256 + t >= a.ov) a.out[o0 + n2 * 256] = v[rev16(n2)];
+                    if (n2 * 256 + te >= a.ov) a.out[o0 + n2 * 256] = v[rev16(n2)];
             } else {
 #pragma unroll
                 for (int n2 = 0; n2 < 16; n2++) {
                     const long long n = o0 + n2 * 256;
-                    if (n2 * 256 + t >= a.ov && n < a.nout) a.out[n] = v[rev16(n2)];
+                    if (n2 * 256 + te >= a.ov && n < a.nout) a.out[n] = v[rev16(n2)];
                 }
             }
         } else {
@@ -311,7 +347,7 @@ __global__ __launch_bounds__(kFftNT, 2) void fir_fft_dec_kernel(const FftArgs a)
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         hf[k] = a.Hf[t * 16 + k];
-        ta[k] = a.TA[t * 16 + k];
+        if (!ROT) ta[k] = a.TA[t * 16 + k];   // the NCO variant re-reads them per segment (register budget)
     }
     tbl[(t >> 4) * 17 + (t & 15)] = a.TB[t];
     const float2* tb = tbl + lo * 17;
@@ -370,6 +406,12 @@ __global__ __launch_bounds__(kFftNT, 2) void fir_fft_dec_kernel(const FftArgs a)
             }
             // ---- pass A + twiddle ----------------------------------------------------------
             fft16<false>(v);
+            if constexpr (ROT) {
+                const float2* tap = a.TA + t * 16;
+                asm volatile("" : "+v"(tap) : "v"(v[0].x));
+#pragma unroll
+                for (int k = 1; k < 16; k++) ta[k] = tap[k];
+            }
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < 16; k++) lds[k * kFftRow1 + t] = (k == 0) ? v[rev16(0)] : cmulc<false>(v[rev16(k)], ta[k]);

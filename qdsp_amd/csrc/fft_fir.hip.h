@@ -42,6 +42,7 @@ struct FftArgs {
     int L;                    // stream positions covered per segment = 4096 - ov
     int nblocks;
     int nwg;                  // persistent workgroups (grid = nwg + 1; the last one hands over history)
+    int vec;                  // 1: in/out 16-byte aligned and segments start on even samples -> float4 path
     // NCO (rot only)
     unsigned long long phase0, dphase;
     double2 rot_step;         // exp(j 2pi nwg*L*dphase): block b -> b + nwg

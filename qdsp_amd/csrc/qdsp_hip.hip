@@ -408,7 +408,8 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
     a.dec = fft_dec(e);
     a.rot = e->rotate ? 1 : 0;
     if (a.dec == 1) {
-        a.ov = e->ntaps - 1;        // FIR: out index == stream position
+        a.ov = (e->ntaps - 1 + 1) & ~1;   // FIR: out index == stream position; even so segments stay 16-byte aligned
+        a.vec = ((((uintptr_t)d_in) | ((uintptr_t)d_out)) & 15) == 0 && !env_int("QDSP_HIP_FFT_NOVEC", 0);
         a.seg_shift = a.ov;
         a.L = qk::kFftN - a.ov;
         a.nblocks = (int)((count + a.L - 1) / a.L);
