@@ -347,7 +347,7 @@ __global__ __launch_bounds__(kFftNT, 2) void fir_fft_dec_kernel(const FftArgs a)
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         hf[k] = a.Hf[t * 16 + k];
-        if (!ROT) ta[k] = a.TA[t * 16 + k];   // the NCO variant re-reads them per segment (register budget)
+        ta[k] = a.TA[t * 16 + k];
     }
     tbl[(t >> 4) * 17 + (t & 15)] = a.TB[t];
     const float2* tb = tbl + lo * 17;
@@ -406,12 +406,6 @@ __global__ __launch_bounds__(kFftNT, 2) void fir_fft_dec_kernel(const FftArgs a)
             }
             // ---- pass A + twiddle ----------------------------------------------------------
             fft16<false>(v);
-            if constexpr (ROT) {
-                const float2* tap = a.TA + t * 16;
-                asm volatile("" : "+v"(tap) : "v"(v[0].x));
-#pragma unroll
-                for (int k = 1; k < 16; k++) ta[k] = tap[k];
-            }
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < 16; k++) lds[k * kFftRow1 + t] = (k == 0) ? v[rev16(0)] : cmulc<false>(v[rev16(k)], ta[k]);
