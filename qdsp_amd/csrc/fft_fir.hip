@@ -126,7 +126,7 @@ __device__ __forceinline__ double2 dcmul(double2 a, double2 b) {
 // i.e. the last radix-16 digit n0 is a multiple of DEC: the inverse transform keeps only
 // those 16/DEC values of n0, and passes B'/A' run on 256/DEC lanes.
 template <int DEC, bool ROT>
-__global__ __launch_bounds__(kFftNT, DEC == 1 ? 4 : 3) void fir_fft_kernel(const FftArgs a) {
+__global__ __launch_bounds__(kFftNT, 3) void fir_fft_kernel(const FftArgs a) {
     __shared__ __attribute__((aligned(16))) cx lds[kFftLdsElems + 16 * 17];
     cx* tbl = lds + kFftLdsElems;  // pass-B twiddles W256^(lo*k), rows padded to 17
     const cx* __restrict__ IN_ = reinterpret_cast<const cx*>(a.in);
@@ -254,11 +254,17 @@ __global__ __launch_bounds__(kFftNT, DEC == 1 ? 4 : 3) void fir_fft_kernel(const
 #pragma unroll
         for (int j = 0; j < 16; j++) v[j] = lds[hi * kFftRow1 + pos1(j * 16 + lo)];
         // ---- pass B (over n1) + twiddle W256^(n0*k1) -----------------------------------
+        // (the LDS-resident twiddles are fetched ahead of the butterflies: with packed-math
+        // consumers the scheduler otherwise emits read -> wait -> use fifteen times)
+        cx tw[16];
+#pragma unroll
+        for (int k = 1; k < 16; k++) tw[k] = tb[k];
+        __builtin_amdgcn_sched_barrier(0);
         fft16<false>(v);
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 16; k++)
-            lds[(hi * 16 + k) * kFftRow2 + lo] = (k == 0) ? v[rev16(0)] : cmulc<false>(v[rev16(k)], tb[k]);
+            lds[(hi * 16 + k) * kFftRow2 + lo] = (k == 0) ? v[rev16(0)] : cmulc<false>(v[rev16(k)], tw[k]);
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 16; j++) v[j] = lds[t * kFftRow2 + j];
@@ -267,12 +273,15 @@ __global__ __launch_bounds__(kFftNT, DEC == 1 ? 4 : 3) void fir_fft_kernel(const
         cx y[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) y[k] = cmulc<false>(v[rev16(k)], hf[k]);
+#pragma unroll
+        for (int k = 1; k < 16; k++) tw[k] = tb[k];
+        __builtin_amdgcn_sched_barrier(0);
         fft16<true>(y);
         __syncthreads();
         if constexpr (DEC == 1) {
 #pragma unroll
             for (int j = 0; j < 16; j++)
-                lds[t * kFftRow2 + j] = (j == 0) ? y[rev16(0)] : cmulc<true>(y[rev16(j)], tb[j]);
+                lds[t * kFftRow2 + j] = (j == 0) ? y[rev16(0)] : cmulc<true>(y[rev16(j)], tw[j]);
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < 16; j++) v[j] = lds[(hi * 16 + j) * kFftRow2 + lo];
@@ -325,7 +334,7 @@ __global__ __launch_bounds__(kFftNT, DEC == 1 ? 4 : 3) void fir_fft_kernel(const
 #pragma unroll
             for (int s = 0; s < NS; s++) {
                 const int n0 = s * DEC;
-                lds[(hi * NS + s) * kFftRow2 + lo] = (n0 == 0) ? y[rev16(0)] : cmulc<true>(y[rev16(n0)], tb[n0]);
+                lds[(hi * NS + s) * kFftRow2 + lo] = (n0 == 0) ? y[rev16(0)] : cmulc<true>(y[rev16(n0)], tw[n0]);
             }
             __syncthreads();
             if (t < NACT) {  // lane u = k0*NS + s : pass B' over k1
@@ -483,11 +492,15 @@ __global__ __launch_bounds__(kFftNT, 2) void fir_fft_dec_kernel(const FftArgs a)
 #pragma unroll
             for (int j = 0; j < 16; j++) v[j] = lds[hi * kFftRow1 + j * 16 + lo];
             // ---- pass B + twiddle ----------------------------------------------------------
+            cx tw[16];
+#pragma unroll
+            for (int k = 1; k < 16; k++) tw[k] = tb[k];
+            __builtin_amdgcn_sched_barrier(0);
             fft16<false>(v);
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < 16; k++)
-                lds[(hi * 16 + k) * kFftRow2 + lo] = (k == 0) ? v[rev16(0)] : cmulc<false>(v[rev16(k)], tb[k]);
+                lds[(hi * 16 + k) * kFftRow2 + lo] = (k == 0) ? v[rev16(0)] : cmulc<false>(v[rev16(k)], tw[k]);
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < 16; j++) v[j] = lds[t * kFftRow2 + j];
