@@ -6,6 +6,9 @@
 //     0.45 ms.  The opaque asm consumers make hipcc emit read -> s_waitcnt 0 -> use chains
 //     (SQ_WAIT_ANY 44 % -> 70 % of wave cycles), which costs more than the halved issue count
 //     gains;
+//   * the hybrid -- vector-typed add/sub (hipcc emits v_pk_add_f32 itself, no asm) with scalar
+//     multiply-by-j and product forms: 1100 VALU ops per segment but 12 spilled VGPRs and 136
+//     extra v_mov: 0.54 ms;
 //   * non-temporal loads/stores for the sample stream: +-1 %;
 //   * pruning the inverse inside one segment for decimators (256/DEC active lanes): no faster
 //     than the full inverse -> the grouped kernel below.
@@ -19,51 +22,37 @@
 
 namespace qk {
 
-// A complex value is an aligned VGPR pair (ext_vector_type(2)).  Plain add/sub are written as
-// vector ops so hipcc emits ONE v_pk_add_f32 for both components by itself (no inline asm:
-// see the rejected-experiments note above); multiply-by-j forms and complex products stay
-// scalar, where packing would need op_sel/neg modifier combinations the backend does not fold.
-typedef float cx __attribute__((ext_vector_type(2)));
-typedef float f4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ cx cxmake(float re, float im) { cx r; r.x = re; r.y = im; return r; }
-__device__ __forceinline__ cx cadd(cx a, cx b) { return a + b; }
-__device__ __forceinline__ cx csub(cx a, cx b) { return a - b; }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 // a * b, and a * conj(b)
-template <bool CONJ> __device__ __forceinline__ cx cmulc(cx a, cx b) {
-    if (CONJ) return cxmake(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -a.x * b.y));
-    return cxmake(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
-}
-// a + (-j)*b (forward) / a + (+j)*b (inverse), and the opposite sign
-template <bool INV> __device__ __forceinline__ cx caddj(cx a, cx b) {
-    return INV ? cxmake(a.x - b.y, a.y + b.x) : cxmake(a.x + b.y, a.y - b.x);
-}
-template <bool INV> __device__ __forceinline__ cx csubj(cx a, cx b) {
-    return INV ? cxmake(a.x + b.y, a.y - b.x) : cxmake(a.x - b.y, a.y + b.x);
+template <bool CONJ> __device__ __forceinline__ float2 cmulc(float2 a, float2 b) {
+    if (CONJ) return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -a.x * b.y));
+    return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
 }
 // multiply by -j (forward) / +j (inverse)
-template <bool INV> __device__ __forceinline__ cx mulj(cx a) {
-    return INV ? cxmake(-a.y, a.x) : cxmake(a.y, -a.x);
+template <bool INV> __device__ __forceinline__ float2 mulj(float2 a) {
+    return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
 }
 
 template <bool INV>
-__device__ __forceinline__ void fft4(cx& a0, cx& a1, cx& a2, cx& a3) {
-    const cx t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), d = csub(a1, a3);
+__device__ __forceinline__ void fft4(float2& a0, float2& a1, float2& a2, float2& a3) {
+    const float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mulj<INV>(csub(a1, a3));
     a0 = cadd(t0, t2);
     a2 = csub(t0, t2);
-    a1 = caddj<INV>(t1, d);   // t1 + (-/+ j) d
-    a3 = csubj<INV>(t1, d);
+    a1 = cadd(t1, t3);
+    a3 = csub(t1, t3);
 }
 
 // In-register 16-point DFT, radix 4x4.  Input v[n]; output X[k] is left at v[rev16(k)].
 __host__ __device__ constexpr int rev16(int k) { return 4 * (k & 3) + (k >> 2); }
 
-template <bool INV> __device__ __forceinline__ void fft16(cx (&v)[16]) {
+template <bool INV> __device__ __forceinline__ void fft16(float2 (&v)[16]) {
     constexpr float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, r = 0.70710678118654752f;
 #pragma unroll
     for (int n0 = 0; n0 < 4; n0++) fft4<INV>(v[n0], v[4 + n0], v[8 + n0], v[12 + n0]);
     // v[4*k0 + n0] *= W16^(n0*k0); forward W = exp(-j 2pi/16), inverse conj
-    const cx w1 = cxmake(c1, -s1), w2 = cxmake(r, -r), w3 = cxmake(s1, -c1);
-    const cx w6 = cxmake(-r, -r), w9 = cxmake(-c1, s1);
+    const float2 w1 = make_float2(c1, -s1), w2 = make_float2(r, -r), w3 = make_float2(s1, -c1);
+    const float2 w6 = make_float2(-r, -r), w9 = make_float2(-c1, s1);
     v[4 * 1 + 1] = cmulc<INV>(v[4 * 1 + 1], w1);
     v[4 * 1 + 2] = cmulc<INV>(v[4 * 1 + 2], w2);
     v[4 * 1 + 3] = cmulc<INV>(v[4 * 1 + 3], w3);
@@ -106,15 +95,8 @@ __device__ __forceinline__ double2 dcmul(double2 a, double2 b) {
 // those 16/DEC values of n0, and passes B'/A' run on 256/DEC lanes.
 template <int DEC, bool ROT>
 __global__ __launch_bounds__(kFftNT, DEC == 1 ? 4 : 3) void fir_fft_kernel(const FftArgs a) {
-    __shared__ __attribute__((aligned(16))) cx lds[kFftLdsElems + 16 * 17];
-    cx* tbl = lds + kFftLdsElems;  // pass-B twiddles W256^(lo*k), rows padded to 17
-    const cx* __restrict__ IN_ = reinterpret_cast<const cx*>(a.in);
-    cx* __restrict__ OUT_ = reinterpret_cast<cx*>(a.out);
-    const cx* __restrict__ HI_ = reinterpret_cast<const cx*>(a.hist);
-    cx* __restrict__ HN_ = reinterpret_cast<cx*>(a.hist_next);
-    const cx* __restrict__ HF_ = reinterpret_cast<const cx*>(a.Hf);
-    const cx* __restrict__ TA_ = reinterpret_cast<const cx*>(a.TA);
-    const cx* __restrict__ TB_ = reinterpret_cast<const cx*>(a.TB);
+    __shared__ __attribute__((aligned(16))) float2 lds[kFftLdsElems + 16 * 17];
+    float2* tbl = lds + kFftLdsElems;  // pass-B twiddles W256^(lo*k), rows padded to 17
     const int t = threadIdx.x;
     const int hi = t >> 4, lo = t & 15;
     const int H = a.H;
@@ -131,18 +113,18 @@ __global__ __launch_bounds__(kFftNT, DEC == 1 ? 4 : 3) void fir_fft_kernel(const
         // history hand-over (filter.h:71 / resampling.h:129): last H samples of hist ++ in
         for (int i = t; i < H; i += kFftNT) {
             const long long g = a.count - H + i;
-            cx v;
+            float2 v;
             if (g < 0) {
-                v = HI_[g + H];
+                v = a.hist[g + H];
             } else {
-                v = IN_[g];
+                v = a.in[g];
                 if (ROT) {
                     const double2 p = fx_phasor(a.phase0 + (unsigned long long)g * a.dphase);
                     const float gain = fmaf((float)(int)(g & 511), a.gm1, 1.0f);
-                    v = cmulc<false>(v, cxmake((float)p.x * gain, (float)p.y * gain));
+                    v = cmulc<false>(v, make_float2((float)p.x * gain, (float)p.y * gain));
                 }
             }
-            HN_[i] = v;
+            a.hist_next[i] = v;
         }
         return;
     }
@@ -151,67 +133,67 @@ __global__ __launch_bounds__(kFftNT, DEC == 1 ? 4 : 3) void fir_fft_kernel(const
     // DEC == 1 keeps both tables in VGPRs (124 in all).  The pruned-inverse variants need a
     // few more live values, so they re-read the pass-A twiddles from the L2-resident table
     // every block (opaque pointer below) rather than spill.
-    cx ta[16], hf[16];
+    float2 ta[16], hf[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        hf[k] = HF_[t * 16 + k];
-        if (DEC == 1) ta[k] = TA_[te * 16 + k];
+        hf[k] = a.Hf[t * 16 + k];
+        if (DEC == 1) ta[k] = a.TA[te * 16 + k];
     }
     // pass-A' twiddles of the pruned inverse: lane w = n1*NS + s <-> element n1*16 + s*DEC.
     // Re-read from the (L2-resident) table every block by the 256/DEC active lanes instead of
     // living in 32 more VGPRs: keeps the kernel at 128 VGPRs = 4 waves/SIMD without spills.
     const int e0 = ((t / NS) * 16 + (t % NS) * DEC) & 255;
-    tbl[(t >> 4) * 17 + (t & 15)] = TB_[t];
-    const cx* tb = tbl + lo * 17;
+    tbl[(t >> 4) * 17 + (t & 15)] = a.TB[t];
+    const float2* tb = tbl + lo * 17;
 
-    cx pl = cxmake(1.0f, 0.0f);   // exp(j 2pi t dphase)
+    float2 pl = make_float2(1.0f, 0.0f);   // exp(j 2pi t dphase)
     double2 pb = make_double2(1.0, 0.0);   // exp(j 2pi (phase0 + seg0 dphase)) of the current block
     if (ROT) {
         const double2 p = fx_phasor((unsigned long long)te * a.dphase);
-        pl = cxmake((float)p.x, (float)p.y);
+        pl = make_float2((float)p.x, (float)p.y);
         pb = fx_phasor(a.phase0 + (unsigned long long)((long long)blockIdx.x * a.L - a.seg_shift) * a.dphase);
     }
 
     for (int b = blockIdx.x; b < a.nblocks; b += a.nwg) {
         const long long seg0 = (long long)b * a.L - a.seg_shift;  // stream position of element 0
         const bool interior = seg0 >= 0 && seg0 + kFftN <= a.count;
-        cx v[16];
+        float2 v[16];
         // ---- load: the lane ends up with elements n2*256 + te, n2 = 0..15 ------------------
         if (interior && a.vec) {
             // rows half*8 + r, elements (te & ~1, +1); row pitch 256 samples = 128 float4
-            const f4_t* __restrict__ p4 = reinterpret_cast<const f4_t*>(IN_ + seg0 + (te & ~1)) + half * 8 * 128;
+            const float4* __restrict__ p4 = reinterpret_cast<const float4*>(a.in + seg0 + (te & ~1)) + half * 8 * 128;
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                const f4_t q4 = p4[r * 128];
+                const float4 q4 = p4[r * 128];
                 // x/y regs: lanes 32-63 <-> z/w regs of lanes 0-31: afterwards (x,y) = row r and
                 // (z,w) = row 8+r of the lane's OWN element, for every lane
                 const auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(q4.x), __float_as_uint(q4.z), false, false);
                 const auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(q4.y), __float_as_uint(q4.w), false, false);
-                v[r] = cxmake(__uint_as_float(sx[0]), __uint_as_float(sy[0]));
-                v[8 + r] = cxmake(__uint_as_float(sx[1]), __uint_as_float(sy[1]));
+                v[r] = make_float2(__uint_as_float(sx[0]), __uint_as_float(sy[0]));
+                v[8 + r] = make_float2(__uint_as_float(sx[1]), __uint_as_float(sy[1]));
             }
         } else if (interior) {
-            const cx* __restrict__ p = IN_ + seg0 + te;
+            const float2* __restrict__ p = a.in + seg0 + te;
 #pragma unroll
             for (int n2 = 0; n2 < 16; n2++) v[n2] = p[n2 * 256];
         } else {
 #pragma unroll
             for (int n2 = 0; n2 < 16; n2++) {
                 const long long g = seg0 + n2 * 256 + te;
-                cx x = cxmake(0.0f, 0.0f);
-                if (g < 0) { if (g + H >= 0) x = HI_[g + H]; }
-                else if (g < a.count) x = IN_[g];
+                float2 x = make_float2(0.0f, 0.0f);
+                if (g < 0) { if (g + H >= 0) x = a.hist[g + H]; }
+                else if (g < a.count) x = a.in[g];
                 v[n2] = x;
             }
         }
         if (ROT) {
-            const cx q = cmulc<false>(cxmake((float)pb.x, (float)pb.y), pl);
+            const float2 q = cmulc<false>(make_float2((float)pb.x, (float)pb.y), pl);
 #pragma unroll
             for (int n2 = 0; n2 < 16; n2++) {
                 const long long g = seg0 + n2 * 256 + te;
                 const float gain = fmaf((float)(int)(g & 511), a.gm1, 1.0f);
-                cx ph = (n2 == 0) ? q : cmulc<false>(q, cxmake(a.wtab[n2].x, a.wtab[n2].y));
-                ph = cxmake(ph.x * gain, ph.y * gain);
+                float2 ph = (n2 == 0) ? q : cmulc<false>(q, a.wtab[n2]);
+                ph = make_float2(ph.x * gain, ph.y * gain);
                 if (interior || g >= 0) v[n2] = cmulc<false>(v[n2], ph);   // history is already rotated
             }
             pb = dcmul(pb, a.rot_step);
@@ -219,7 +201,7 @@ __global__ __launch_bounds__(kFftNT, DEC == 1 ? 4 : 3) void fir_fft_kernel(const
         // ---- pass A (over n2) + twiddle W4096^(t*k0) -----------------------------------
         fft16<false>(v);
         if constexpr (DEC > 1) {
-            const cx* tap = TA_ + te * 16;
+            const float2* tap = a.TA + te * 16;
             asm volatile("" : "+v"(tap) : "v"(v[0].x));  // opaque + ordered after the butterflies
 #pragma unroll
             for (int k = 1; k < 16; k++) ta[k] = tap[k];
@@ -241,7 +223,7 @@ __global__ __launch_bounds__(kFftNT, DEC == 1 ? 4 : 3) void fir_fft_kernel(const
         for (int j = 0; j < 16; j++) v[j] = lds[t * kFftRow2 + j];
         // ---- pass C (over n0), spectrum * Hf, pass C' (over k2) ----------------------------
         fft16<false>(v);
-        cx y[16];
+        float2 y[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) y[k] = cmulc<false>(v[rev16(k)], hf[k]);
         fft16<true>(y);
@@ -261,39 +243,32 @@ __global__ __launch_bounds__(kFftNT, DEC == 1 ? 4 : 3) void fir_fft_kernel(const
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < 16; k++) {
-                const cx e = lds[k * kFftRow1 + pte];
+                const float2 e = lds[k * kFftRow1 + pte];
                 v[k] = (k == 0) ? e : cmulc<true>(e, ta[k]);
             }
             // ---- pass A' (over k0) and store the L valid outputs --------------------------
             fft16<true>(v);
             const long long o0 = seg0 + te;  // output index == stream position (element n2*256 + te)
             if (interior && a.vec) {
-                f4_t* __restrict__ o4 = reinterpret_cast<f4_t*>(OUT_ + seg0 + (te & ~1)) + half * 8 * 128;
+                float4* __restrict__ o4 = reinterpret_cast<float4*>(a.out + seg0 + (te & ~1)) + half * 8 * 128;
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
-                    const cx lo_row = v[rev16(r)], hi_row = v[rev16(8 + r)];
+                    const float2 lo_row = v[rev16(r)], hi_row = v[rev16(8 + r)];
                     const auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo_row.x), __float_as_uint(hi_row.x), false, false);
                     const auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo_row.y), __float_as_uint(hi_row.y), false, false);
                     // now (x,y | z,w) = elements (te & ~1, +1) of row half*8 + r
                     if ((half * 8 + r) * 256 + (te & ~1) >= a.ov)   // ov is even: both elements or neither
-                        {
-                        f4_t o;
-                        o.x = __uint_as_float(sx[0]);
-                        o.y = __uint_as_float(sy[0]);
-                        o.z = __uint_as_float(sx[1]);
-                        o.w = __uint_as_float(sy[1]);
-                        o4[r * 128] = o;
-                    }
+                        o4[r * 128] = make_float4(__uint_as_float(sx[0]), __uint_as_float(sy[0]), __uint_as_float(sx[1]), __uint_as_float(sy[1]));
                 }
             } else if (interior) {
 #pragma unroll
                 for (int n2 = 0; n2 < 16; n2++)
-                    if (n2 * 256 + te >= a.ov) OUT_[o0 + n2 * 256] = v[rev16(n2)];
+                    if (n2 * 256 + te >= a.ov) a.out[o0 + n2 * 256] = v[rev16(n2)];
             } else {
 #pragma unroll
                 for (int n2 = 0; n2 < 16; n2++) {
                     const long long n = o0 + n2 * 256;
-                    if (n2 * 256 + te >= a.ov && n < a.nout) OUT_[n] = v[rev16(n2)];
+                    if (n2 * 256 + te >= a.ov && n < a.nout) a.out[n] = v[rev16(n2)];
                 }
             }
         } else {
@@ -318,11 +293,11 @@ __global__ __launch_bounds__(kFftNT, DEC == 1 ? 4 : 3) void fir_fft_kernel(const
             }
             __syncthreads();
             if (t < NACT) {  // lane w = n1*NS + s : twiddle, pass A' over k0, store
-                const cx* ta2 = TA_ + e0 * 16;
+                const float2* ta2 = a.TA + e0 * 16;
                 asm volatile("" : "+v"(ta2) : "v"(v[0].x));  // opaque: not hoisted out of the block loop, not issued early
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
-                    const cx e = lds[t * kFftRow2 + k];
+                    const float2 e = lds[t * kFftRow2 + k];
                     v[k] = (k == 0) ? e : cmulc<true>(e, ta2[k]);
                 }
                 fft16<true>(v);
@@ -331,7 +306,7 @@ __global__ __launch_bounds__(kFftNT, DEC == 1 ? 4 : 3) void fir_fft_kernel(const
                 for (int n2 = 0; n2 < 16; n2++) {
                     const int i = n2 * 256 + e0;
                     const long long n = nb + i / DEC;
-                    if (i >= a.ov && n < a.nout) OUT_[n] = v[rev16(n2)];
+                    if (i >= a.ov && n < a.nout) a.out[n] = v[rev16(n2)];
                 }
             }
         }
@@ -348,16 +323,9 @@ __global__ __launch_bounds__(kFftNT, DEC == 1 ? 4 : 3) void fir_fft_kernel(const
 // LDS: exchange buffer + staging = 2 x 34 KB -> 2 workgroups per CU.
 template <int DEC, bool ROT>
 __global__ __launch_bounds__(kFftNT, 2) void fir_fft_dec_kernel(const FftArgs a) {
-    __shared__ __attribute__((aligned(16))) cx lds[2 * kFftLdsElems + 16 * 17];
-    cx* stage = lds + kFftLdsElems;      // [DEC*NACT rows][17]
-    cx* tbl = lds + 2 * kFftLdsElems;    // pass-B twiddles
-    const cx* __restrict__ IN_ = reinterpret_cast<const cx*>(a.in);
-    cx* __restrict__ OUT_ = reinterpret_cast<cx*>(a.out);
-    const cx* __restrict__ HI_ = reinterpret_cast<const cx*>(a.hist);
-    cx* __restrict__ HN_ = reinterpret_cast<cx*>(a.hist_next);
-    const cx* __restrict__ HF_ = reinterpret_cast<const cx*>(a.Hf);
-    const cx* __restrict__ TA_ = reinterpret_cast<const cx*>(a.TA);
-    const cx* __restrict__ TB_ = reinterpret_cast<const cx*>(a.TB);
+    __shared__ __attribute__((aligned(16))) float2 lds[2 * kFftLdsElems + 16 * 17];
+    float2* stage = lds + kFftLdsElems;      // [DEC*NACT rows][17]
+    float2* tbl = lds + 2 * kFftLdsElems;    // pass-B twiddles
     const int t = threadIdx.x;
     const int hi = t >> 4, lo = t & 15;
     const int H = a.H;
@@ -367,56 +335,56 @@ __global__ __launch_bounds__(kFftNT, 2) void fir_fft_dec_kernel(const FftArgs a)
     if ((int)blockIdx.x == a.nwg) {
         for (int i = t; i < H; i += kFftNT) {
             const long long g = a.count - H + i;
-            cx v;
+            float2 v;
             if (g < 0) {
-                v = HI_[g + H];
+                v = a.hist[g + H];
             } else {
-                v = IN_[g];
+                v = a.in[g];
                 if (ROT) {
                     const double2 p = fx_phasor(a.phase0 + (unsigned long long)g * a.dphase);
                     const float gain = fmaf((float)(int)(g & 511), a.gm1, 1.0f);
-                    v = cmulc<false>(v, cxmake((float)p.x * gain, (float)p.y * gain));
+                    v = cmulc<false>(v, make_float2((float)p.x * gain, (float)p.y * gain));
                 }
             }
-            HN_[i] = v;
+            a.hist_next[i] = v;
         }
         return;
     }
 
     // per-lane constants kept in registers: forward twiddles and the lane's spectrum slice; the
     // inverse-pass twiddles (used once per group) are re-read from the L2-resident table
-    cx ta[16], hf[16];
+    float2 ta[16], hf[16];
     // inverse-pass lane w = bb*NACT + n1*NS + s  <->  element e0 = n1*16 + s*DEC of segment bb
     const int wbb = t / NACT, wr = t % NACT;
     const int e0 = (wr / NS) * 16 + (wr % NS) * DEC;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        hf[k] = HF_[t * 16 + k];
-        ta[k] = TA_[t * 16 + k];
+        hf[k] = a.Hf[t * 16 + k];
+        ta[k] = a.TA[t * 16 + k];
     }
-    tbl[(t >> 4) * 17 + (t & 15)] = TB_[t];
-    const cx* tb = tbl + lo * 17;
+    tbl[(t >> 4) * 17 + (t & 15)] = a.TB[t];
+    const float2* tb = tbl + lo * 17;
 
-    cx pl = cxmake(1.0f, 0.0f);
+    float2 pl = make_float2(1.0f, 0.0f);
     if (ROT) {
         const double2 p = fx_phasor((unsigned long long)t * a.dphase);
-        pl = cxmake((float)p.x, (float)p.y);
+        pl = make_float2((float)p.x, (float)p.y);
     }
 
-    auto load_segment = [&](int b, cx (&v)[16]) {
+    auto load_segment = [&](int b, float2 (&v)[16]) {
         const long long seg0 = (long long)b * a.L - a.seg_shift;
         if (b < a.nblocks && seg0 >= 0 && seg0 + kFftN <= a.count) {
-            const cx* __restrict__ p = IN_ + seg0 + t;
+            const float2* __restrict__ p = a.in + seg0 + t;
 #pragma unroll
             for (int n2 = 0; n2 < 16; n2++) v[n2] = p[n2 * 256];
         } else {
 #pragma unroll
             for (int n2 = 0; n2 < 16; n2++) {
                 const long long g = seg0 + n2 * 256 + t;
-                cx x = cxmake(0.0f, 0.0f);
+                float2 x = make_float2(0.0f, 0.0f);
                 if (b < a.nblocks) {
-                    if (g < 0) { if (g + H >= 0) x = HI_[g + H]; }
-                    else if (g < a.count) x = IN_[g];
+                    if (g < 0) { if (g + H >= 0) x = a.hist[g + H]; }
+                    else if (g < a.count) x = a.in[g];
                 }
                 v[n2] = x;
             }
@@ -431,21 +399,21 @@ __global__ __launch_bounds__(kFftNT, 2) void fir_fft_dec_kernel(const FftArgs a)
         // sincos per group and lane); later segments follow by an FP64 rotation of L samples.
         double2 pb = make_double2(1.0, 0.0);
         if (ROT) pb = fx_phasor(a.phase0 + (unsigned long long)((long long)b0 * a.L - a.seg_shift) * a.dphase);
-        cx v[16], vn[16];
+        float2 v[16], vn[16];
         load_segment(b0, v);
 #pragma unroll 1
         for (int bb = 0; bb < DEC; bb++) {
             const int b = b0 + bb;
             const long long seg0 = (long long)b * a.L - a.seg_shift;
             if (ROT) {
-                const cx q = cmulc<false>(cxmake((float)pb.x, (float)pb.y), pl);
+                const float2 q = cmulc<false>(make_float2((float)pb.x, (float)pb.y), pl);
                 pb = dcmul(pb, a.rot_step);
 #pragma unroll
                 for (int n2 = 0; n2 < 16; n2++) {
                     const long long g = seg0 + n2 * 256 + t;
                     const float gain = fmaf((float)(int)(g & 511), a.gm1, 1.0f);
-                    cx ph = (n2 == 0) ? q : cmulc<false>(q, cxmake(a.wtab[n2].x, a.wtab[n2].y));
-                    ph = cxmake(ph.x * gain, ph.y * gain);
+                    float2 ph = (n2 == 0) ? q : cmulc<false>(q, a.wtab[n2]);
+                    ph = make_float2(ph.x * gain, ph.y * gain);
                     if (g >= 0) v[n2] = cmulc<false>(v[n2], ph);   // history is already rotated
                 }
             }
@@ -469,7 +437,7 @@ __global__ __launch_bounds__(kFftNT, 2) void fir_fft_dec_kernel(const FftArgs a)
             for (int j = 0; j < 16; j++) v[j] = lds[t * kFftRow2 + j];
             // ---- pass C, spectrum product, pass C', keep n0 = s*DEC ---------------------------
             fft16<false>(v);
-            cx y[16];
+            float2 y[16];
 #pragma unroll
             for (int k = 0; k < 16; k++) y[k] = cmulc<false>(v[rev16(k)], hf[k]);
             fft16<true>(y);
@@ -498,11 +466,11 @@ __global__ __launch_bounds__(kFftNT, 2) void fir_fft_dec_kernel(const FftArgs a)
         __syncthreads();
         // ---- pass A' (lane w = bb*NACT + n1*NS + s, over k0) and store -----------------------------
         {
-            const cx* ta2 = TA_ + e0 * 16;
+            const float2* ta2 = a.TA + e0 * 16;
             asm volatile("" : "+v"(ta2) : "v"(v[0].x));  // opaque: re-read per group, after pass B'
 #pragma unroll
             for (int k = 0; k < 16; k++) {
-                const cx e = lds[t * kFftRow2 + k];
+                const float2 e = lds[t * kFftRow2 + k];
                 v[k] = (k == 0) ? e : cmulc<true>(e, ta2[k]);
             }
         }
@@ -513,7 +481,7 @@ __global__ __launch_bounds__(kFftNT, 2) void fir_fft_dec_kernel(const FftArgs a)
         for (int n2 = 0; n2 < 16; n2++) {
             const int i = n2 * 256 + e0;
             const long long n = nb + i / DEC;
-            if (b < a.nblocks && i >= a.ov && n < a.nout) OUT_[n] = v[rev16(n2)];
+            if (b < a.nblocks && i >= a.ov && n < a.nout) a.out[n] = v[rev16(n2)];
         }
         // next group's pass-A write to `lds` is behind that group's first barrier; its staging
         // writes are behind several more: no extra barrier needed here.
