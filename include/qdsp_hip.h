@@ -25,6 +25,10 @@
  *                        stream; state (history, NCO phase) is advanced in stream order.
  *                        in/out must not alias.  `stream` NULL = HIP's default stream.
  *                        All calls on one handle must be stream-ordered by the caller.
+ *   - `*_process_ex`   : like `*_process`, but each side says where its buffer lives
+ *                        (`in_on_device` / `out_on_device`): a block whose neighbour is
+ *                        another HIP-backed block reads / writes the stream's device-resident
+ *                        buffer and skips that PCIe copy.  Synchronous.
  *   - one `process*` call == one `run()` of the reference block: history carries over
  *     exactly as the reference's memmove does, and the resampler's phase counter restarts
  *     at 0 (src/dsp/resampling.h:114,121).
@@ -66,6 +70,7 @@ int qdsp_hip_dev_alloc(int device, void** p, size_t bytes);
 int qdsp_hip_dev_free(int device, void* p);
 int qdsp_hip_memcpy_h2d(int device, void* d_dst, const void* h_src, size_t bytes);
 int qdsp_hip_memcpy_d2h(int device, void* h_dst, const void* d_src, size_t bytes);
+int qdsp_hip_memcpy_d2d(int device, void* d_dst, const void* d_src, size_t bytes);
 int qdsp_hip_device_sync(int device);
 
 /* ---- FIR<complex_t> : src/dsp/filter.h:51-74 ------------------------------------------ */
@@ -79,6 +84,8 @@ int qdsp_hip_fir_cf32_create(void** h, int device, const float* taps, int ntaps,
 int qdsp_hip_fir_cf32_process(void* h, const float* in_iq, int count, float* out_iq);
 int qdsp_hip_fir_cf32_process_dev(void* h, const void* d_in, int64_t count, void* d_out,
                                   void* hip_stream);
+int qdsp_hip_fir_cf32_process_ex(void* h, const void* in, int in_on_device, int count, void* out,
+                                 int out_on_device);
 /* FIR<T>::updateWindow (filter.h:43-49): new taps; history is kept (resized, newest
  * samples preserved) as the reference keeps its buffer. */
 int qdsp_hip_fir_cf32_set_taps(void* h, const float* taps, int ntaps);
@@ -109,6 +116,8 @@ int qdsp_hip_fir_f32_create(void** h, int device, const float* taps, int ntaps, 
 int qdsp_hip_fir_f32_process(void* h, const float* in, int count, float* out);
 int qdsp_hip_fir_f32_process_dev(void* h, const void* d_in, int64_t count, void* d_out,
                                  void* hip_stream);
+int qdsp_hip_fir_f32_process_ex(void* h, const void* in, int in_on_device, int count, void* out,
+                                int out_on_device);
 int qdsp_hip_fir_f32_set_taps(void* h, const float* taps, int ntaps);
 int qdsp_hip_fir_f32_set_mode(void* h, int mode); /* accepted; FIR<float> always runs direct form */
 int qdsp_hip_fir_f32_reset(void* h);
@@ -133,6 +142,8 @@ int qdsp_hip_decim_cf32_create(void** h, int device, const float* taps, int ntap
 int qdsp_hip_decim_cf32_process(void* h, const float* in_iq, int count, float* out_iq);
 int64_t qdsp_hip_decim_cf32_process_dev(void* h, const void* d_in, int64_t count, void* d_out,
                                         void* hip_stream);
+int qdsp_hip_decim_cf32_process_ex(void* h, const void* in, int in_on_device, int count, void* out,
+                                   int out_on_device);
 /* updateWindow / setInSampleRate / setOutSampleRate (resampling.h:53-93) all funnel here. */
 int qdsp_hip_decim_cf32_configure(void* h, const float* taps, int ntaps, int interp, int decim);
 int64_t qdsp_hip_decim_cf32_out_size(void* h, int64_t count); /* calcOutSize, :95-97 */
@@ -154,6 +165,8 @@ int qdsp_hip_decim_f32_create(void** h, int device, const float* taps, int ntaps
 int qdsp_hip_decim_f32_process(void* h, const float* in, int count, float* out);
 int64_t qdsp_hip_decim_f32_process_dev(void* h, const void* d_in, int64_t count, void* d_out,
                                        void* hip_stream);
+int qdsp_hip_decim_f32_process_ex(void* h, const void* in, int in_on_device, int count, void* out,
+                                  int out_on_device);
 int qdsp_hip_decim_f32_configure(void* h, const float* taps, int ntaps, int interp, int decim);
 int64_t qdsp_hip_decim_f32_out_size(void* h, int64_t count);
 int qdsp_hip_decim_f32_set_mode(void* h, int mode); /* accepted; real data always runs direct form */
@@ -178,6 +191,8 @@ int qdsp_hip_xlate_cf32_create(void** h, int device, float phase_inc_re, float p
 int qdsp_hip_xlate_cf32_process(void* h, const float* in_iq, int count, float* out_iq);
 int qdsp_hip_xlate_cf32_process_dev(void* h, const void* d_in, int64_t count, void* d_out,
                                     void* hip_stream);
+int qdsp_hip_xlate_cf32_process_ex(void* h, const void* in, int in_on_device, int count, void* out,
+                                   int out_on_device);
 int qdsp_hip_xlate_cf32_set_phase_inc(void* h, float phase_inc_re, float phase_inc_im);
 int qdsp_hip_xlate_cf32_get_phase(void* h, float* phase_re, float* phase_im);
 int qdsp_hip_xlate_cf32_set_phase(void* h, float phase_re, float phase_im);
@@ -203,6 +218,8 @@ int qdsp_hip_xlate_fir_decim_cf32_create(void** h, int device, const float* taps
 int qdsp_hip_xlate_fir_decim_cf32_process(void* h, const float* in_iq, int count, float* out_iq);
 int64_t qdsp_hip_xlate_fir_decim_cf32_process_dev(void* h, const void* d_in, int64_t count,
                                                   void* d_out, void* hip_stream);
+int qdsp_hip_xlate_fir_decim_cf32_process_ex(void* h, const void* in, int in_on_device, int count,
+                                             void* out, int out_on_device);
 int qdsp_hip_xlate_fir_decim_cf32_configure(void* h, const float* taps, int ntaps, int interp,
                                             int decim);
 int qdsp_hip_xlate_fir_decim_cf32_set_phase_inc(void* h, float phase_inc_re, float phase_inc_im);

@@ -66,6 +66,10 @@ def load():
     sig("qdsp_hip_dev_free", i32, i32, vp)
     sig("qdsp_hip_memcpy_h2d", i32, i32, vp, vp, C.c_size_t)
     sig("qdsp_hip_memcpy_d2h", i32, i32, vp, vp, C.c_size_t)
+    sig("qdsp_hip_memcpy_d2d", i32, i32, vp, vp, C.c_size_t)
+    for p in ("qdsp_hip_fir_cf32", "qdsp_hip_fir_f32", "qdsp_hip_decim_cf32", "qdsp_hip_decim_f32", "qdsp_hip_xlate_cf32",
+              "qdsp_hip_xlate_fir_decim_cf32"):
+        sig(p + "_process_ex", i32, vp, vp, i32, i32, vp, i32)
     sig("qdsp_hip_device_sync", i32, i32)
 
     for p in ("qdsp_hip_fir_cf32", "qdsp_hip_fir_f32"):

@@ -550,6 +550,29 @@ int64_t process_host(Engine* e, const float* in, int count, float* out) {
     return nout;
 }
 
+// run() with each side on the host (pinned stream buffer) or already on the device (the
+// device-resident companion of a stream): copies only where a side is on the host.
+int64_t process_ex(Engine* e, const void* in, int in_dev, int count, void* out, int out_dev) {
+    if (count < 0 || (count > 0 && (!in || !out))) return QDSP_HIP_EINVAL;
+    if ((!in_dev || !out_dev) && count > e->max_block) {
+        int rc = ensure_io(e, count);
+        if (rc) return rc;
+    }
+    HIPCHK(hipSetDevice(e->device));
+    const void* src = in;
+    if (!in_dev) {
+        if (count) HIPCHK(hipMemcpyAsync(e->d_in, in, (size_t)count * e->ch * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        src = e->d_in;
+    }
+    void* dst = out_dev ? out : e->d_out;
+    const int64_t nout = process_dev(e, src, count, dst, e->stream);
+    if (nout < 0) return nout;
+    if (!out_dev && nout)
+        HIPCHK(hipMemcpyAsync(out, e->d_out, (size_t)nout * e->ch * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return nout;
+}
+
 int reset(Engine* e) {
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipDeviceSynchronize());
@@ -722,6 +745,11 @@ int qdsp_hip_memcpy_d2h(int device, void* h, const void* d, size_t bytes) {
     HIPCHK(hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost));
     return 0;
 }
+int qdsp_hip_memcpy_d2d(int device, void* d_dst, const void* d_src, size_t bytes) {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMemcpy(d_dst, d_src, bytes, hipMemcpyDeviceToDevice));
+    return 0;
+}
 int qdsp_hip_device_sync(int device) { HIPCHK(hipSetDevice(device)); HIPCHK(hipDeviceSynchronize()); return 0; }
 
 // ---- filter-bearing operators: FIR, resampler, fused VFO ---------------------------------
@@ -764,6 +792,12 @@ int qdsp_hip_device_sync(int device) { HIPCHK(hipSetDevice(device)); HIPCHK(hipD
         int64_t r = process_dev(e, d_in, count, d_out, s);                                        \
         return r < 0 ? (int)r : 0;                                                                \
     }                                                                                             \
+    int prefix##_process_ex(void* h, const void* in, int in_dev, int count, void* out, int out_dev) { \
+        Engine* e = as_engine(h, KIND_FIR);                                                       \
+        if (!e || e->ch != CH) return QDSP_HIP_EINVAL;                                            \
+        int64_t r = process_ex(e, in, in_dev, count, out, out_dev);                               \
+        return r < 0 ? (int)r : 0;                                                                \
+    }                                                                                             \
     int prefix##_set_taps(void* h, const float* taps, int ntaps) {                                \
         Engine* e = as_engine(h, KIND_FIR);                                                       \
         return e ? configure(e, taps, ntaps, 1, 1) : QDSP_HIP_EINVAL;                             \
@@ -798,6 +832,11 @@ QDSP_FIR_API(qdsp_hip_fir_f32, 1)
         Engine* e = as_engine(h, KIND_DECIM);                                                     \
         if (!e || e->ch != CH) return QDSP_HIP_EINVAL;                                            \
         return process_dev(e, d_in, count, d_out, s);                                             \
+    }                                                                                             \
+    int prefix##_process_ex(void* h, const void* in, int in_dev, int count, void* out, int out_dev) { \
+        Engine* e = as_engine(h, KIND_DECIM);                                                     \
+        if (!e || e->ch != CH) return QDSP_HIP_EINVAL;                                            \
+        return (int)process_ex(e, in, in_dev, count, out, out_dev);                               \
     }                                                                                             \
     int prefix##_configure(void* h, const float* taps, int ntaps, int interp, int decim) {        \
         Engine* e = as_engine(h, KIND_DECIM);                                                     \
@@ -842,6 +881,12 @@ int qdsp_hip_xlate_cf32_process_dev(void* h, const void* d_in, int64_t count, vo
     Engine* e = as_engine(h, KIND_XLATE);
     if (!e) return QDSP_HIP_EINVAL;
     int64_t r = process_dev(e, d_in, count, d_out, s);
+    return r < 0 ? (int)r : 0;
+}
+int qdsp_hip_xlate_cf32_process_ex(void* h, const void* in, int in_dev, int count, void* out, int out_dev) {
+    Engine* e = as_engine(h, KIND_XLATE);
+    if (!e) return QDSP_HIP_EINVAL;
+    int64_t r = process_ex(e, in, in_dev, count, out, out_dev);
     return r < 0 ? (int)r : 0;
 }
 int qdsp_hip_xlate_cf32_set_phase_inc(void* h, float re, float im) {
@@ -892,6 +937,10 @@ int qdsp_hip_xlate_fir_decim_cf32_process(void* h, const float* in, int count, f
 int64_t qdsp_hip_xlate_fir_decim_cf32_process_dev(void* h, const void* d_in, int64_t count, void* d_out, void* s) {
     Engine* e = as_engine(h, KIND_VFO);
     return e ? process_dev(e, d_in, count, d_out, s) : QDSP_HIP_EINVAL;
+}
+int qdsp_hip_xlate_fir_decim_cf32_process_ex(void* h, const void* in, int in_dev, int count, void* out, int out_dev) {
+    Engine* e = as_engine(h, KIND_VFO);
+    return e ? (int)process_ex(e, in, in_dev, count, out, out_dev) : QDSP_HIP_EINVAL;
 }
 int qdsp_hip_xlate_fir_decim_cf32_configure(void* h, const float* taps, int ntaps, int interp, int decim) {
     Engine* e = as_engine(h, KIND_VFO);

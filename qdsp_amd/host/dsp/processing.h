@@ -39,6 +39,7 @@ public:
         if (rc != 0) { handle = nullptr; detail::hipBlockFail("FrequencyXlator::init", rc); }
         base::registerInput(_in);
         base::registerOutput(&out);
+        _in->consumerTakesDevice = handle != nullptr;
     }
 
     // (sic) the reference names its input setter setInputSize (processing.h:26)
@@ -46,7 +47,9 @@ public:
         std::lock_guard<std::mutex> lck(base::ctrlMtx);
         base::tempStop();
         base::unregisterInput(_in);
+        _in->consumerTakesDevice = false;
         _in = in;
+        _in->consumerTakesDevice = handle != nullptr;
         base::registerInput(_in);
         base::tempStart();
     }
@@ -67,10 +70,14 @@ public:
         const int count = _in->read();
         if (count < 0) { return -1; }
         if (!handle) { return -1; }
-        const int rc = qdsp_hip_xlate_cf32_process(handle, reinterpret_cast<const float*>(_in->readBuf), count,
-                                                   reinterpret_cast<float*>(out.writeBuf));
+        const bool inDev = _in->readOnDevice;
+        const bool outDev = out.consumerTakesDevice && out.ensureDevice(detail::hipDeviceForBlocks());
+        const void* src = inDev ? static_cast<const void*>(_in->devReadBuf) : static_cast<const void*>(_in->readBuf);
+        void* dst = outDev ? static_cast<void*>(out.devWriteBuf) : static_cast<void*>(out.writeBuf);
+        const int rc = qdsp_hip_xlate_cf32_process_ex(handle, src, inDev, count, dst, outDev);
         _in->flush();
         if (rc != 0) { return detail::hipBlockFail("FrequencyXlator::run", rc); }
+        out.writeOnDevice = outDev;
         if (!out.swap(count)) { return -1; }
         return count;
     }

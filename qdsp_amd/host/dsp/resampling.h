@@ -47,13 +47,16 @@ public:
         if (rc != 0) { handle = nullptr; detail::hipBlockFail("PolyphaseResampler::init", rc); }
         base::registerInput(_in);
         base::registerOutput(&out);
+        _in->consumerTakesDevice = handle != nullptr;
     }
 
     void setInput(stream<T>* in) {
         std::lock_guard<std::mutex> lck(base::ctrlMtx);
         base::tempStop();
         base::unregisterInput(_in);
+        _in->consumerTakesDevice = false;
         _in = in;
+        _in->consumerTakesDevice = handle != nullptr;
         base::registerInput(_in);
         base::tempStart();
     }
@@ -96,11 +99,15 @@ public:
         const int count = _in->read();
         if (count < 0) { return -1; }
         if (!handle) { return -1; }
-        const int outCount = kPair
-            ? qdsp_hip_decim_cf32_process(handle, reinterpret_cast<const float*>(_in->readBuf), count, reinterpret_cast<float*>(out.writeBuf))
-            : qdsp_hip_decim_f32_process(handle, reinterpret_cast<const float*>(_in->readBuf), count, reinterpret_cast<float*>(out.writeBuf));
+        const bool inDev = _in->readOnDevice;
+        const bool outDev = out.consumerTakesDevice && out.ensureDevice(detail::hipDeviceForBlocks());
+        const void* src = inDev ? static_cast<const void*>(_in->devReadBuf) : static_cast<const void*>(_in->readBuf);
+        void* dst = outDev ? static_cast<void*>(out.devWriteBuf) : static_cast<void*>(out.writeBuf);
+        const int outCount = kPair ? qdsp_hip_decim_cf32_process_ex(handle, src, inDev, count, dst, outDev)
+                                   : qdsp_hip_decim_f32_process_ex(handle, src, inDev, count, dst, outDev);
         _in->flush();
         if (outCount < 0) { return detail::hipBlockFail("PolyphaseResampler::run", outCount); }
+        out.writeOnDevice = outDev;
         if (!out.swap(outCount)) { return -1; }
         return count;
     }

@@ -11,6 +11,13 @@
 // host memory (qdsp_hip_host_alloc) instead of volk_malloc, so a HIP-backed block can DMA
 // straight out of readBuf and into writeBuf; when no HIP runtime is usable they fall back
 // to ordinary aligned memory (the channel itself needs no GPU).
+//
+// Device-resident companion (new): a stream can also carry a PAIR OF DEVICE
+// BUFFERS that swap in lockstep with the host pair.  A HIP-backed producer whose consumer is
+// another HIP-backed block (`consumerTakesDevice`, set by that consumer when it registers the
+// stream) leaves its block in devWriteBuf and marks it `writeOnDevice`; after swap() the
+// consumer sees `readOnDevice` and reads devReadBuf: no PCIe round trip between adjacent GPU
+// blocks.  Host blocks never look at these members, so the reference protocol is unchanged.
 #pragma once
 #include <condition_variable>
 #include <cstdlib>
@@ -63,6 +70,20 @@ public:
         // the two pointers have been exchanged an unknown number of times; each carries its flag
         detail::stream_mem::put(writeBuf, pinnedW);
         detail::stream_mem::put(readBuf, pinnedR);
+        if (devWriteBuf) { qdsp_hip_dev_free(devDevice, devWriteBuf); }
+        if (devReadBuf) { qdsp_hip_dev_free(devDevice, devReadBuf); }
+    }
+
+    // Allocate the device pair on first use; false if there is no usable device memory.
+    bool ensureDevice(int device) {
+        if (devWriteBuf && devReadBuf) { return true; }
+        void *a = nullptr, *b = nullptr;
+        if (qdsp_hip_dev_alloc(device, &a, sizeof(T) * STREAM_BUFFER_SIZE) != 0) { return false; }
+        if (qdsp_hip_dev_alloc(device, &b, sizeof(T) * STREAM_BUFFER_SIZE) != 0) { qdsp_hip_dev_free(device, a); return false; }
+        devDevice = device;
+        devWriteBuf = static_cast<T*>(a);
+        devReadBuf = static_cast<T*>(b);
+        return true;
     }
 
     stream(const stream&) = delete;
@@ -74,6 +95,9 @@ public:
         if (writerStopped) { return false; }
         T* t = writeBuf; writeBuf = readBuf; readBuf = t;
         bool p = pinnedW; pinnedW = pinnedR; pinnedR = p;
+        t = devWriteBuf; devWriteBuf = devReadBuf; devReadBuf = t;
+        readOnDevice = writeOnDevice;
+        writeOnDevice = false;
         pending = size;
         slotFree = false;
         hasData = true;
@@ -105,6 +129,13 @@ public:
     T* writeBuf;
     T* readBuf;
 
+    // device-resident companion (see the header comment)
+    T* devWriteBuf = nullptr;
+    T* devReadBuf = nullptr;
+    bool writeOnDevice = false;        // producer: the block being swapped in lives in devWriteBuf
+    bool readOnDevice = false;         // consumer: the block just read lives in devReadBuf
+    bool consumerTakesDevice = false;  // set by a HIP-backed consumer on its input stream
+
 private:
     void setFlag(bool& f, bool v) {
         {
@@ -122,6 +153,7 @@ private:
     bool readerStopped = false;
     int pending = 0;
     bool pinnedW = false, pinnedR = false;
+    int devDevice = 0;
 };
 
 }  // namespace dsp

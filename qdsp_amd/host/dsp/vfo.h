@@ -41,6 +41,7 @@ public:
         if (rc != 0) { handle = nullptr; hipBlockFail("VFO::init", rc); }
         base::registerInput(_in);
         base::registerOutput(&out);
+        _in->consumerTakesDevice = handle != nullptr;
     }
 
     void configure(const std::vector<float>& taps, int interp, int decim) {
@@ -61,10 +62,14 @@ public:
         const int count = _in->read();
         if (count < 0) { return -1; }
         if (!handle) { return -1; }
-        const int outCount = qdsp_hip_xlate_fir_decim_cf32_process(handle, reinterpret_cast<const float*>(_in->readBuf), count,
-                                                                   reinterpret_cast<float*>(out.writeBuf));
+        const bool inDev = _in->readOnDevice;
+        const bool outDev = out.consumerTakesDevice && out.ensureDevice(hipDeviceForBlocks());
+        const void* src = inDev ? static_cast<const void*>(_in->devReadBuf) : static_cast<const void*>(_in->readBuf);
+        void* dst = outDev ? static_cast<void*>(out.devWriteBuf) : static_cast<void*>(out.writeBuf);
+        const int outCount = qdsp_hip_xlate_fir_decim_cf32_process_ex(handle, src, inDev, count, dst, outDev);
         _in->flush();
         if (outCount < 0) { return hipBlockFail("VFO::run", outCount); }
+        out.writeOnDevice = outDev;
         if (!out.swap(outCount)) { return -1; }
         return count;
     }

@@ -11,6 +11,11 @@
 //   graph_check xlate  <in.cf32> <out.cf32> <block> <sampleRate> <freq>
 //   graph_check vfo    <in.cf32> <out.cf32> <block> <offset> <inSR> <outSR> <bw>
 //   graph_check wavfir <in.wav>  <out.cf32> <block>   config 1: int16 IQ WAV -> 63-tap FIR
+//   graph_check chain  <in.cf32> <out.cf32> <block> <taps.f32> <sampleRate> <freq> <inSR> <outSR>
+//                      source -> FrequencyXlator -> FIR -> PolyphaseResampler -> sink: three GPU
+//                      blocks in a row, the two links between them device-resident
+//   graph_check split  <in.cf32> <out_prefix> <block> <n> <inSR> <outSR> <bw>
+//                      source -> Splitter -> n x VFO(offset_i = (i - (n-1)/2) * inSR/n) -> sinks
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -24,6 +29,7 @@
 #include <dsp/filter.h>
 #include <dsp/processing.h>
 #include <dsp/resampling.h>
+#include <dsp/routing.h>
 #include <dsp/sink.h>
 #include <dsp/source.h>
 #include <dsp/vfo.h>
@@ -244,6 +250,71 @@ int main(int argc, char** argv) {
         };
         const float off = (float)atof(argv[5]), inSR = (float)atof(argv[6]), outSR = (float)atof(argv[7]), bw = (float)atof(argv[8]);
         return runGraph<complex_t>(in, out, block, [&](stream<complex_t>* s) { return new VfoBox(s, off, inSR, outSR, bw); });
+    }
+    if (mode == "chain" && argc >= 10) {
+        // three HIP-backed blocks back to back; only the first reads and the last writes host memory
+        FileTaps taps(argv[5]);
+        const float sr = (float)atof(argv[6]), f = (float)atof(argv[7]), inSR = (float)atof(argv[8]), outSR = (float)atof(argv[9]);
+        struct Chain {
+            FrequencyXlator<complex_t> xl;
+            FIR<complex_t> fir;
+            filter_window::BlackmanWindow win;
+            PolyphaseResampler<complex_t> rs;
+            stream<complex_t>& out;
+            Chain(stream<complex_t>* s, FileTaps* t, float sr, float f, float inSR, float outSR)
+                : xl(s, sr, f), fir(&xl.out, t), win(outSR / 2.0f, outSR / 2.0f, inSR), rs(&fir.out, &win, inSR, outSR), out(rs.out) {}
+            void start() { rs.start(); fir.start(); xl.start(); }
+            void stop() { xl.stop(); fir.stop(); rs.stop(); }
+        };
+        int rc = runGraph<complex_t>(in, out, block, [&](stream<complex_t>* s) { return new Chain(s, &taps, sr, f, inSR, outSR); });
+        return rc;
+    }
+    if (mode == "split" && argc >= 9) {
+        const int n = atoi(argv[5]);
+        const float inSR = (float)atof(argv[6]), outSR = (float)atof(argv[7]), bw = (float)atof(argv[8]);
+        Feed<complex_t> feed;
+        feed.data = readAll<complex_t>(in);
+        feed.block = block;
+        const long nblocks = (long)((feed.data.size() + block - 1) / block);
+        HandlerSource<complex_t> src(Feed<complex_t>::pull, &feed);
+        Splitter<complex_t> split(&src.out);
+        std::vector<stream<complex_t>*> links;
+        std::vector<VFO*> vfos;
+        std::vector<Collect<complex_t>*> cols;
+        std::vector<HandlerSink<complex_t>*> sinks;
+        for (int i = 0; i < n; i++) {
+            links.push_back(new stream<complex_t>());
+            const float off = ((float)i - (float)(n - 1) / 2.0f) * inSR / (float)n;
+            vfos.push_back(new VFO(links[i], off, inSR, outSR, bw));
+            split.bindStream(links[i]);
+            cols.push_back(new Collect<complex_t>());
+            sinks.push_back(new HandlerSink<complex_t>(vfos[i]->out, Collect<complex_t>::push, cols[i]));
+        }
+        for (auto* s : sinks) { s->start(); }
+        for (auto* v : vfos) { v->start(); }
+        split.start();
+        src.start();
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < n; i++) {
+            while (cols[i]->blocks.load() < nblocks) {
+                std::this_thread::sleep_for(std::chrono::milliseconds(1));
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) { fprintf(stderr, "split graph timed out\n"); return 3; }
+            }
+        }
+        src.stop();
+        split.stop();
+        for (auto* v : vfos) { v->stop(); }
+        for (auto* s : sinks) { s->stop(); }
+        for (int i = 0; i < n; i++) {
+            std::ofstream o(std::string(out) + "." + std::to_string(i) + ".cf32", std::ios::binary);
+            o.write(reinterpret_cast<const char*>(cols[i]->data.data()), (std::streamsize)(cols[i]->data.size() * sizeof(complex_t)));
+        }
+        printf("split ok: %d channels, %zu in, %zu out each\n", n, feed.data.size(), cols[0]->data.size());
+        for (auto* s : sinks) { delete s; }
+        for (auto* v : vfos) { delete v; }
+        for (auto* l : links) { delete l; }
+        for (auto* c : cols) { delete c; }
+        return 0;
     }
     if (mode == "wavfir") {
         // BASELINE config 1: int16 stereo (I,Q) WAV -> complex (s / 32768.0f) -> 63-tap FIR.

@@ -67,6 +67,7 @@ def test_headers_keep_the_reference_surface():
                       "stream<complex_t>* out"],
         "dsp/window.h": ["generic_window", "BlackmanWindow", "BlackmanBandpassWindow", "RRCTaps", "getTapCount", "createTaps"],
         "dsp/types.h": ["struct complex_t", "struct stereo_t", "FL_M_PI 3.1415926535f", "fastPhase", "fastAmplitude", "conj()"],
+        "dsp/routing.h": ["class Splitter", "bindStream", "unbindStream", "setInput"],
         "wav.h": ["class WavWriter", "writeSamples"], "wavreader.h": ["class WavReader", "readSamples", "getSampleRate", "isValid"],
     }
     for f, names in need.items():
@@ -166,3 +167,37 @@ def test_graph_wav_config1(harness, tmp_path):
     spec = np.abs(np.fft.fft(y[4096:4096 + 65536] * np.hanning(65536)))
     f = np.fft.fftfreq(65536, 1 / fs)
     assert spec[np.argmin(np.abs(f - 100e3))] > 30 * spec[np.argmin(np.abs(f + 700e3))]
+
+
+@gpu
+def test_graph_device_resident_chain(harness, data):
+    """source -> FrequencyXlator -> FIR -> PolyphaseResampler -> sink: the two inner links stay on
+    the device (stream.h device-resident companion, *_process_ex); result == the same blocks
+    chained through the oracle."""
+    d, x = data
+    taps = O.lowpass_taps_f64(128, 0.2)
+    taps.tofile(d / "t128.f32")
+    b = 40_000
+    run([harness, "chain", str(d / "x.cf32"), str(d / "yc.cf32"), str(b), str(d / "t128.f32"), "48000", "-5000", "48000", "12000"])
+    y = np.fromfile(d / "yc.cf32", dtype=np.complex64)
+    xl = O.Xlator(48000.0, -5000.0, exact=True, volk_gain=True)
+    fir = O.Fir(taps, acc=O.ACC_F64)
+    L, M = O.resamp_ratio(48000.0, 12000.0)
+    n = O.blackman_tap_count(6000.0, 6000.0, 48000.0)
+    rs = O.Resampler(O.blackman_taps(6000.0, 48000.0, n, factor=float(L)), L, M, acc=O.ACC_F64)
+    want = np.concatenate([rs.process(fir.process(xl.process(x[i:i + b]))) for i in range(0, len(x), b)])
+    assert (L, M) == (1, 4) and len(y) == len(want) and rel_rms(y, want) < 3e-6
+
+
+@gpu
+def test_graph_splitter_to_vfos(harness, data):
+    """source -> Splitter -> 4 x VFO -> sinks (the channelizer shape of the reference)."""
+    d, x = data
+    b, n = 50_000, 4
+    run([harness, "split", str(d / "x.cf32"), str(d / "ys"), str(b), str(n), "2400000", "240000", "200000"])
+    for i in range(n):
+        y = np.fromfile(str(d / "ys") + f".{i}.cf32", dtype=np.complex64)
+        off = np.float32((np.float32(i) - np.float32(n - 1) / np.float32(2.0)) * np.float32(2.4e6) / np.float32(n))
+        v = O.Vfo(float(off), 2.4e6, 240e3, 200e3, exact_nco=True, volk_gain=True)
+        want = np.concatenate([v.process(x[j:j + b]) for j in range(0, len(x), b)])
+        assert len(y) == len(want) and rel_rms(y, want) < 3e-6, i
