@@ -207,6 +207,19 @@ int qdsp_hip_xlate_cf32_advance(void* h, int64_t nsamples);
 int qdsp_hip_xlate_cf32_set_volk_gain(void* h, int on);
 void qdsp_hip_xlate_cf32_destroy(void* h);
 
+/* ---- SineSource : src/dsp/source.h:5-71 ------------------------------------------------- */
+/* The reference runs volk_32fc_s32fc_x2_rotator_32fc over a buffer of ones (source.h:55-59):
+ * out[n] = phase_n, phase_{n+1} = phase_n * phase_inc, phase_0 = (1,0).  Same NCO as
+ * xlate_cf32 with no input traffic.  generate(): `out` on the host (synchronous copy) or
+ * device-resident (out_on_device = 1); generate_dev(): asynchronous on `hip_stream`. */
+int qdsp_hip_sine_cf32_create(void** h, int device, float phase_inc_re, float phase_inc_im, int max_block);
+int qdsp_hip_sine_cf32_generate(void* h, int count, void* out, int out_on_device);
+int qdsp_hip_sine_cf32_generate_dev(void* h, int64_t count, void* d_out, void* hip_stream);
+int qdsp_hip_sine_cf32_set_phase_inc(void* h, float phase_inc_re, float phase_inc_im);
+int qdsp_hip_sine_cf32_get_phase(void* h, float* phase_re, float* phase_im);
+int qdsp_hip_sine_cf32_set_volk_gain(void* h, int on);
+void qdsp_hip_sine_cf32_destroy(void* h);
+
 /* ---- VFO : src/dsp/vfo.h:19-36 (FrequencyXlator -> PolyphaseResampler), fused ---------- */
 /* One kernel does what the reference runs as two blocks/threads with a stream hop between
  * them: rotate while staging into LDS, then the polyphase dot products.  Semantics are

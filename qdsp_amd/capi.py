@@ -111,6 +111,13 @@ def load():
         sig(p + "_history_dev", i32, vp, pvp)
         sig(p + "_set_history_dev", i32, vp, vp, vp)
         sig(p + "_destroy", None, vp)
+    sig("qdsp_hip_sine_cf32_create", i32, pvp, i32, C.c_float, C.c_float, i32)
+    sig("qdsp_hip_sine_cf32_generate", i32, vp, i32, vp, i32)
+    sig("qdsp_hip_sine_cf32_generate_dev", i32, vp, i64, vp, vp)
+    sig("qdsp_hip_sine_cf32_set_phase_inc", i32, vp, C.c_float, C.c_float)
+    sig("qdsp_hip_sine_cf32_get_phase", i32, vp, fp, fp)
+    sig("qdsp_hip_sine_cf32_set_volk_gain", i32, vp, i32)
+    sig("qdsp_hip_sine_cf32_destroy", None, vp)
     p = "qdsp_hip_chan_cf32"
     sig(p + "_create", i32, pvp, i32, fp, i32, i32, i32, i32, fp, fp, i32)
     sig(p + "_process", i32, vp, vp, i32, vp, i32)

@@ -327,7 +327,10 @@ template <int NT> __global__ __launch_bounds__(NT) void xlate_kernel(const Xlate
         const double2 ph1 = cmul(ph, a.rot_one);
         if (g + 1 < a.count) {
             float2 x0, x1;
-            if (a.vec) {
+            if (!a.in) {   // SineSource: the rotator runs over a buffer of ones (src/dsp/source.h:55-59)
+                x0 = make_float2(1.0f, 0.0f);
+                x1 = x0;
+            } else if (a.vec) {
                 const float4 v = reinterpret_cast<const float4*>(a.in)[p];
                 x0 = make_float2(v.x, v.y);
                 x1 = make_float2(v.z, v.w);
@@ -343,7 +346,7 @@ template <int NT> __global__ __launch_bounds__(NT) void xlate_kernel(const Xlate
                 a.out[g + 1] = y1;
             }
         } else {
-            a.out[g] = rotate(a.in[g], ph, g, a.gm1);
+            a.out[g] = rotate(a.in ? a.in[g] : make_float2(1.0f, 0.0f), ph, g, a.gm1);
         }
         ph = cmul(ph, a.rot_stride);
     }

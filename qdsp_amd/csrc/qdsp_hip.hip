@@ -23,7 +23,7 @@ namespace {
 
 constexpr int kMaxDynLds = 64 * 1024;  // default dynamic-LDS ceiling; tiles are sized under it
 
-enum Kind : int { KIND_FIR = 1, KIND_DECIM = 2, KIND_XLATE = 3, KIND_VFO = 4, KIND_CHAN = 5 };
+enum Kind : int { KIND_FIR = 1, KIND_DECIM = 2, KIND_XLATE = 3, KIND_VFO = 4, KIND_CHAN = 5, KIND_SINE = 6 };
 constexpr uint32_t kMagic = 0x51445350u;  // "QDSP"
 
 struct Launch {
@@ -465,7 +465,7 @@ int launch_xlate(Engine* e, const void* d_in, int64_t count, void* d_out, hipStr
     if (grid > 256 * 16) grid = 256 * 16;  // 16 blocks per CU, grid-stride beyond
     unit_of_fx(e->dphase, 1.0L, &a.rot_one.x, &a.rot_one.y);
     unit_of_fx(e->dphase, (long double)(2 * grid * NT), &a.rot_stride.x, &a.rot_stride.y);
-    a.vec = (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0;
+    a.vec = (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0;   // d_in == nullptr (SineSource) counts as aligned
     a.gm1 = e->volk_gain ? e->gm1 : 0.0f;
     hipLaunchKernelGGL((qk::xlate_kernel<NT>), dim3((unsigned)grid), dim3(NT), 0, s, a);
     HIPCHK(hipGetLastError());
@@ -478,7 +478,7 @@ int launch_xlate(Engine* e, const void* d_in, int64_t count, void* d_out, hipStr
 
 // One run() worth of work on device pointers.  Returns the output count.
 int64_t process_dev(Engine* e, const void* d_in, int64_t count, void* d_out, void* stream) {
-    if (count < 0 || (count > 0 && (!d_in || !d_out))) return QDSP_HIP_EINVAL;
+    if (count < 0 || (count > 0 && ((!d_in && e->kind != KIND_SINE) || !d_out))) return QDSP_HIP_EINVAL;
     HIPCHK(hipSetDevice(e->device));
     hipStream_t s = static_cast<hipStream_t>(stream);  // NULL == HIP's default stream
     const int64_t nout = out_size(e, count);
@@ -916,6 +916,57 @@ int qdsp_hip_xlate_cf32_set_volk_gain(void* h, int on) {
     return 0;
 }
 void qdsp_hip_xlate_cf32_destroy(void* h) { Engine* e = as_engine(h, KIND_XLATE); if (e) destroy(e); }
+
+// ---- SineSource -----------------------------------------------------------------------------
+int qdsp_hip_sine_cf32_create(void** h, int device, float inc_re, float inc_im, int max_block) {
+    if (inc_re == 0.0f && inc_im == 0.0f) return QDSP_HIP_EINVAL;
+    int rc = create(h, KIND_SINE, device, 2, true, false, max_block);
+    if (rc) return rc;
+    Engine* e = static_cast<Engine*>(*h);
+    set_inc(e, inc_re, inc_im);
+    rc = ensure_io(e, max_block);
+    if (rc) { destroy(e); *h = nullptr; }
+    return rc;
+}
+int qdsp_hip_sine_cf32_generate(void* h, int count, void* out, int out_on_device) {
+    Engine* e = as_engine(h, KIND_SINE);
+    if (!e || count < 0 || (count > 0 && !out)) return QDSP_HIP_EINVAL;
+    if (!out_on_device && count > e->max_block) {
+        int rc = ensure_io(e, count);
+        if (rc) return rc;
+    }
+    HIPCHK(hipSetDevice(e->device));
+    void* dst = out_on_device ? out : e->d_out;
+    const int64_t r = process_dev(e, nullptr, count, dst, e->stream);
+    if (r < 0) return (int)r;
+    if (!out_on_device && count)
+        HIPCHK(hipMemcpyAsync(out, e->d_out, (size_t)count * 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+int qdsp_hip_sine_cf32_generate_dev(void* h, int64_t count, void* d_out, void* stream) {
+    Engine* e = as_engine(h, KIND_SINE);
+    if (!e) return QDSP_HIP_EINVAL;
+    const int64_t r = process_dev(e, nullptr, count, d_out, stream);
+    return r < 0 ? (int)r : 0;
+}
+int qdsp_hip_sine_cf32_set_phase_inc(void* h, float re, float im) {
+    Engine* e = as_engine(h, KIND_SINE);
+    if (!e || (re == 0.0f && im == 0.0f)) return QDSP_HIP_EINVAL;
+    set_inc(e, re, im);
+    return 0;
+}
+int qdsp_hip_sine_cf32_get_phase(void* h, float* re, float* im) {
+    Engine* e = as_engine(h, KIND_SINE);
+    return e ? get_phase(e, re, im) : QDSP_HIP_EINVAL;
+}
+int qdsp_hip_sine_cf32_set_volk_gain(void* h, int on) {
+    Engine* e = as_engine(h, KIND_SINE);
+    if (!e) return QDSP_HIP_EINVAL;
+    e->volk_gain = on != 0;
+    return 0;
+}
+void qdsp_hip_sine_cf32_destroy(void* h) { Engine* e = as_engine(h, KIND_SINE); if (e) destroy(e); }
 
 // ---- fused VFO ------------------------------------------------------------------------------
 int qdsp_hip_xlate_fir_decim_cf32_create(void** h, int device, const float* taps, int ntaps, int interp,

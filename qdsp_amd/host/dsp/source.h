@@ -1,10 +1,90 @@
-// dsp/source.h -- HandlerSource<T>: a callback fills out.writeBuf and returns the count
-// (reference: src/dsp/source.h:74-107).  (SineSource is VOLK-rotator based and listed as
-// "next" in SURVEY 8f; it is not part of this round.)
+// dsp/source.h -- SineSource (HIP-backed) and HandlerSource<T>.
+//
+// SineSource: same surface as the reference (src/dsp/source.h:5-71); where the reference
+// rotates a buffer of ones with VOLK each run() (source.h:55-59), this one asks the device
+// NCO for the next _blockSize samples (qdsp_hip_sine_cf32_*), device-resident when the
+// consumer is another HIP-backed block.
+// HandlerSource<T>: a callback fills out.writeBuf and returns the count (source.h:74-107).
 #pragma once
+#include <cmath>
+
 #include "block.h"
+#include "filter.h"
 
 namespace dsp {
+
+class SineSource : public generic_block<SineSource> {
+    using base = generic_block<SineSource>;
+
+public:
+    SineSource() {}
+    SineSource(int blockSize, float sampleRate, float freq) { init(blockSize, sampleRate, freq); }
+
+    ~SineSource() {
+        base::stop();
+        if (handle) { qdsp_hip_sine_cf32_destroy(handle); }
+    }
+
+    void init(int blockSize, float sampleRate, float freq) {
+        _blockSize = blockSize;
+        _sampleRate = sampleRate;
+        _freq = freq;
+        float dRe, dIm;
+        delta(dRe, dIm);
+        const int rc = qdsp_hip_sine_cf32_create(&handle, detail::hipDeviceForBlocks(), dRe, dIm, STREAM_BUFFER_SIZE);
+        if (rc != 0) { handle = nullptr; detail::hipBlockFail("SineSource::init", rc); }
+        base::registerOutput(&out);
+    }
+
+    void setBlockSize(int blockSize) {
+        std::lock_guard<std::mutex> lck(base::ctrlMtx);
+        base::tempStop();
+        _blockSize = blockSize;
+        base::tempStart();
+    }
+    int getBlockSize() { return _blockSize; }
+
+    void setSampleRate(float sampleRate) {
+        _sampleRate = sampleRate;
+        push();
+    }
+    float getSampleRate() { return _sampleRate; }
+
+    void setFrequency(float freq) {
+        _freq = freq;
+        push();
+    }
+    float getFrequency() { return _freq; }
+
+    int run() override {
+        if (!handle) { return -1; }
+        const bool outDev = out.consumerTakesDevice && out.ensureDevice(detail::hipDeviceForBlocks());
+        void* dst = outDev ? static_cast<void*>(out.devWriteBuf) : static_cast<void*>(out.writeBuf);
+        const int rc = qdsp_hip_sine_cf32_generate(handle, _blockSize, dst, outDev);
+        if (rc != 0) { return detail::hipBlockFail("SineSource::run", rc); }
+        out.writeOnDevice = outDev;
+        if (!out.swap(_blockSize)) { return -1; }
+        return _blockSize;
+    }
+
+    stream<complex_t> out;
+
+private:
+    void delta(float& dRe, float& dIm) const {
+        const float theta = (_freq / _sampleRate) * 2.0f * FL_M_PI;  // source.h:18
+        dRe = std::cos(theta);
+        dIm = std::sin(theta);
+    }
+    void push() {
+        float dRe, dIm;
+        delta(dRe, dIm);
+        if (handle) { qdsp_hip_sine_cf32_set_phase_inc(handle, dRe, dIm); }
+    }
+
+    int _blockSize = 0;
+    float _sampleRate = 1.0f, _freq = 0.0f;
+    void* handle = nullptr;
+};
 
 template <class T>
 class HandlerSource : public generic_block<HandlerSource<T>> {

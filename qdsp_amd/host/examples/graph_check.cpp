@@ -11,6 +11,8 @@
 //   graph_check xlate  <in.cf32> <out.cf32> <block> <sampleRate> <freq>
 //   graph_check vfo    <in.cf32> <out.cf32> <block> <offset> <inSR> <outSR> <bw>
 //   graph_check wavfir <in.wav>  <out.cf32> <block>   config 1: int16 IQ WAV -> 63-tap FIR
+//   graph_check sine   <out.cf32> <blockSize> <nblocks> <sampleRate> <freq> [fir_taps.f32]
+//                      SineSource -> (optional FIR) -> sink
 //   graph_check chain  <in.cf32> <out.cf32> <block> <taps.f32> <sampleRate> <freq> <inSR> <outSR>
 //                      source -> FrequencyXlator -> FIR -> PolyphaseResampler -> sink: three GPU
 //                      blocks in a row, the two links between them device-resident
@@ -212,6 +214,32 @@ int main(int argc, char** argv) {
     const std::string mode = argv[1];
     if (mode == "taps" && argc >= 3) { return dumpTaps(argv[2]); }
     if (mode == "stream") { return streamSelfTest(); }
+    if (mode == "sine" && argc >= 7) {
+        const int bs = atoi(argv[3]), nb = atoi(argv[4]);
+        SineSource src(bs, (float)atof(argv[5]), (float)atof(argv[6]));
+        Collect<complex_t> col;
+        FileTaps* taps = argc >= 8 ? new FileTaps(argv[7]) : nullptr;
+        FIR<complex_t>* fir = taps ? new FIR<complex_t>(&src.out, taps) : nullptr;
+        HandlerSink<complex_t> sink(fir ? &fir->out : &src.out, Collect<complex_t>::push, &col);
+        sink.start();
+        if (fir) { fir->start(); }
+        src.start();
+        const auto t0 = std::chrono::steady_clock::now();
+        while (col.blocks.load() < nb) {
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) { fprintf(stderr, "sine graph timed out\n"); return 3; }
+        }
+        src.stop();
+        if (fir) { fir->stop(); }
+        sink.stop();
+        col.data.resize((size_t)bs * nb);
+        std::ofstream o(argv[2], std::ios::binary);
+        o.write(reinterpret_cast<const char*>(col.data.data()), (std::streamsize)(col.data.size() * sizeof(complex_t)));
+        delete fir;
+        delete taps;
+        printf("sine ok: %d blocks of %d\n", nb, bs);
+        return 0;
+    }
     if (argc < 5) { fprintf(stderr, "missing arguments\n"); return 2; }
     const char* in = argv[2];
     const char* out = argv[3];

@@ -68,6 +68,8 @@ def test_headers_keep_the_reference_surface():
         "dsp/window.h": ["generic_window", "BlackmanWindow", "BlackmanBandpassWindow", "RRCTaps", "getTapCount", "createTaps"],
         "dsp/types.h": ["struct complex_t", "struct stereo_t", "FL_M_PI 3.1415926535f", "fastPhase", "fastAmplitude", "conj()"],
         "dsp/routing.h": ["class Splitter", "bindStream", "unbindStream", "setInput"],
+        "dsp/source.h": ["class SineSource", "setBlockSize", "getBlockSize", "setFrequency", "class HandlerSource", "setHandler"],
+        "dsp/sink.h": ["class HandlerSink", "class NullSink", "class FileSink"],
         "wav.h": ["class WavWriter", "writeSamples"], "wavreader.h": ["class WavReader", "readSamples", "getSampleRate", "isValid"],
     }
     for f, names in need.items():
@@ -201,3 +203,25 @@ def test_graph_splitter_to_vfos(harness, data):
         v = O.Vfo(float(off), 2.4e6, 240e3, 200e3, exact_nco=True, volk_gain=True)
         want = np.concatenate([v.process(x[j:j + b]) for j in range(0, len(x), b)])
         assert len(y) == len(want) and rel_rms(y, want) < 3e-6, i
+
+
+@gpu
+def test_graph_sine_source(harness, tmp_path):
+    """SineSource (device NCO) alone, and feeding a FIR through a device-resident link."""
+    bs, nb, fs, f = 4096, 8, 48000.0, 1234.0
+    run([harness, "sine", str(tmp_path / "s.cf32"), str(bs), str(nb), str(fs), str(f)])
+    y = np.fromfile(tmp_path / "s.cf32", dtype=np.complex64)
+    ones = np.ones(bs * nb, np.complex64)
+    xl = O.Xlator(fs, f, exact=True, volk_gain=True)      # rotator over ones, one call per block
+    want = np.concatenate([xl.process(ones[i:i + bs]) for i in range(0, len(ones), bs)])
+    assert len(y) == len(want) and np.abs(y - want).max() < 6e-7
+    g = O.Xlator(fs, f)                                    # the reference's recursive phasor
+    wg = np.concatenate([g.process(ones[i:i + bs]) for i in range(0, len(ones), bs)])
+    assert rel_rms(y, wg) < 1e-5
+    taps = O.lowpass_taps_f64(64, 0.1)
+    taps.tofile(tmp_path / "t.f32")
+    run([harness, "sine", str(tmp_path / "sf.cf32"), str(bs), str(nb), str(fs), str(f), str(tmp_path / "t.f32")])
+    yf = np.fromfile(tmp_path / "sf.cf32", dtype=np.complex64)
+    fir = O.Fir(taps, acc=O.ACC_F64)
+    wf = np.concatenate([fir.process(want[i:i + bs]) for i in range(0, len(want), bs)])
+    assert rel_rms(yf, wf) < 2e-6
