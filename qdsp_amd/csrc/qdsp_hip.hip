@@ -4,6 +4,7 @@
 #include "../../include/qdsp_hip.h"
 #include "kernels.hip.h"
 #include "fft_fir.hip.h"
+#include "chan.hip.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -656,6 +657,15 @@ struct Chan {
     void* d_out = nullptr;
     int max_block = 0;
     size_t out_cap = 0;            // samples per channel
+    // uniform polyphase fast path (chan.hip): 64 channels spaced +-1/64 turn/sample, decim 64
+    int mode = 0;                  // QDSP_HIP_FIR_AUTO / _DIRECT (one fused VFO kernel per channel) / _FFT (= fast path if the plan allows)
+    bool volk_gain = true;
+    int ntaps = 0, interp = 1, decim = 1;
+    float* d_taps = nullptr;       // prototype taps padded to 256
+    float2* d_tw64 = nullptr;
+    float* d_hist[2] = {nullptr, nullptr};   // P samples rotated by channel 0's NCO
+    int cur = 0;
+    Launch last;
 };
 Chan* as_chan(void* h) {
     Chan* c = static_cast<Chan*>(h);
@@ -666,21 +676,113 @@ void chan_destroy(Chan* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (Engine* e : c->vfo) destroy(e);
+    if (c->d_taps) (void)hipFree(c->d_taps);
+    if (c->d_tw64) (void)hipFree(c->d_tw64);
+    for (int i = 0; i < 2; i++)
+        if (c->d_hist[i]) (void)hipFree(c->d_hist[i]);
     if (c->d_in) (void)hipFree(c->d_in);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     c->magic = 0;
     delete c;
 }
+// The uniform plan the fast path needs: 64 channels, interp 1, decim 64, <= 256 taps, and the
+// channels' fixed-point phase increments equal to channel 0's plus c * (+-2^58) to within
+// float rounding of the (cos, sin) pairs they came from.  Fills sign / deviations.
+bool chan_uniform_plan(const Chan* c, int* inv, long long* ddelta) {
+    if (c->nchan != 64 || c->interp != 1 || c->decim != 64 || c->ntaps < 1 || c->ntaps > 256) return false;
+    const unsigned long long d0 = c->vfo[0]->dphase;
+    const long long tol = (long long)(18446744073709551616.0 * 4e-7);
+    for (int sign = 1; sign >= -1; sign -= 2) {
+        bool ok = true;
+        for (int i = 0; i < 64 && ok; i++) {
+            const unsigned long long ideal = d0 + (unsigned long long)((long long)sign * (long long)i) * (1ULL << 58);
+            const long long dev = (long long)(c->vfo[i]->dphase - ideal);
+            if (dev > tol || dev < -tol) ok = false;
+            ddelta[i] = dev;
+        }
+        if (ok) { *inv = sign > 0; return true; }
+    }
+    return false;
+}
+
+int chan_launch_uniform(Chan* c, const void* d_in, int64_t count, int64_t nout, void* d_out, int64_t out_stride, hipStream_t s) {
+    qk::ChanArgs a;
+    memset(&a, 0, sizeof(a));
+    if (!chan_uniform_plan(c, &a.inv, a.ddelta)) return QDSP_HIP_EINVAL;
+    const int P = c->ntaps;
+    if (!c->d_taps) {
+        std::vector<float> tp(256, 0.0f);
+        for (int i = 0; i < c->ntaps; i++) tp[i] = c->vfo[0]->taps_host[i];
+        std::vector<float2> tw(64);
+        const long double two_pi = 6.283185307179586476925286766559005768L;
+        for (int m = 0; m < 64; m++) tw[m] = make_float2((float)cosl(two_pi * m / 64), (float)(-sinl(two_pi * m / 64)));
+        HIPCHK(hipMalloc(&c->d_taps, 256 * sizeof(float)));
+        HIPCHK(hipMalloc(&c->d_tw64, 64 * sizeof(float2)));
+        HIPCHK(hipMemcpy(c->d_taps, tp.data(), 256 * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->d_tw64, tw.data(), 64 * sizeof(float2), hipMemcpyHostToDevice));
+        for (int i = 0; i < 2; i++) {
+            HIPCHK(hipMalloc(&c->d_hist[i], (size_t)P * sizeof(float2)));
+            HIPCHK(hipMemset(c->d_hist[i], 0, (size_t)P * sizeof(float2)));
+        }
+    }
+    a.in = static_cast<const float2*>(d_in);
+    a.out = static_cast<float2*>(d_out);
+    a.hist = reinterpret_cast<const float2*>(c->d_hist[c->cur]);
+    a.hist_next = reinterpret_cast<float2*>(c->d_hist[c->cur ^ 1]);
+    a.taps = c->d_taps;
+    a.tw64 = c->d_tw64;
+    a.count = count;
+    a.nout = nout;
+    a.out_stride = out_stride;
+    a.P = P;
+    a.Q = (c->ntaps + 63) / 64;
+    a.ntiles = (int)((nout + 63) / 64);
+    int nwg = 256 * env_int("QDSP_HIP_CHAN_WG_PER_CU", 8);
+    if (nwg > a.ntiles) nwg = a.ntiles;
+    a.nwg = nwg;
+    a.kcentre = (c->ntaps - 1) / 2;
+    a.phase0 = c->vfo[0]->phase;
+    a.dphase0 = c->vfo[0]->dphase;
+    unit_of_fx(a.dphase0, 256.0L, &a.rot256.x, &a.rot256.y);
+    for (int i = 0; i < 64; i++) {
+        a.dphi[i] = c->vfo[i]->phase - c->vfo[0]->phase;
+        a.gm1[i] = c->volk_gain ? c->vfo[i]->gm1 : 0.0f;
+    }
+    const size_t rows = (size_t)(63 + a.Q) * 68;
+    const size_t elems = rows > 256 * 17 ? rows : 256 * 17;
+    a.lds_elems = (int)elems;
+    const size_t lds = elems * sizeof(float2) + 256 * sizeof(float);
+    int rc = qk::launch_chan_uniform(a, nwg + 1, lds, s);
+    if (rc) return rc;
+    c->cur ^= 1;
+    for (int i = 0; i < 64; i++) c->vfo[i]->phase += (unsigned long long)count * c->vfo[i]->dphase;
+    c->last.name = "chan_uniform_kernel";
+    c->last.grid = nwg + 1;
+    c->last.block = 256;
+    c->last.lds = (int)lds;
+    return 0;
+}
+
 int64_t chan_process_dev(Chan* c, const void* d_in, int64_t count, void* d_out, int64_t out_stride, void* stream) {
     if (count < 0 || c->vfo.empty()) return QDSP_HIP_EINVAL;
     const int64_t nout = out_size(c->vfo[0], count);
     if (out_stride < nout) return QDSP_HIP_EINVAL;
+    {
+        int inv;
+        long long dd[64];
+        const int mode = c->mode ? c->mode : env_int("QDSP_HIP_FIR_MODE", 0);
+        if (mode != 1 && chan_uniform_plan(c, &inv, dd)) {
+            int rc = chan_launch_uniform(c, d_in, count, nout, d_out, out_stride, static_cast<hipStream_t>(stream));
+            return rc ? rc : nout;
+        }
+    }
     for (int i = 0; i < c->nchan; i++) {
         float2* o = static_cast<float2*>(d_out) + (size_t)i * out_stride;
         const int64_t r = process_dev(c->vfo[i], d_in, count, o, stream);
         if (r < 0) return r;
     }
+    c->last = c->vfo[0]->last;
     return nout;
 }
 
@@ -1047,6 +1149,9 @@ int qdsp_hip_chan_cf32_create(void** h, int device, const float* taps, int ntaps
     if (!c) return QDSP_HIP_ENOMEM;
     c->device = device;
     c->nchan = nchan;
+    c->ntaps = ntaps;
+    c->interp = interp;
+    c->decim = decim;
     int rc = 0;
     for (int i = 0; i < nchan && rc == 0; i++) {
         void* eh = nullptr;
@@ -1097,12 +1202,14 @@ int qdsp_hip_chan_cf32_set_phase_inc(void* h, int chan, float re, float im) {
 int qdsp_hip_chan_cf32_set_mode(void* h, int mode) {
     Chan* c = as_chan(h);
     if (!c || mode < 0 || mode > 2) return QDSP_HIP_EINVAL;
+    c->mode = mode;
     for (Engine* e : c->vfo) e->fir_mode = mode;
     return 0;
 }
 int qdsp_hip_chan_cf32_set_volk_gain(void* h, int on) {
     Chan* c = as_chan(h);
     if (!c) return QDSP_HIP_EINVAL;
+    c->volk_gain = on != 0;
     for (Engine* e : c->vfo) e->volk_gain = on != 0;
     return 0;
 }
@@ -1110,6 +1217,9 @@ int qdsp_hip_chan_cf32_reset(void* h) {
     Chan* c = as_chan(h);
     if (!c) return QDSP_HIP_EINVAL;
     for (Engine* e : c->vfo) { int rc = reset(e); if (rc) return rc; }
+    HIPCHK(hipSetDevice(c->device));
+    for (int i = 0; i < 2; i++)
+        if (c->d_hist[i]) HIPCHK(hipMemset(c->d_hist[i], 0, (size_t)c->ntaps * sizeof(float2)));
     return 0;
 }
 int qdsp_hip_chan_cf32_channels(void* h) {
@@ -1134,6 +1244,13 @@ int qdsp_hip_synth_iq_dev(int device, void* d_out, int64_t first_sample, int64_t
 }
 
 int qdsp_hip_last_kernel(void* h, char* name, int name_len, int* grid, int* block, int* lds) {
+    if (Chan* c = as_chan(h)) {
+        if (name && name_len > 0) { strncpy(name, c->last.name, name_len - 1); name[name_len - 1] = 0; }
+        if (grid) *grid = c->last.grid;
+        if (block) *block = c->last.block;
+        if (lds) *lds = c->last.lds;
+        return 0;
+    }
     Engine* e = any_engine(h);
     if (!e) return QDSP_HIP_EINVAL;
     if (name && name_len > 0) { strncpy(name, e->last.name, name_len - 1); name[name_len - 1] = 0; }

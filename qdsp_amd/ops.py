@@ -318,6 +318,24 @@ class Channelizer:
     def out_size(self, n: int) -> int:
         return int(capi.check(self._L.qdsp_hip_chan_cf32_out_size(self._h, n)))
 
+    def last_kernel(self):
+        name = C.create_string_buffer(128)
+        g, b, l = C.c_int(), C.c_int(), C.c_int()
+        capi.check(self._L.qdsp_hip_last_kernel(self._h, name, 128, C.byref(g), C.byref(b), C.byref(l)))
+        return {"name": name.value.decode(), "grid": g.value, "block": b.value, "lds_bytes": l.value}
+
+    def time_dev(self, x, out, iters: int) -> float:
+        """Mean ms per process_dev over `iters` calls (torch events on the current stream)."""
+        import torch
+
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            self.process(x, out)
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / iters
+
     def process(self, x, out=None):
         if _is_torch(x):
             import torch

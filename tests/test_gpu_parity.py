@@ -472,28 +472,60 @@ def test_full_size_properties(ops, gold):
 @pytest.mark.parametrize("dec", [8, 64])
 def test_channelizer_64_channels(ops, gold, dec):
     """64 frequency-translating decimators on one stream == Splitter -> 64 x VFO
-    (src/dsp/routing.h:47-57 + src/dsp/vfo.h): offsets (c - 31.5) fs/64, 256 taps."""
+    (src/dsp/routing.h:47-57 + src/dsp/vfo.h): offsets (c - 31.5) fs/64, 256 taps.
+    decim 64 takes the uniform polyphase + 64-point-DFT kernel (chan.hip); decim 8 runs one
+    fused VFO kernel per channel.  Tolerances: per-channel path 2e-6; polyphase path 4e-6 (its
+    per-channel NCO deviation / VOLK gain are applied at the centre of the tap window)."""
+    import torch
+
     taps = gold["taps256"]
     nch, fs = 64, 1.0
-    n = 131_072 if dec == 8 else 65_536
+    n = 131_072 if dec == 8 else 1 << 20
     x = O.synth_iq(0, n, seed=64 + dec)
     offs = [(c - 31.5) * fs / nch for c in range(nch)]
     incs = [ops.phase_delta(fs, -f) for f in offs]          # VFO: xlator(-offset), vfo.h:28
-    ch = ops.Channelizer(taps, 1, dec, incs)
-    sizes = [n // 2, n // 2]
-    ys = [np.array(ch.process(x[:sizes[0]])), np.array(ch.process(x[sizes[0]:]))]   # host-pointer path, 2 calls
+    ch = ops.Channelizer(taps, 1, dec, incs, max_block=n)
+    cuts = [0, n // 2 + 64 * 7, n]                           # two calls, history + 64 NCO phases carried
+    ys = [np.array(ch.process(x[a:b])) for a, b in zip(cuts, cuts[1:])]
     y = np.concatenate(ys, axis=1)
+    fast = ch.last_kernel()["name"] == "chan_uniform_kernel"
+    assert fast == (dec == 64)
     assert y.shape == (nch, n // dec)
+    tol = 4e-6 if fast else 2e-6
+    worst = 0.0
     for c in (0, 1, 17, 31, 32, 63):
         xl = O.Xlator(fs, -offs[c], exact=True, volk_gain=True)
         rs = O.Resampler(taps, 1, dec, acc=O.ACC_F64)
-        want = np.concatenate([rs.process(xl.process(x[:sizes[0]])), rs.process(xl.process(x[sizes[0]:]))])
-        assert rel_rms(y[c], want) < 2e-6, c
-    # device path, one call, same numbers as the per-channel fused operator
-    import torch
-
-    ch2 = ops.Channelizer(taps, 1, dec, incs)
+        want = np.concatenate([rs.process(xl.process(x[a:b])) for a, b in zip(cuts, cuts[1:])])
+        e = rel_rms(y[c], want)
+        worst = max(worst, e)
+        assert e < tol, (c, e)
+        # and inside the north_star bar against the reference's own recursive float phasor
+        g = O.Xlator(fs, -offs[c])
+        rg = O.Resampler(taps, 1, dec)
+        wg = np.concatenate([rg.process(g.process(x[a:b])) for a, b in zip(cuts, cuts[1:])])
+        assert rel_rms(y[c][: 65_536 // dec], wg[: 65_536 // dec]) < TOL_RMS, c
+    # device path in one call; the polyphase kernel against the per-channel kernels
+    ch2 = ops.Channelizer(taps, 1, dec, incs, max_block=0)
     yd = ch2.process(dev(x)).cpu().numpy()
-    v = ops.Vfo(taps, 1, dec, incs[17])
-    assert np.array_equal(yd[17], np.array(v.process(x)))
+    ch3 = ops.Channelizer(taps, 1, dec, incs, max_block=0)
+    ch3.set_mode(ch3.DIRECT)
+    y3 = ch3.process(dev(x[: n // 4])).cpu().numpy()
+    assert ch3.last_kernel()["name"] != "chan_uniform_kernel"
+    for c in range(0, nch, 7):
+        assert rel_rms(yd[c][: y3.shape[1]], y3[c]) < 2 * tol, c
     torch.cuda.synchronize()
+
+
+def test_channelizer_non_uniform_plan_falls_back(ops, gold):
+    """Arbitrary offsets (or another decimation) are served by one fused kernel per channel."""
+    taps = gold["taps256"]
+    n = 65_536
+    x = O.synth_iq(0, n, seed=9)
+    incs = [ops.phase_delta(1.0, f) for f in (0.01, -0.2, 0.3333, 0.125)]
+    ch = ops.Channelizer(taps, 1, 64, incs, max_block=n)
+    y = np.array(ch.process(x))
+    assert ch.last_kernel()["name"] != "chan_uniform_kernel" and y.shape == (4, n // 64)
+    for c, f in enumerate((0.01, -0.2, 0.3333, 0.125)):
+        want = O.Resampler(taps, 1, 64, acc=O.ACC_F64).process(O.Xlator(1.0, f, exact=True, volk_gain=True).process(x))
+        assert rel_rms(y[c], want) < 2e-6
