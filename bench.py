@@ -51,6 +51,8 @@ WORKLOADS = {
     "decim8": dict(ntaps=256, decim=8, rot=False, bytes=9.0, flops=128.0),
     "xlate_fir_decim8": dict(ntaps=256, decim=8, rot=True, bytes=9.0, flops=134.0),
     "xlate": dict(ntaps=0, decim=1, rot=True, bytes=16.0, flops=6.0),
+    # BASELINE configs[4]: 64 channels at (c - 31.5) fs/64, 256 taps, decimate 64: 8 B in + 64*8/64 B out
+    "chan64": dict(ntaps=256, decim=64, rot=True, bytes=16.0, flops=1408.0, nchan=64),
 }
 
 
@@ -71,6 +73,9 @@ def make_op(ops, name: str, device: int):
     w = WORKLOADS[name]
     if name == "xlate":
         return ops.Xlator(phase_inc=ops.phase_delta(1.0, 0.1234), device=device, max_block=0)
+    if name == "chan64":
+        incs = [ops.phase_delta(1.0, -(c - 31.5) / 64.0) for c in range(64)]
+        return ops.Channelizer(lowpass_taps(256, 1.0 / 128.0), 1, 64, incs, device=device, max_block=0)
     taps = lowpass_taps(w["ntaps"], 1.0 / 16.0) if w["ntaps"] != 63 else None
     if taps is None:
         import numpy as np
@@ -205,7 +210,10 @@ def main():
     w = WORKLOADS[args.workload]
     n = 1 << args.log2n
     op = make_op(ops, args.workload, local_rank)
-    has_hist = args.workload != "xlate"
+    is_chan = args.workload == "chan64"
+    if is_chan and world > 1:
+        raise SystemExit("workload chan64 is single-GPU in this round (time-sharding it needs a halo entry point for the shared history)")
+    has_hist = args.workload != "xlate" and not is_chan
     H = op.history_len if has_hist else 0
 
     # Block-cyclic cut of one continuous stream: step s, rank r owns samples
@@ -213,7 +221,7 @@ def main():
     # so the halo a rank needs is always its ring predecessor's current tail.
     x = ops.synth_iq(n, first_sample=rank * n, seed=1234, device=local_rank)
     nout = n // w["decim"]
-    out = torch.empty(nout, dtype=torch.complex64, device=dev)
+    out = torch.empty((w["nchan"], nout) if is_chan else nout, dtype=torch.complex64, device=dev)
     tail = x[n - H:] if H else None
     halo = torch.zeros(max(H, 1), dtype=torch.complex64, device=dev)   # RCCL recv lands here ...
     set_hist = getattr(capi_mod.load(), op._prefix + "_set_history_dev") if H else None
@@ -225,9 +233,15 @@ def main():
 
     capi = capi_mod
 
-    fn = getattr(capi.load(), op._prefix + "_process_dev")
     h, xin, yout = op._h, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr())
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    if is_chan:
+        _chan_fn = capi.load().qdsp_hip_chan_cf32_process_dev
+
+        def fn(h_, xin_, n_, yout_, stream_):
+            return _chan_fn(h_, xin_, n_, yout_, nout, stream_)
+    else:
+        fn = getattr(capi.load(), op._prefix + "_process_dev")
 
     def step():
         if world > 1 and H:
@@ -268,7 +282,7 @@ def main():
             if rc < 0:
                 capi.check(int(rc), "process_dev")
             torch.cuda.synchronize()
-        if has_hist:
+        if has_hist or is_chan:
             op.reset()
         if args.workload in ("xlate", "xlate_fir_decim8"):
             op.set_phase(1.0, 0.0)
@@ -359,6 +373,7 @@ def main():
                     "decim8": "256-tap polyphase decimate-by-8, synthetic IQ",
                     "xlate_fir_decim8": "fused NCO + 256-tap FIR + decimate-by-8 (BASELINE configs[2])",
                     "xlate": "NCO frequency translator alone",
+                    "chan64": "64-channel polyphase channelizer, 256 taps, decimate 64 (BASELINE configs[4])",
                 }[args.workload],
                 "name": args.workload,
                 "samples_per_gpu_per_step": n,
