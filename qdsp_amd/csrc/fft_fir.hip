@@ -9,6 +9,10 @@
 //   * the hybrid -- vector-typed add/sub (hipcc emits v_pk_add_f32 itself, no asm) with scalar
 //     multiply-by-j and product forms: 1100 VALU ops per segment but 12 spilled VGPRs and 136
 //     extra v_mov: 0.54 ms;
+//   * two segments per workgroup with every value held as a (segment A, segment B) 2-vector, so
+//     hipcc emits v_pk_add/mul/fma_f32 natively (1258 packed ops per TWO segments, no asm):
+//     235 VGPRs -> 2 waves/SIMD, 74 KB LDS; numerically identical, 0.48 ms vs 0.45 ms -- the
+//     eight barriers per pass are exposed at that occupancy;
 //   * non-temporal loads/stores for the sample stream: +-1 %;
 //   * pruning the inverse inside one segment for decimators (256/DEC active lanes): no faster
 //     than the full inverse -> the grouped kernel below.

@@ -52,7 +52,5 @@ struct FftArgs {
 
 // Defined in fft_fir.hip (its own translation unit: built with -fno-slp-vectorize, see there).
 int launch_fir_fft(const FftArgs& a, int grid, hipStream_t stream);
-// Defined in fft_fir2.hip: the two-segments-per-workgroup form of the DEC == 1 kernel.
-int launch_fir_fft2(const FftArgs& a, int grid, hipStream_t stream);
 
 }  // namespace qk

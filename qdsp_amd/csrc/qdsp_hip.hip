@@ -425,10 +425,8 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
     // FIR: 4 workgroups resident per CU (124 VGPRs, 37 KB LDS), 16 queued per CU for balance.
     // Decimators work in groups of `dec` segments, 2 resident per CU (70 KB LDS).
     const bool grouped = a.dec >= 4;
-    // FIR: two segments per workgroup, values packed (segment A, segment B) -> v_pk_* math
-    const bool dual = a.dec == 1 && env_int("QDSP_HIP_FFT_DUAL", 1) != 0;
-    const int per_cu = env_int("QDSP_HIP_FFT_WG_PER_CU", grouped ? 4 : (dual ? 8 : 16));
-    const int units = grouped ? (a.nblocks + a.dec - 1) / a.dec : (dual ? (a.nblocks + 1) / 2 : a.nblocks);
+    const int per_cu = env_int("QDSP_HIP_FFT_WG_PER_CU", grouped ? 4 : 16);
+    const int units = grouped ? (a.nblocks + a.dec - 1) / a.dec : a.nblocks;
     int nwg = 256 * per_cu;
     if (nwg > units) nwg = units;
     a.nwg = nwg;
@@ -445,12 +443,12 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
             a.wtab[n2] = make_float2((float)c, (float)sn);
         }
     }
-    rc = dual ? qk::launch_fir_fft2(a, nwg + 1, s) : qk::launch_fir_fft(a, nwg + 1, s);
+    rc = qk::launch_fir_fft(a, nwg + 1, s);
     if (rc) return rc;
-    e->last.name = dual ? "fir_fft2_kernel" : "fir_fft_kernel";
+    e->last.name = "fir_fft_kernel";
     e->last.grid = nwg + 1;
     e->last.block = qk::kFftNT;
-    e->last.lds = (int)(((grouped || dual ? 2 : 1) * qk::kFftLdsElems + 16 * 17) * sizeof(float2));
+    e->last.lds = (int)(((grouped ? 2 : 1) * qk::kFftLdsElems + 16 * 17) * sizeof(float2));
     return 0;
 }
 
