@@ -13,6 +13,8 @@
 //     hipcc emits v_pk_add/mul/fma_f32 natively (1258 packed ops per TWO segments, no asm):
 //     235 VGPRs -> 2 waves/SIMD, 74 KB LDS; numerically identical, 0.48 ms vs 0.45 ms -- the
 //     eight barriers per pass are exposed at that occupancy;
+//   * 16-byte loads by lane pairs (as fir_fft_kernel does) in the grouped decimator kernel, with
+//     segments moved to even starts: 248 VGPRs, decim-8 0.36 ms vs 0.33 ms with 8-byte loads;
 //   * non-temporal loads/stores for the sample stream: +-1 %;
 //   * pruning the inverse inside one segment for decimators (256/DEC active lanes): no faster
 //     than the full inverse -> the grouped kernel below.
