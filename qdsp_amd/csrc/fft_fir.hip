@@ -41,10 +41,10 @@ __host__ __device__ constexpr int pos1(int e) { return (e >> 1) + 136 * (e & 1);
 //                                         y[n'] = sum_k taps[k] s[n'*DEC - P + k]
 //   ROT      : FrequencyXlator applied to `in` while loading (the fused VFO)
 // s = hist ++ in.  Segment b starts at stream position b*L - seg_shift; its elements
-// i >= ov are valid filter outputs (position p = seg0 + i).  For DEC > 1 the segments start on
-// multiples of DEC (so they stay 16-byte aligned), which puts the wanted positions
-// (p == -1 mod DEC) on the elements with i == DEC-1 mod DEC, i.e. the last radix-16 digit
-// n0 == DEC-1 (mod DEC): the inverse transform keeps only those 16/DEC values of n0.
+// i >= ov are valid filter outputs (position p = seg0 + i).  For DEC > 1 the segments are
+// placed so that the wanted positions (p == -1 mod DEC) are the elements with i == 0 mod DEC,
+// i.e. the last radix-16 digit n0 is a multiple of DEC: the inverse transform keeps only
+// those 16/DEC values of n0, and passes B'/A' run on 256/DEC lanes.
 template <int DEC, bool ROT>
 __global__ __launch_bounds__(kFftNT, DEC == 1 ? 4 : 3) void fir_fft_kernel(const FftArgs a) {
     __shared__ __attribute__((aligned(16))) float2 lds[kFftLdsElems + 16 * 17];
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(kFftNT, DEC == 1 ? 4 : 3) void fir_fft_kernel(const
     const int te = (t & ~63) | ((t & 31) << 1) | ((t >> 5) & 1);
     const int half = (t >> 5) & 1;
     const int pte = pos1(te);
-    constexpr int NS = 16 / DEC;       // kept values of n0: DEC-1, 2*DEC-1, ...
+    constexpr int NS = 16 / DEC;       // kept values of n0: 0, DEC, 2*DEC, ...
     constexpr int NACT = 256 / DEC;    // lanes active in the pruned inverse passes
 
     if ((int)blockIdx.x == a.nwg) {
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kFftNT, DEC == 1 ? 4 : 3) void fir_fft_kernel(const
     // pass-A' twiddles of the pruned inverse: lane w = n1*NS + s <-> element n1*16 + s*DEC.
     // Re-read from the (L2-resident) table every block by the 256/DEC active lanes instead of
     // living in 32 more VGPRs: keeps the kernel at 128 VGPRs = 4 waves/SIMD without spills.
-    const int e0 = ((t / NS) * 16 + (t % NS) * DEC + DEC - 1) & 255;
+    const int e0 = ((t / NS) * 16 + (t % NS) * DEC) & 255;
     tbl[(t >> 4) * 17 + (t & 15)] = a.TB[t];
     const float2* tb = tbl + lo * 17;
 
@@ -228,8 +228,8 @@ __global__ __launch_bounds__(kFftNT, DEC == 1 ? 4 : 3) void fir_fft_kernel(const
             // lane (k0 = hi, k1 = lo) -> row (k0*NS + s), column k1
 #pragma unroll
             for (int s = 0; s < NS; s++) {
-                const int n0 = s * DEC + DEC - 1;
-                lds[(hi * NS + s) * kFftRow2 + lo] = cmulc<true>(y[rev16(n0)], tb[n0]);
+                const int n0 = s * DEC;
+                lds[(hi * NS + s) * kFftRow2 + lo] = (n0 == 0) ? y[rev16(0)] : cmulc<true>(y[rev16(n0)], tb[n0]);
             }
             __syncthreads();
             if (t < NACT) {  // lane u = k0*NS + s : pass B' over k1
@@ -253,11 +253,11 @@ __global__ __launch_bounds__(kFftNT, DEC == 1 ? 4 : 3) void fir_fft_kernel(const
                     v[k] = (k == 0) ? e : cmulc<true>(e, ta2[k]);
                 }
                 fft16<true>(v);
-                const long long nb = ((long long)b * a.L - a.ov) / DEC - 1;  // n' = (seg0 + i + 1)/DEC
+                const long long nb = ((long long)b * a.L - a.ov) / DEC;  // (b*L + i - ov)/DEC at i = 0
 #pragma unroll
                 for (int n2 = 0; n2 < 16; n2++) {
                     const int i = n2 * 256 + e0;
-                    const long long n = nb + (i + 1) / DEC;
+                    const long long n = nb + i / DEC;
                     if (i >= a.ov && n < a.nout) a.out[n] = v[rev16(n2)];
                 }
             }
@@ -283,10 +283,6 @@ __global__ __launch_bounds__(kFftNT, 2) void fir_fft_dec_kernel(const FftArgs a)
     const int H = a.H;
     constexpr int NS = 16 / DEC;
     constexpr int NACT = 256 / DEC;
-    // 16-byte loads by lane pairs, as in fir_fft_kernel: element owned in pass A, its LDS column
-    const int te = (t & ~63) | ((t & 31) << 1) | ((t >> 5) & 1);
-    const int half = (t >> 5) & 1;
-    const int pte = pos1(te);
 
     if ((int)blockIdx.x == a.nwg) {
         for (int i = t; i < H; i += kFftNT) {
@@ -310,44 +306,33 @@ __global__ __launch_bounds__(kFftNT, 2) void fir_fft_dec_kernel(const FftArgs a)
     // per-lane constants kept in registers: forward twiddles and the lane's spectrum slice; the
     // inverse-pass twiddles (used once per group) are re-read from the L2-resident table
     float2 ta[16], hf[16];
-    // inverse-pass lane w = bb*NACT + n1*NS + s  <->  element e0 = n1*16 + s*DEC + DEC-1 of segment bb
+    // inverse-pass lane w = bb*NACT + n1*NS + s  <->  element e0 = n1*16 + s*DEC of segment bb
     const int wbb = t / NACT, wr = t % NACT;
-    const int e0 = (wr / NS) * 16 + (wr % NS) * DEC + DEC - 1;
+    const int e0 = (wr / NS) * 16 + (wr % NS) * DEC;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         hf[k] = a.Hf[t * 16 + k];
-        ta[k] = a.TA[te * 16 + k];
+        ta[k] = a.TA[t * 16 + k];
     }
     tbl[(t >> 4) * 17 + (t & 15)] = a.TB[t];
     const float2* tb = tbl + lo * 17;
 
     float2 pl = make_float2(1.0f, 0.0f);
     if (ROT) {
-        const double2 p = fx_phasor((unsigned long long)te * a.dphase);
+        const double2 p = fx_phasor((unsigned long long)t * a.dphase);
         pl = make_float2((float)p.x, (float)p.y);
     }
 
     auto load_segment = [&](int b, float2 (&v)[16]) {
         const long long seg0 = (long long)b * a.L - a.seg_shift;
-        const bool interior = b < a.nblocks && seg0 >= 0 && seg0 + kFftN <= a.count;
-        if (interior && a.vec) {
-            const float4* __restrict__ p4 = reinterpret_cast<const float4*>(a.in + seg0 + (te & ~1)) + half * 8 * 128;
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const float4 q4 = p4[r * 128];
-                const auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(q4.x), __float_as_uint(q4.z), false, false);
-                const auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(q4.y), __float_as_uint(q4.w), false, false);
-                v[r] = make_float2(__uint_as_float(sx[0]), __uint_as_float(sy[0]));
-                v[8 + r] = make_float2(__uint_as_float(sx[1]), __uint_as_float(sy[1]));
-            }
-        } else if (interior) {
-            const float2* __restrict__ p = a.in + seg0 + te;
+        if (b < a.nblocks && seg0 >= 0 && seg0 + kFftN <= a.count) {
+            const float2* __restrict__ p = a.in + seg0 + t;
 #pragma unroll
             for (int n2 = 0; n2 < 16; n2++) v[n2] = p[n2 * 256];
         } else {
 #pragma unroll
             for (int n2 = 0; n2 < 16; n2++) {
-                const long long g = seg0 + n2 * 256 + te;
+                const long long g = seg0 + n2 * 256 + t;
                 float2 x = make_float2(0.0f, 0.0f);
                 if (b < a.nblocks) {
                     if (g < 0) { if (g + H >= 0) x = a.hist[g + H]; }
@@ -377,7 +362,7 @@ __global__ __launch_bounds__(kFftNT, 2) void fir_fft_dec_kernel(const FftArgs a)
                 pb = dcmul(pb, a.rot_step);
 #pragma unroll
                 for (int n2 = 0; n2 < 16; n2++) {
-                    const long long g = seg0 + n2 * 256 + te;
+                    const long long g = seg0 + n2 * 256 + t;
                     const float gain = fmaf((float)(int)(g & 511), a.gm1, 1.0f);
                     float2 ph = (n2 == 0) ? q : cmulc<false>(q, a.wtab[n2]);
                     ph = make_float2(ph.x * gain, ph.y * gain);
@@ -388,11 +373,11 @@ __global__ __launch_bounds__(kFftNT, 2) void fir_fft_dec_kernel(const FftArgs a)
             fft16<false>(v);
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 16; k++) lds[k * kFftRow1 + pte] = (k == 0) ? v[rev16(0)] : cmulc<false>(v[rev16(k)], ta[k]);
+            for (int k = 0; k < 16; k++) lds[k * kFftRow1 + t] = (k == 0) ? v[rev16(0)] : cmulc<false>(v[rev16(k)], ta[k]);
             if (bb + 1 < DEC) load_segment(b + 1, vn);   // prefetch: lands during passes B and C
             __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 16; j++) v[j] = lds[hi * kFftRow1 + pos1(j * 16 + lo)];
+            for (int j = 0; j < 16; j++) v[j] = lds[hi * kFftRow1 + j * 16 + lo];
             // ---- pass B + twiddle ----------------------------------------------------------
             fft16<false>(v);
             __syncthreads();
@@ -411,8 +396,8 @@ __global__ __launch_bounds__(kFftNT, 2) void fir_fft_dec_kernel(const FftArgs a)
             // staging is only read after the group's last segment (barrier below): no hazard here
 #pragma unroll
             for (int s = 0; s < NS; s++) {
-                const int n0 = s * DEC + DEC - 1;
-                stage[(bb * NACT + hi * NS + s) * kFftRow2 + lo] = cmulc<true>(y[rev16(n0)], tb[n0]);
+                const int n0 = s * DEC;
+                stage[(bb * NACT + hi * NS + s) * kFftRow2 + lo] = (n0 == 0) ? y[rev16(0)] : cmulc<true>(y[rev16(n0)], tb[n0]);
             }
             if (bb + 1 < DEC) {
 #pragma unroll
@@ -443,11 +428,11 @@ __global__ __launch_bounds__(kFftNT, 2) void fir_fft_dec_kernel(const FftArgs a)
         }
         fft16<true>(v);
         const int b = b0 + wbb;
-        const long long nb = ((long long)b * a.L - a.ov) / DEC - 1;  // n' = (seg0 + i + 1)/DEC (ov, L multiples of DEC)
+        const long long nb = ((long long)b * a.L - a.ov) / DEC;  // (b*L + i - ov)/DEC at i = 0 (ov, L multiples of DEC)
 #pragma unroll
         for (int n2 = 0; n2 < 16; n2++) {
             const int i = n2 * 256 + e0;
-            const long long n = nb + (i + 1) / DEC;
+            const long long n = nb + i / DEC;
             if (b < a.nblocks && i >= a.ov && n < a.nout) a.out[n] = v[rev16(n2)];
         }
         // next group's pass-A write to `lds` is behind that group's first barrier; its staging

@@ -415,12 +415,9 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
         a.L = qk::kFftN - a.ov;
         a.nblocks = (int)((count + a.L - 1) / a.L);
     } else {
-        // resampler: y[n'] sits at stream position n'*dec - 1.  Segments start dec samples before
-        // their first valid position, on multiples of dec (16-byte aligned): the wanted positions
-        // are then the elements i == dec-1 (mod dec).
+        // resampler: y[n'] sits at stream position n'*dec - 1; segments start one sample early
         a.ov = ((e->ntaps - 1 + a.dec - 1) / a.dec) * a.dec;
-        a.seg_shift = a.ov + a.dec;
-        a.vec = (((uintptr_t)d_in) & 15) == 0 && !env_int("QDSP_HIP_FFT_NOVEC", 0);
+        a.seg_shift = a.ov + 1;
         a.L = qk::kFftN - a.ov;
         const int per_block = a.L / a.dec;
         a.nblocks = (int)((nout + per_block - 1) / per_block);
