@@ -19,8 +19,8 @@ import sys
 
 
 def load(pattern):
-    f = glob.glob(pattern)
-    return list(csv.DictReader(open(f[0]))) if f else []
+    f = sorted(glob.glob(pattern), key=os.path.getmtime)   # the newest run if several were merged
+    return list(csv.DictReader(open(f[-1]))) if f else []
 
 
 def main():
@@ -77,9 +77,9 @@ def main():
         json.dump(summary, f, indent=1)
     # copy the raw stats CSVs next to it (small)
     for src, dst in ((os.path.join(prof, "trace", "*", "*_kernel_stats.csv"), f"{tag}_{workload}_kernel_stats.csv"),):
-        g = glob.glob(src)
+        g = sorted(glob.glob(src), key=os.path.getmtime)
         if g:
-            open(os.path.join(out_dir, dst), "w").write(open(g[0]).read())
+            open(os.path.join(out_dir, dst), "w").write(open(g[-1]).read())
     if traffic is not None:
         tj = os.path.join(out_dir, "traffic.json")
         d = json.load(open(tj)) if os.path.exists(tj) else {}
