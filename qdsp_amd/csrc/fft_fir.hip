@@ -46,7 +46,7 @@ __host__ __device__ constexpr int pos1(int e) { return (e >> 1) + 136 * (e & 1);
 // i.e. the last radix-16 digit n0 is a multiple of DEC: the inverse transform keeps only
 // those 16/DEC values of n0, and passes B'/A' run on 256/DEC lanes.
 template <int DEC, bool ROT>
-__global__ __launch_bounds__(kFftNT, DEC == 1 ? 4 : 3) void fir_fft_kernel(const FftArgs a) {
+__global__ __launch_bounds__(kFftNT, (DEC == 1 && !ROT) ? 4 : 3) void fir_fft_kernel(const FftArgs a) {
     __shared__ __attribute__((aligned(16))) float2 lds[kFftLdsElems + 16 * 17];
     float2* tbl = lds + kFftLdsElems;  // pass-B twiddles W256^(lo*k), rows padded to 17
     const int t = threadIdx.x;
@@ -201,7 +201,16 @@ __global__ __launch_bounds__(kFftNT, DEC == 1 ? 4 : 3) void fir_fft_kernel(const
             // ---- pass A' (over k0) and store the L valid outputs --------------------------
             fft16<true>(v);
             const long long o0 = seg0 + te;  // output index == stream position (element n2*256 + te)
-            if (interior && a.vec) {
+            if (a.decm > 1) {
+                // Any integer decimation: the full inverse ran; keep the positions p == -1 (mod decm)
+                // (y[n'] sits at stream position n'*decm - 1) -- strided 8-byte stores, 1/decm of them.
+#pragma unroll
+                for (int n2 = 0; n2 < 16; n2++) {
+                    const long long p1 = o0 + n2 * 256 + 1;
+                    const long long n = p1 / a.decm;
+                    if (n2 * 256 + te >= a.ov && p1 - n * a.decm == 0 && n < a.nout) a.out[n] = v[rev16(n2)];
+                }
+            } else if (interior && a.vec) {
                 float4* __restrict__ o4 = reinterpret_cast<float4*>(a.out + seg0 + (te & ~1)) + half * 8 * 128;
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
@@ -444,9 +453,9 @@ int launch_fir_fft(const FftArgs& a, int grid, hipStream_t stream) {
 #define QK_FFT(dec, rot) hipLaunchKernelGGL((fir_fft_dec_kernel<dec, rot>), dim3(grid), dim3(kFftNT), 0, stream, a)
     const bool r = a.rot != 0;
     switch (a.dec) {
-        case 1:
-            if (r) return -1;
-            hipLaunchKernelGGL((fir_fft_kernel<1, false>), dim3(grid), dim3(kFftNT), 0, stream, a);
+        case 1:  // FIR, or any-decimation resampler / VFO through the strided store (a.decm)
+            if (r) hipLaunchKernelGGL((fir_fft_kernel<1, true>), dim3(grid), dim3(kFftNT), 0, stream, a);
+            else hipLaunchKernelGGL((fir_fft_kernel<1, false>), dim3(grid), dim3(kFftNT), 0, stream, a);
             break;
         case 2:  // half the outputs are kept: the per-segment pruned inverse (128 active lanes) is enough
             if (r) hipLaunchKernelGGL((fir_fft_kernel<2, true>), dim3(grid), dim3(kFftNT), 0, stream, a);

@@ -35,7 +35,8 @@ struct FftArgs {
     long long count;          // input samples of this call
     long long nout;           // outputs of this call
     int H;                    // history length (ntaps-1 for the FIR, taps per phase for the resampler)
-    int dec;                  // 1, 2, 4, 8, 16
+    int dec;                  // 1, 2, 4, 8, 16: decimation handled by pruning the inverse transform
+    int decm;                 // dec == 1 only: keep every decm-th output of the full inverse (1 = FIR)
     int rot;                  // 1: rotate `in` by the NCO while loading
     int ov;                   // leading invalid elements of a segment (multiple of dec)
     int seg_shift;            // segment b starts at stream position b*L - seg_shift

@@ -332,12 +332,14 @@ template <int CH, bool ROT> int launch_any(Engine* e, qk::AnyArgs& a, hipStream_
 // ---- overlap-save FFT FIR -------------------------------------------------------------------
 constexpr int kFftMaxTaps = 2049;   // keeps >= 2048 valid outputs per 4096-point block
 
-// DEC the overlap-save kernel would run with for this engine, 0 if it cannot.
+// DEC the overlap-save kernel would run with for this engine, 0 if it cannot: 1 = full inverse
+// (the FIR, and any other integer decimation through a strided store), 2/4/8/16 = pruned inverse.
 int fft_dec(const Engine* e) {
     if (e->ch != 2 || e->L != 1 || e->ntaps < 2 || e->ntaps > kFftMaxTaps) return 0;
     if (e->kind == KIND_FIR) return 1;
     if (e->kind == KIND_DECIM || e->kind == KIND_VFO) {
         if (e->M == 2 || e->M == 4 || e->M == 8 || e->M == 16) return e->M;
+        if (e->M >= 3) return 1;
     }
     return 0;
 }
@@ -408,7 +410,17 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
     a.H = e->H;
     a.dec = fft_dec(e);
     a.rot = e->rotate ? 1 : 0;
-    if (a.dec == 1) {
+    a.decm = 1;
+    if (a.dec == 1 && e->kind != KIND_FIR) {
+        // any-decimation resampler / VFO: y[n'] sits at stream position n'*M - 1.  Even overlap and
+        // an even segment start (two samples before the first valid position) keep 16-byte loads.
+        a.decm = e->M;
+        a.ov = (e->ntaps - 1 + 1) & ~1;
+        a.seg_shift = a.ov + 2;
+        a.L = qk::kFftN - a.ov;
+        a.nblocks = (int)((count + 2 + a.L - 1) / a.L);
+        a.vec = (((uintptr_t)d_in) & 15) == 0 && !env_int("QDSP_HIP_FFT_NOVEC", 0);
+    } else if (a.dec == 1) {
         a.ov = (e->ntaps - 1 + 1) & ~1;   // FIR: out index == stream position; even so segments stay 16-byte aligned
         a.vec = ((((uintptr_t)d_in) | ((uintptr_t)d_out)) & 15) == 0 && !env_int("QDSP_HIP_FFT_NOVEC", 0);
         a.seg_shift = a.ov;

@@ -43,6 +43,18 @@ def main():
                 print(f"{name} R={r} NT={nt}: {e}", flush=True)
     os.environ.pop("QDSP_HIP_R", None)
     os.environ.pop("QDSP_HIP_NT", None)
+    # any-decimation VFO (the reference's typical 2.4 MHz -> 240 kHz): direct vs overlap-save + strided store
+    for (dec, ntaps) in ((10, 97), (10, 256), (3, 63), (5, 128), (2, 256), (64, 256)):
+        taps = bench.lowpass_taps(ntaps, 0.4 / dec)
+        out = torch.empty(n // dec + 1, dtype=torch.complex64, device="cuda")
+        for mode in (1, 2):
+            op = ops.Vfo(taps, 1, dec, ops.phase_delta(1.0, 0.1234), max_block=0)
+            op.set_mode(mode)
+            op.process(x, out)
+            torch.cuda.synchronize()
+            ms = min(op.time_dev(x, out, 10) for _ in range(3))
+            print(f"vfo dec={dec:3d} ntaps={ntaps:4d} mode={'direct' if mode == 1 else 'fft':6s} {op.last_kernel()['name']:18s} {ms:8.4f} ms {n / ms / 1e6:8.1f} Gs/s", flush=True)
+            op.close()
     # decimators: direct form vs overlap-save with pruned inverse
     for name in ("decim8", "xlate_fir_decim8"):
         w = bench.WORKLOADS[name]

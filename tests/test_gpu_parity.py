@@ -270,6 +270,32 @@ def test_fft_decimator_vs_oracle(ops, dec, ntaps):
     assert rel_rms(y, run_blocks(d, x, sizes)) < TOL_FFT
 
 
+@pytest.mark.parametrize("dec", [3, 5, 10, 17, 64])
+@pytest.mark.parametrize("ntaps", [97, 256])
+def test_fft_any_decimation_vs_oracle(ops, dec, ntaps):
+    """Decimations outside {2,4,8,16}: full inverse + strided store (resampler and fused VFO)."""
+    rng = np.random.default_rng(dec * 100 + ntaps)
+    taps = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    n = 70_000
+    x = O.synth_iq(0, n, seed=dec)
+    sizes = [30_001, 4, 39_995]
+    r = ops.Resampler(taps, 1, dec)
+    r.set_mode(r.FFT)
+    y = run_blocks(r, x, sizes)
+    assert r.last_kernel()["name"] == "fir_fft_kernel"
+    want = run_blocks(O.Resampler(taps, 1, dec, acc=O.ACC_F64), x, sizes)
+    assert len(y) == len(want) and rel_rms(y, want) < TOL_FFT
+    assert np.array_equal(r.get_history(), x[n - ntaps:])
+    inc = ops.phase_delta(1.0, -0.0777)
+    v = ops.Vfo(taps, 1, dec, inc)
+    v.set_mode(v.FFT)
+    yv = run_blocks(v, x, sizes)
+    assert v.last_kernel()["name"] == "fir_fft_kernel"
+    xl, rs = O.Xlator(1.0, -0.0777, exact=True, volk_gain=True), O.Resampler(taps, 1, dec, acc=O.ACC_F64)
+    wv = np.concatenate([rs.process(xl.process(x[a:b])) for a, b in ((0, 30_001), (30_001, 30_005), (30_005, n))])
+    assert len(yv) == len(wv) and rel_rms(yv, wv) < TOL_FFT
+
+
 @pytest.mark.parametrize("dec", [2, 8, 16])
 def test_fft_fused_vfo_vs_oracle(ops, gold, dec):
     """NCO applied while loading the segment + overlap-save decimator, vs xlator -> resampler."""
