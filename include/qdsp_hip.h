@@ -147,9 +147,10 @@ int qdsp_hip_decim_cf32_process_ex(void* h, const void* in, int in_on_device, in
 /* updateWindow / setInSampleRate / setOutSampleRate (resampling.h:53-93) all funnel here. */
 int qdsp_hip_decim_cf32_configure(void* h, const float* taps, int ntaps, int interp, int decim);
 int64_t qdsp_hip_decim_cf32_out_size(void* h, int64_t count); /* calcOutSize, :95-97 */
-/* QDSP_HIP_FIR_AUTO / _DIRECT / _FFT as for the FIR.  The overlap-save path serves
- * interp == 1 with decim in {2, 4, 8, 16} (pruned inverse transform); everything else is
- * direct form whatever the mode. */
+/* QDSP_HIP_FIR_AUTO / _DIRECT / _FFT as for the FIR.  The overlap-save path serves interp == 1
+ * with any decimation >= 2 (decim in {2, 4, 8, 16}: pruned inverse transform; others: full
+ * inverse, every decim-th output stored); AUTO takes it from 64 taps on calls of >= 65536
+ * samples.  interp > 1 is direct form whatever the mode. */
 int qdsp_hip_decim_cf32_set_mode(void* h, int mode);
 int qdsp_hip_decim_cf32_reset(void* h);
 int qdsp_hip_decim_cf32_history_len(void* h); /* = taps per phase */

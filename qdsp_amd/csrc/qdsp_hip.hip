@@ -350,7 +350,10 @@ bool fft_eligible(const Engine* e, int64_t count) {
     if (mode == 1) return false;
     if (mode == 2) return true;
     // auto: long filters on calls big enough to fill the chip with 4096-point segments
-    return e->ntaps >= env_int("QDSP_HIP_FFT_MIN_TAPS", 24) * (e->M > 1 ? e->M / 2 : 1) && count >= env_int("QDSP_HIP_FFT_MIN_COUNT", 1 << 16);
+    // (measured crossovers, 2^27 samples: FIR from ~24 taps; decimators / VFO from ~64 taps whatever
+    // the decimation -- scripts/tune.py)
+    const int min_taps = e->M > 1 ? env_int("QDSP_HIP_FFT_MIN_TAPS_DECIM", 64) : env_int("QDSP_HIP_FFT_MIN_TAPS", 24);
+    return e->ntaps >= min_taps && count >= env_int("QDSP_HIP_FFT_MIN_COUNT", 1 << 16);
 }
 
 int fft_prepare(Engine* e) {
