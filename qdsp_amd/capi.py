@@ -36,6 +36,16 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(LIB_PATH) and os.environ.get("QDSP_HIP_NO_AUTOBUILD", "0") != "1":
+        # a fresh checkout (the .so is git-ignored): compile it once with hipcc -- this builds the
+        # product itself, it is not a fallback path
+        import shutil
+        import subprocess
+
+        hipcc = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        if os.path.exists(hipcc):
+            subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), f"HIPCC={hipcc}"], check=False,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     if not os.path.exists(LIB_PATH):
         raise QdspHipError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
