@@ -106,8 +106,11 @@ int qdsp_hip_fir_cf32_history_len(void* h);
 int qdsp_hip_fir_cf32_get_history(void* h, float* hist_iq);
 int qdsp_hip_fir_cf32_set_history(void* h, const float* hist_iq);
 int qdsp_hip_fir_cf32_history_dev(void* h, void** d_hist);
-/* Copy `history_len` samples from device memory into the history the next call reads,
- * asynchronously on `hip_stream` (e.g. from the buffer an RCCL recv just filled). */
+/* Install the `history_len` INPUT samples that precede the next call (device memory, e.g. the
+ * buffer an RCCL recv of the neighbour's tail just filled), asynchronously on `hip_stream`.
+ * xlate_fir_decim_cf32 keeps its history rotated (as the reference resampler's buffer holds
+ * the xlator's output): it rotates the samples itself, with the NCO phases they would have
+ * had (set / advance the phase first). */
 int qdsp_hip_fir_cf32_set_history_dev(void* h, const void* d_hist, void* hip_stream);
 void qdsp_hip_fir_cf32_destroy(void* h);
 

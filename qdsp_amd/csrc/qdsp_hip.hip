@@ -468,13 +468,17 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
 }
 
 int launch_xlate(Engine* e, const void* d_in, int64_t count, void* d_out, hipStream_t s) {
+    return launch_xlate_raw(e, d_in, count, d_out, e->phase, e->volk_gain ? e->gm1 : 0.0f, s);
+}
+
+int launch_xlate_raw(Engine* e, const void* d_in, int64_t count, void* d_out, unsigned long long phase0, float gm1, hipStream_t s) {
     constexpr int NT = 256;
     if (count <= 0) return 0;
     qk::XlateArgs a;
     a.in = static_cast<const float2*>(d_in);
     a.out = static_cast<float2*>(d_out);
     a.count = count;
-    a.phase0 = e->phase;
+    a.phase0 = phase0;
     a.dphase = e->dphase;
     const long long npairs = (count + 1) / 2;
     long long grid = (npairs + NT - 1) / NT;
@@ -482,7 +486,7 @@ int launch_xlate(Engine* e, const void* d_in, int64_t count, void* d_out, hipStr
     unit_of_fx(e->dphase, 1.0L, &a.rot_one.x, &a.rot_one.y);
     unit_of_fx(e->dphase, (long double)(2 * grid * NT), &a.rot_stride.x, &a.rot_stride.y);
     a.vec = (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0;   // d_in == nullptr (SineSource) counts as aligned
-    a.gm1 = e->volk_gain ? e->gm1 : 0.0f;
+    a.gm1 = gm1;
     hipLaunchKernelGGL((qk::xlate_kernel<NT>), dim3((unsigned)grid), dim3(NT), 0, s, a);
     HIPCHK(hipGetLastError());
     e->last.name = "xlate_kernel";
@@ -615,12 +619,20 @@ int set_history(Engine* e, const float* hist) {
     return 0;
 }
 
+int launch_xlate_raw(Engine* e, const void* d_in, int64_t count, void* d_out, unsigned long long phase0, float gm1, hipStream_t s);
+
+// `d_hist` holds the H INPUT samples that precede the next call.  Engines with an NCO keep
+// their history rotated (as the reference resampler's buffer holds the xlator's output), so
+// those samples are rotated here with the phases they would have had: phase - H*dphase onward.
 int set_history_dev(Engine* e, const void* d_hist, void* stream) {
     if (!d_hist) return QDSP_HIP_EINVAL;
     HIPCHK(hipSetDevice(e->device));
-    if (e->H > 0)
-        HIPCHK(hipMemcpyAsync(e->d_hist[e->cur], d_hist, (size_t)e->H * e->ch * sizeof(float), hipMemcpyDeviceToDevice,
-                              static_cast<hipStream_t>(stream)));
+    if (e->H <= 0) return 0;
+    if (e->rotate && e->has_filter)
+        return launch_xlate_raw(e, d_hist, e->H, e->d_hist[e->cur], e->phase - (unsigned long long)e->H * e->dphase, 0.0f,
+                                static_cast<hipStream_t>(stream));
+    HIPCHK(hipMemcpyAsync(e->d_hist[e->cur], d_hist, (size_t)e->H * e->ch * sizeof(float), hipMemcpyDeviceToDevice,
+                          static_cast<hipStream_t>(stream)));
     return 0;
 }
 

@@ -556,3 +556,26 @@ def test_channelizer_non_uniform_plan_falls_back(ops, gold):
     for c, f in enumerate((0.01, -0.2, 0.3333, 0.125)):
         want = O.Resampler(taps, 1, 64, acc=O.ACC_F64).process(O.Xlator(1.0, f, exact=True, volk_gain=True).process(x))
         assert rel_rms(y[c], want) < 2e-6
+
+
+def test_vfo_set_history_dev_rotates_raw_samples(ops, gold):
+    """Multi-GPU halo for the fused VFO: the neighbour's RAW tail goes in, the engine rotates it
+    with the phases those samples had (set_history_dev on an NCO-bearing handle)."""
+    import torch
+
+    taps = gold["taps256"]
+    n = 200_000
+    x = O.synth_iq(0, n, seed=77)
+    inc = ops.phase_delta(1.0, 0.1234)
+    for dec in (8, 10):
+        whole = ops.Vfo(taps, 1, dec, inc)
+        whole.set_volk_gain(False)
+        y = whole.process(dev(x)).cpu().numpy()
+        cut = 100_000 if dec == 8 else 100_000           # multiple of dec: same output grid
+        second = ops.Vfo(taps, 1, dec, inc)
+        second.set_volk_gain(False)
+        second.advance(cut)                               # chunk start phase: no communication needed
+        second.set_history_dev(dev(x[cut - second.history_len:cut]))
+        y2 = second.process(dev(x[cut:])).cpu().numpy()
+        torch.cuda.synchronize()
+        assert rel_rms(y2, y[cut // dec:]) < 2e-6, dec
