@@ -467,6 +467,8 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
     return 0;
 }
 
+int launch_xlate_raw(Engine* e, const void* d_in, int64_t count, void* d_out, unsigned long long phase0, float gm1, hipStream_t s);
+
 int launch_xlate(Engine* e, const void* d_in, int64_t count, void* d_out, hipStream_t s) {
     return launch_xlate_raw(e, d_in, count, d_out, e->phase, e->volk_gain ? e->gm1 : 0.0f, s);
 }
@@ -618,8 +620,6 @@ int set_history(Engine* e, const float* hist) {
         HIPCHK(hipMemcpy(e->d_hist[e->cur], hist, (size_t)e->H * e->ch * sizeof(float), hipMemcpyHostToDevice));
     return 0;
 }
-
-int launch_xlate_raw(Engine* e, const void* d_in, int64_t count, void* d_out, unsigned long long phase0, float gm1, hipStream_t s);
 
 // `d_hist` holds the H INPUT samples that precede the next call.  Engines with an NCO keep
 // their history rotated (as the reference resampler's buffer holds the xlator's output), so
