@@ -211,9 +211,8 @@ def main():
     n = 1 << args.log2n
     op = make_op(ops, args.workload, local_rank)
     is_chan = args.workload == "chan64"
-    if is_chan and world > 1:
-        raise SystemExit("workload chan64 is single-GPU in this round (time-sharding it needs a halo entry point for the shared history)")
-    has_hist = args.workload != "xlate" and not is_chan
+    has_hist = args.workload != "xlate"
+    has_nco = w["rot"]
     H = op.history_len if has_hist else 0
 
     # Block-cyclic cut of one continuous stream: step s, rank r owns samples
@@ -270,8 +269,17 @@ def main():
         if rc < 0:
             capi.check(int(rc), "process_dev")
 
-    if args.workload in ("xlate", "xlate_fir_decim8") and world > 1:
-        op.advance(rank * n)  # phase of this rank's first sample; each step then advances by n
+    # NCO bookkeeping without communication: `pos` = stream position of this rank's next
+    # chunk; phases are exact multiples of the fixed-point increment, so advance() is exact.
+    pos = rank * n
+    if has_nco and world > 1:
+        op.advance(pos)
+
+    def stepped():
+        nonlocal pos
+        pos += world * n
+        if has_nco and world > 1:
+            op.advance((world - 1) * n)   # the call itself advanced by n
 
     if args.spinup_ms > 0:
         # Time-based, so it must be communication-free (ranks run different counts): the bare
@@ -282,44 +290,41 @@ def main():
             if rc < 0:
                 capi.check(int(rc), "process_dev")
             torch.cuda.synchronize()
-        if has_hist or is_chan:
-            op.reset()
-        if args.workload in ("xlate", "xlate_fir_decim8"):
+        if has_hist:
+            op.reset()                     # zero history, NCO phase 0
+        else:
             op.set_phase(1.0, 0.0)
-            if world > 1:
-                op.advance(rank * n)
+        if has_nco and world > 1:
+            op.advance(pos)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
     dbg("spinup done")
     for _ in range(args.warmup):
         step()
-        if args.workload in ("xlate", "xlate_fir_decim8") and world > 1:
-            op.advance((world - 1) * n)
+        stepped()
     torch.cuda.synchronize()
 
     # Halo check (outside the timed region, no oracle): a fresh operator fed the predecessor's
     # regenerated tail + my head must reproduce my head.
     if world > 1 and H:
-        if w["rot"]:
-            ph_now = op.get_phase()                # phase of the next sample to be processed (start of a chunk)
+        pos_now = pos
         step()
-        if w["rot"]:
-            op.advance((world - 1) * n)
+        stepped()
         torch.cuda.synchronize()
         m = 1 << 16
         prev_tail = ops.synth_iq(H, first_sample=((rank - 1) % world) * n + n - H, seed=1234, device=local_rank)
         chk = make_op(ops, args.workload, local_rank)
-        if w["rot"]:
-            chk.set_phase(ph_now.real, ph_now.imag)
+        if has_nco:
+            chk.advance(pos_now)
         chk.set_history_dev(prev_tail)
         ref = chk.process(x[:m])
         torch.cuda.synchronize()
+        got = out[:, : ref.shape[1]] if is_chan else out[: ref.numel()]
         # (not bit-equal by construction: the short reference call ends in a zero-padded FFT
         # segment where the full chunk has real samples; a wrong halo is an O(1) error)
-        err = (ref - out[: ref.numel()]).abs().max().item()
-        # (the carried NCO phase goes through a float pair in this check: allow its rounding)
-        if not err < (2e-5 if w["rot"] else 2e-6) * max(ref.abs().max().item(), 1e-30):
+        err = (ref - got).abs().max().item()
+        if not err < 2e-6 * max(ref.abs().max().item(), 1e-30):
             raise SystemExit(f"rank {rank}: halo exchange produced different outputs than the unsharded filter (max err {err:.3e})")
         chk.close()
 
@@ -330,8 +335,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        if args.workload in ("xlate", "xlate_fir_decim8") and world > 1:
-            op.advance((world - 1) * n)
+        stepped()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -259,9 +259,9 @@ void qdsp_hip_xlate_fir_decim_cf32_destroy(void* h);
  * xlate_fir_decim_cf32 with phase increment (phase_inc_re[c], phase_inc_im[c]); all channels
  * share taps / interp / decim.  Output is channel-major: channel c's samples start at
  * out + c*out_stride (complex samples).  process* return the per-channel output count.
- * This round runs one fused kernel per channel on the same stream (the input stays in
- * L2 / Infinity Cache across channels); a shared-forward-transform kernel is the planned
- * replacement and will keep this ABI. */
+ * 64 channels spaced 1/64 turn per sample with decim 64 and <= 256 taps run as ONE polyphase
+ * filter-bank kernel (qdsp_amd/csrc/chan.hip); any other plan runs one fused kernel per
+ * channel on the same stream.  set_mode(QDSP_HIP_FIR_DIRECT) forces the per-channel form. */
 int qdsp_hip_chan_cf32_create(void** h, int device, const float* taps, int ntaps, int interp,
                               int decim, int nchan, const float* phase_inc_re,
                               const float* phase_inc_im, int max_block);
@@ -273,6 +273,12 @@ int qdsp_hip_chan_cf32_set_phase_inc(void* h, int chan, float phase_inc_re, floa
 int qdsp_hip_chan_cf32_set_mode(void* h, int mode);
 int qdsp_hip_chan_cf32_set_volk_gain(void* h, int on);
 int qdsp_hip_chan_cf32_reset(void* h);
+/* Time-sharding a stream over GPUs (as for xlate_fir_decim_cf32): history_len raw INPUT
+ * samples that precede the next call, rotated internally with each channel's NCO; advance
+ * moves every channel's NCO by n samples without processing. */
+int qdsp_hip_chan_cf32_history_len(void* h);
+int qdsp_hip_chan_cf32_set_history_dev(void* h, const void* d_hist, void* hip_stream);
+int qdsp_hip_chan_cf32_advance(void* h, int64_t n);
 int qdsp_hip_chan_cf32_channels(void* h);
 void qdsp_hip_chan_cf32_destroy(void* h);
 

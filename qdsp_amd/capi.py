@@ -137,6 +137,9 @@ def load():
     sig(p + "_set_mode", i32, vp, i32)
     sig(p + "_set_volk_gain", i32, vp, i32)
     sig(p + "_reset", i32, vp)
+    sig(p + "_history_len", i32, vp)
+    sig(p + "_set_history_dev", i32, vp, vp, vp)
+    sig(p + "_advance", i32, vp, i64)
     sig(p + "_channels", i32, vp)
     sig(p + "_destroy", None, vp)
     sig("qdsp_hip_synth_iq_dev", i32, i32, vp, i64, i64, C.c_uint32, vp)

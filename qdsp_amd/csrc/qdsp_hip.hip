@@ -733,10 +733,8 @@ bool chan_uniform_plan(const Chan* c, int* inv, long long* ddelta) {
     return false;
 }
 
-int chan_launch_uniform(Chan* c, const void* d_in, int64_t count, int64_t nout, void* d_out, int64_t out_stride, hipStream_t s) {
-    qk::ChanArgs a;
-    memset(&a, 0, sizeof(a));
-    if (!chan_uniform_plan(c, &a.inv, a.ddelta)) return QDSP_HIP_EINVAL;
+// Tables and the shared history of the uniform fast path (allocated on first use).
+int chan_uniform_prepare(Chan* c) {
     const int P = c->ntaps;
     if (!c->d_taps) {
         std::vector<float> tp(256, 0.0f);
@@ -753,6 +751,15 @@ int chan_launch_uniform(Chan* c, const void* d_in, int64_t count, int64_t nout, 
             HIPCHK(hipMemset(c->d_hist[i], 0, (size_t)P * sizeof(float2)));
         }
     }
+    return 0;
+}
+
+int chan_launch_uniform(Chan* c, const void* d_in, int64_t count, int64_t nout, void* d_out, int64_t out_stride, hipStream_t s) {
+    qk::ChanArgs a;
+    memset(&a, 0, sizeof(a));
+    if (!chan_uniform_plan(c, &a.inv, a.ddelta)) return QDSP_HIP_EINVAL;
+    const int P = c->ntaps;
+    { int rc = chan_uniform_prepare(c); if (rc) return rc; }
     a.in = static_cast<const float2*>(d_in);
     a.out = static_cast<float2*>(d_out);
     a.hist = reinterpret_cast<const float2*>(c->d_hist[c->cur]);
@@ -1247,6 +1254,36 @@ int qdsp_hip_chan_cf32_reset(void* h) {
     HIPCHK(hipSetDevice(c->device));
     for (int i = 0; i < 2; i++)
         if (c->d_hist[i]) HIPCHK(hipMemset(c->d_hist[i], 0, (size_t)c->ntaps * sizeof(float2)));
+    return 0;
+}
+int qdsp_hip_chan_cf32_history_len(void* h) {
+    Chan* c = as_chan(h);
+    return c ? c->vfo[0]->H : QDSP_HIP_EINVAL;
+}
+int qdsp_hip_chan_cf32_set_history_dev(void* h, const void* d_hist, void* s) {
+    Chan* c = as_chan(h);
+    if (!c || !d_hist) return QDSP_HIP_EINVAL;
+    HIPCHK(hipSetDevice(c->device));
+    int inv;
+    long long dd[64];
+    if (chan_uniform_plan(c, &inv, dd)) {
+        // shared history of the fast path: the raw samples rotated by channel 0's NCO
+        int rc = chan_uniform_prepare(c);
+        if (rc) return rc;
+        Engine* e0 = c->vfo[0];
+        rc = launch_xlate_raw(e0, d_hist, c->ntaps, c->d_hist[c->cur], e0->phase - (unsigned long long)c->ntaps * e0->dphase, 0.0f,
+                              static_cast<hipStream_t>(s));
+        if (rc) return rc;
+    }
+    const int mode = c->mode ? c->mode : env_int("QDSP_HIP_FIR_MODE", 0);
+    if (mode == 1 || !chan_uniform_plan(c, &inv, dd))
+        for (Engine* e : c->vfo) { int rc = set_history_dev(e, d_hist, s); if (rc) return rc; }
+    return 0;
+}
+int qdsp_hip_chan_cf32_advance(void* h, int64_t n) {
+    Chan* c = as_chan(h);
+    if (!c) return QDSP_HIP_EINVAL;
+    for (Engine* e : c->vfo) e->phase += (unsigned long long)n * e->dphase;
     return 0;
 }
 int qdsp_hip_chan_cf32_channels(void* h) {

@@ -318,6 +318,23 @@ class Channelizer:
     def out_size(self, n: int) -> int:
         return int(capi.check(self._L.qdsp_hip_chan_cf32_out_size(self._h, n)))
 
+    _prefix = "qdsp_hip_chan_cf32"
+
+    @property
+    def history_len(self) -> int:
+        return int(capi.check(self._L.qdsp_hip_chan_cf32_history_len(self._h)))
+
+    def set_history_dev(self, hist):
+        """The history_len raw input samples preceding the next call (device tensor)."""
+        import torch
+
+        assert hist.is_cuda and hist.is_contiguous() and hist.dtype == torch.complex64 and hist.numel() == self.history_len
+        stream = torch.cuda.current_stream(hist.device).cuda_stream
+        capi.check(self._L.qdsp_hip_chan_cf32_set_history_dev(self._h, hist.data_ptr(), stream))
+
+    def advance(self, n: int):
+        capi.check(self._L.qdsp_hip_chan_cf32_advance(self._h, int(n)))
+
     def last_kernel(self):
         name = C.create_string_buffer(128)
         g, b, l = C.c_int(), C.c_int(), C.c_int()

@@ -579,3 +579,33 @@ def test_vfo_set_history_dev_rotates_raw_samples(ops, gold):
         y2 = second.process(dev(x[cut:])).cpu().numpy()
         torch.cuda.synchronize()
         assert rel_rms(y2, y[cut // dec:]) < 2e-6, dec
+
+
+@pytest.mark.parametrize("mode", ["uniform", "per_channel"])
+def test_channelizer_time_sharded_halo(ops, gold, mode):
+    """BASELINE configs[4] at N > 1: a second handle started mid-stream from advance() and the
+    predecessor's raw tail (set_history_dev) continues the unsharded outputs."""
+    import torch
+
+    taps = gold["taps256"]
+    n, cut = 1 << 19, 1 << 18
+    x = dev(O.synth_iq(0, n, seed=5))
+    incs = [ops.phase_delta(1.0, -(c - 31.5) / 64.0) for c in range(64)]
+
+    def make():
+        ch = ops.Channelizer(taps, 1, 64, incs, max_block=0)
+        ch.set_volk_gain(False)
+        if mode == "per_channel":
+            ch.set_mode(ch.DIRECT)
+        return ch
+
+    whole = make()
+    y = whole.process(x).cpu().numpy()
+    assert (whole.last_kernel()["name"] == "chan_uniform_kernel") == (mode == "uniform")
+    second = make()
+    second.advance(cut)
+    second.set_history_dev(x[cut - second.history_len:cut].contiguous())
+    y2 = second.process(x[cut:].contiguous()).cpu().numpy()
+    torch.cuda.synchronize()
+    for c in (0, 5, 33, 63):
+        assert rel_rms(y2[c], y[c][cut // 64:]) < 2e-6, c
