@@ -20,7 +20,13 @@
 //   stage xr (4288 samples, rotated while staging) -> LDS
 //   lane (n', sub): 16 branch sums U[sub + 4i] (taps in registers) -> radix-16 DFT in registers
 //   LDS transpose -> lane (n', g): radix-4 across sub -> 16 channel outputs
-//   LDS transpose -> lane (c, quarter): correction x 16 consecutive n', contiguous stores.
+//   LDS transpose -> wave w, lane n': correction and store of channels 16w .. 16w+15, each store
+//   instruction 64 consecutive n' of one channel (512 contiguous bytes: the first version stored
+//   64 scattered 8-byte pieces per instruction and was bound by L2 write requests, 134 M per GiB).
+// Phasors: per-lane FP64 state advanced by one FP64 complex multiply per tile (channel 0's NCO at
+// the lane's first staged sample; channel c's correction at the tile's first output, lanes 0..63),
+// set up with one sincospi per lane per launch.  Within a tile the correction angle grows by
+// 64*ddelta_c per output (<= 1e-2 rad over the tile): a 3-term FP32 series.
 #include "chan.hip.h"
 #include "cfft.hip.h"
 
@@ -71,11 +77,19 @@ __global__ __launch_bounds__(256, 3) void chan_uniform_kernel(const ChanArgs a) 
         tw[i] = a.tw64[(i * sub) & 63];          // exp(-j 2pi m / 64); conjugated below when INV
         if (INV) tw[i].y = -tw[i].y;
     }
-    const int cs = t >> 2, qt = t & 3;           // roles in the store phase: channel, quarter of the tile
-    const unsigned long long dphi_c = a.dphi[cs];    // phi_c - phi_0
-    const long long ddel_c = a.ddelta[cs];           // dphi_c - dphi_0 -+ c*2^58 (tiny, signed)
-    const float gm1_c = a.gm1[cs];
-    const double2 corr_step = fx_phasor((unsigned long long)(ddel_c * (long long)kChK));
+    // store-phase tables behind the taps: corrA[64] (per tile), {theta_c, gm1_c}[64] (per launch)
+    float2* corrA = reinterpret_cast<float2*>(tapl + 256);
+    float2* cst = corrA + 64;
+    double2 corr = make_double2(1.0, 0.0), corr_step = corr;
+    if (t < 64) {
+        const long long ddel_c = a.ddelta[t];            // dphase_c - dphase_0 -+ c*2^58 (tiny, signed)
+        const long long jc0 = (long long)blockIdx.x * (kChT * kChK) - P + a.kcentre;   // window centre of the first output
+        corr = fx_phasor(a.dphi[t] + (unsigned long long)(jc0 * ddel_c));
+        corr_step = fx_phasor((unsigned long long)(ddel_c * (long long)(kChT * kChK) * (long long)a.nwg));
+        cst[t] = make_float2((float)((double)(ddel_c * (long long)kChK) * 3.4061215800865545e-19), a.gm1[t]);   // 2pi / 2^64
+    }
+    const int wv = t >> 6, ln = t & 63;              // roles in the store phase: channel group, output time
+    double2 ph0 = fx_phasor(a.phase0 + (unsigned long long)((long long)blockIdx.x * (kChT * kChK) - P + t) * a.dphase0);
 
     for (int tile = blockIdx.x; tile < a.ntiles; tile += a.nwg) {
         const long long n0 = (long long)tile * kChT;       // first output time of the tile
@@ -83,7 +97,8 @@ __global__ __launch_bounds__(256, 3) void chan_uniform_kernel(const ChanArgs a) 
         const int span = (kChT - 1 + Q) * 64;
         // ---- stage xr ---------------------------------------------------------------------
         {
-            double2 ph = fx_phasor(a.phase0 + (unsigned long long)(jb + t) * a.dphase0);
+            double2 ph = ph0;
+            ph0 = dcmul(ph0, a.rot_tile);
             for (int u = t; u < span; u += 256) {
                 const long long g = jb + u;
                 float2 v = make_float2(0.0f, 0.0f);
@@ -138,20 +153,30 @@ __global__ __launch_bounds__(256, 3) void chan_uniform_kernel(const ChanArgs a) 
 #pragma unroll
                 for (int c1 = 0; c1 < 4; c1++) lds[(16 * c1 + 4 * g + c0l) * kChRow3 + nl] = R[4 * c0l + c1];
         }
+        if (t < 64) {
+            corrA[t] = make_float2((float)corr.x, (float)corr.y);
+            corr = dcmul(corr, corr_step);
+        }
         __syncthreads();
-        // ---- per-channel correction and contiguous stores: lane (channel cs, quarter qt) -----------
+        // ---- per-channel correction and contiguous stores: wave wv, lane n' = ln ----------------------
         {
-            const long long nq = n0 + qt * 16;                               // first n' of this lane
-            const long long jc = nq * kChK - P + a.kcentre;                  // window-centre position of n' = nq
-            double2 corr = fx_phasor(dphi_c + (unsigned long long)(jc * ddel_c));
-            float2* __restrict__ o = a.out + (size_t)cs * a.out_stride + nq;
+            const long long nn = n0 + ln;
+            const long long j = nn * kChK - P + a.kcentre;                   // window-centre position of this output
+            const float jm = (float)(int)(j & 511);
+            const float fl = (float)ln;
+            float2* __restrict__ o = a.out + nn;
+            const bool live = nn < a.nout;
 #pragma unroll
             for (int k = 0; k < 16; k++) {
-                const float2 y = lds[cs * kChRow3 + qt * 16 + k];
-                const long long j = jc + (long long)k * kChK;
-                const float2 r = rot_gain(y, corr, j, gm1_c);
-                if (nq + k < a.nout) o[k] = r;
-                corr = dcmul(corr, corr_step);
+                const int c = wv * 16 + k;
+                const float2 y = lds[c * kChRow3 + ln];
+                const float2 A = corrA[c], tg = cst[c];
+                const float ang = fl * tg.x, a2 = ang * ang;
+                const float br = fmaf(a2, -0.5f, 1.0f), bi = fmaf(a2 * ang, -1.0f / 6.0f, ang);
+                const float gain = fmaf(jm, tg.y, 1.0f);
+                const float pr = fmaf(A.x, br, -A.y * bi) * gain, pi = fmaf(A.x, bi, A.y * br) * gain;
+                const float2 r = make_float2(fmaf(y.x, pr, -y.y * pi), fmaf(y.x, pi, y.y * pr));
+                if (live) o[(size_t)c * a.out_stride] = r;
             }
         }
         __syncthreads();   // layout 3 is read before the next tile's staging overwrites it

@@ -20,9 +20,10 @@ struct ChanArgs {
     int nwg;                   // persistent workgroups (grid = nwg + 1: the last hands over history)
     int kcentre;               // tap index the per-channel correction is evaluated at ((ntaps-1)/2)
     int inv;                   // 1: channel spacing +1/64 turn/sample, 0: -1/64
-    int lds_elems;             // float2 elements of the tile buffer (the 256-float tap table sits behind it)
+    int lds_elems;             // float2 elements of the tile buffer (256-float tap table + 2 x 64 float2 behind it)
     unsigned long long phase0, dphase0;   // channel 0's NCO (fixed point, 2^64 = one turn)
     double2 rot256;            // exp(j 2pi 256 dphase0)
+    double2 rot_tile;          // exp(j 2pi 4096 nwg dphase0): a workgroup's tile -> its next tile
     unsigned long long dphi[64];   // phi_c - phi_0 at the first sample of this call
     long long ddelta[64];          // dphase_c - dphase_0 -+ c*2^58: deviation from the uniform plan
     float gm1[64];                 // |phase_inc_c| - 1 (VOLK magnitude sawtooth), 0 = off

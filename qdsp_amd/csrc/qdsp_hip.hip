@@ -779,6 +779,7 @@ int chan_launch_uniform(Chan* c, const void* d_in, int64_t count, int64_t nout, 
     a.phase0 = c->vfo[0]->phase;
     a.dphase0 = c->vfo[0]->dphase;
     unit_of_fx(a.dphase0, 256.0L, &a.rot256.x, &a.rot256.y);
+    unit_of_fx(a.dphase0, 4096.0L * nwg, &a.rot_tile.x, &a.rot_tile.y);
     for (int i = 0; i < 64; i++) {
         a.dphi[i] = c->vfo[i]->phase - c->vfo[0]->phase;
         a.gm1[i] = c->volk_gain ? c->vfo[i]->gm1 : 0.0f;
@@ -786,7 +787,7 @@ int chan_launch_uniform(Chan* c, const void* d_in, int64_t count, int64_t nout, 
     const size_t rows = (size_t)(63 + a.Q) * 68;
     const size_t elems = rows > 256 * 17 ? rows : 256 * 17;
     a.lds_elems = (int)elems;
-    const size_t lds = elems * sizeof(float2) + 256 * sizeof(float);
+    const size_t lds = elems * sizeof(float2) + 256 * sizeof(float) + 128 * sizeof(float2);
     int rc = qk::launch_chan_uniform(a, nwg + 1, lds, s);
     if (rc) return rc;
     c->cur ^= 1;
