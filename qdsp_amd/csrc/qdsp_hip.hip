@@ -688,9 +688,11 @@ struct Chan {
     int mode = 0;                  // QDSP_HIP_FIR_AUTO / _DIRECT (one fused VFO kernel per channel) / _FFT (= fast path if the plan allows)
     bool volk_gain = true;
     int ntaps = 0, interp = 1, decim = 1;
-    float* d_taps = nullptr;       // prototype taps padded to 256
+    float2* d_taps = nullptr;      // prototype taps * exp(j k dphase_0), padded to 256 (rebuilt when dphase_0 changes)
+    unsigned long long gt_dphase = 0;
+    bool gt_valid = false;
     float2* d_tw64 = nullptr;
-    float* d_hist[2] = {nullptr, nullptr};   // P samples rotated by channel 0's NCO
+    float* d_hist[2] = {nullptr, nullptr};   // P raw input samples (shared by all channels)
     int cur = 0;
     Launch last;
 };
@@ -736,20 +738,32 @@ bool chan_uniform_plan(const Chan* c, int* inv, long long* ddelta) {
 // Tables and the shared history of the uniform fast path (allocated on first use).
 int chan_uniform_prepare(Chan* c) {
     const int P = c->ntaps;
+    const long double two_pi = 6.283185307179586476925286766559005768L;
     if (!c->d_taps) {
-        std::vector<float> tp(256, 0.0f);
-        for (int i = 0; i < c->ntaps; i++) tp[i] = c->vfo[0]->taps_host[i];
         std::vector<float2> tw(64);
-        const long double two_pi = 6.283185307179586476925286766559005768L;
         for (int m = 0; m < 64; m++) tw[m] = make_float2((float)cosl(two_pi * m / 64), (float)(-sinl(two_pi * m / 64)));
-        HIPCHK(hipMalloc(&c->d_taps, 256 * sizeof(float)));
+        HIPCHK(hipMalloc(&c->d_taps, 256 * sizeof(float2)));
         HIPCHK(hipMalloc(&c->d_tw64, 64 * sizeof(float2)));
-        HIPCHK(hipMemcpy(c->d_taps, tp.data(), 256 * sizeof(float), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(c->d_tw64, tw.data(), 64 * sizeof(float2), hipMemcpyHostToDevice));
         for (int i = 0; i < 2; i++) {
             HIPCHK(hipMalloc(&c->d_hist[i], (size_t)P * sizeof(float2)));
             HIPCHK(hipMemset(c->d_hist[i], 0, (size_t)P * sizeof(float2)));
         }
+    }
+    const unsigned long long d0 = c->vfo[0]->dphase;
+    if (!c->gt_valid || c->gt_dphase != d0) {
+        // channel 0's mixer folded into the prototype: g[k] = h[k] * exp(j 2pi k dphase_0 / 2^64)
+        std::vector<float2> g(256, make_float2(0.0f, 0.0f));
+        for (int k = 0; k < c->ntaps; k++) {
+            double cr, sr;
+            unit_of_fx(d0, (long double)k, &cr, &sr);
+            const double h = c->vfo[0]->taps_host[k];
+            g[k] = make_float2((float)(h * cr), (float)(h * sr));
+        }
+        HIPCHK(hipDeviceSynchronize());     // rare (retune of channel 0): nothing in flight may still read the table
+        HIPCHK(hipMemcpy(c->d_taps, g.data(), 256 * sizeof(float2), hipMemcpyHostToDevice));
+        c->gt_dphase = d0;
+        c->gt_valid = true;
     }
     return 0;
 }
@@ -764,31 +778,27 @@ int chan_launch_uniform(Chan* c, const void* d_in, int64_t count, int64_t nout, 
     a.out = static_cast<float2*>(d_out);
     a.hist = reinterpret_cast<const float2*>(c->d_hist[c->cur]);
     a.hist_next = reinterpret_cast<float2*>(c->d_hist[c->cur ^ 1]);
-    a.taps = c->d_taps;
+    a.gtaps = c->d_taps;
     a.tw64 = c->d_tw64;
     a.count = count;
     a.nout = nout;
     a.out_stride = out_stride;
     a.P = P;
     a.Q = (c->ntaps + 63) / 64;
-    a.ntiles = (int)((nout + 63) / 64);
-    int nwg = 256 * env_int("QDSP_HIP_CHAN_WG_PER_CU", 8);
-    if (nwg > a.ntiles) nwg = a.ntiles;
+    a.ntiles = (int)((nout + 15) / 16);
+    int nwg = 256 * env_int("QDSP_HIP_CHAN_WG_PER_CU", 12);  // 3 resident per CU, 4 rounds
+    if (nwg > (a.ntiles + 3) / 4) nwg = (a.ntiles + 3) / 4;
+    if (nwg < 1) nwg = 1;
     a.nwg = nwg;
     a.kcentre = (c->ntaps - 1) / 2;
     a.phase0 = c->vfo[0]->phase;
     a.dphase0 = c->vfo[0]->dphase;
-    unit_of_fx(a.dphase0, 256.0L, &a.rot256.x, &a.rot256.y);
-    unit_of_fx(a.dphase0, 4096.0L * nwg, &a.rot_tile.x, &a.rot_tile.y);
     for (int i = 0; i < 64; i++) {
         a.dphi[i] = c->vfo[i]->phase - c->vfo[0]->phase;
         a.gm1[i] = c->volk_gain ? c->vfo[i]->gm1 : 0.0f;
     }
-    const size_t rows = (size_t)(63 + a.Q) * 68;
-    const size_t elems = rows > 256 * 17 ? rows : 256 * 17;
-    a.lds_elems = (int)elems;
-    const size_t lds = elems * sizeof(float2) + 256 * sizeof(float) + 128 * sizeof(float2);
-    int rc = qk::launch_chan_uniform(a, nwg + 1, lds, s);
+    const size_t lds = qk::chan_uniform_lds_bytes();
+    int rc = qk::launch_chan_uniform(a, nwg + 1, s);
     if (rc) return rc;
     c->cur ^= 1;
     for (int i = 0; i < 64; i++) c->vfo[i]->phase += (unsigned long long)count * c->vfo[i]->dphase;
@@ -1268,13 +1278,11 @@ int qdsp_hip_chan_cf32_set_history_dev(void* h, const void* d_hist, void* s) {
     int inv;
     long long dd[64];
     if (chan_uniform_plan(c, &inv, dd)) {
-        // shared history of the fast path: the raw samples rotated by channel 0's NCO
+        // shared history of the fast path: raw input (channel 0's mixer lives in the taps)
         int rc = chan_uniform_prepare(c);
         if (rc) return rc;
-        Engine* e0 = c->vfo[0];
-        rc = launch_xlate_raw(e0, d_hist, c->ntaps, c->d_hist[c->cur], e0->phase - (unsigned long long)c->ntaps * e0->dphase, 0.0f,
-                              static_cast<hipStream_t>(s));
-        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(c->d_hist[c->cur], d_hist, (size_t)c->ntaps * sizeof(float2), hipMemcpyDeviceToDevice,
+                              static_cast<hipStream_t>(s)));
     }
     const int mode = c->mode ? c->mode : env_int("QDSP_HIP_FIR_MODE", 0);
     if (mode == 1 || !chan_uniform_plan(c, &inv, dd))
