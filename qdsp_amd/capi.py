@@ -33,9 +33,11 @@ def declared_symbols() -> list[str]:
 def load():
     """dlopen libqdsp_hip.so.  torch is imported first so that the process holds exactly one
     HIP runtime (torch bundles a libamdhip64 with the same SONAME as /opt/rocm's)."""
-    global _lib
+    global _lib, LIB_PATH
     if _lib is not None:
         return _lib
+    if os.environ.get("QDSP_HIP_LIB"):          # kernel experiments: another build of the same library
+        LIB_PATH = os.environ["QDSP_HIP_LIB"]
     if not os.path.exists(LIB_PATH) and os.environ.get("QDSP_HIP_NO_AUTOBUILD", "0") != "1":
         # a fresh checkout (the .so is git-ignored): compile it once with hipcc -- this builds the
         # product itself, it is not a fallback path

@@ -28,20 +28,34 @@
 //            per store and was bound by L2 write requests: 134 M per GiB of output.)
 // rot_c(n') = A_c(tile) * W(n' - n0) * B_c(n' - n0): A_c is FP64 state of lane c advanced by one
 // complex multiply per tile, W = exp(j 64 m dphi_0) a per-lane constant, B_c = exp(j 64 m delta_c) a
-// 3-term FP32 series.  History is raw input.
+// 2-term FP32 series (<= 2.4e-3 rad over 16 outputs).  History is raw input.
+// All complex arithmetic is packed FP32 (cpk.hip.h: v_pk_* does the real and imaginary lane in one
+// issue, 1190 -> ~800 VALU instructions per tile).  The kernel runs at the speed of its memory skeleton
+// (scripts/micro/write_streams.hip: the same loads and stores without any arithmetic take the same
+// 0.43 ms per 2^27 samples; a plain 1 GiB copy takes 0.37-0.41 ms, scripts/micro/copy_bw.hip).
 #include "chan.hip.h"
 #include "cfft.hip.h"
+#include "cpk.hip.h"
+#include <type_traits>
 
 namespace qk {
 
 constexpr int kChK = 64;                 // channels == branches == decimation
 constexpr int kChT = 16;                 // output times per wave tile
 constexpr int kChRowT = 68;              // T[n'][mu] row pitch: lanes (n', sub) read 4n' + sub (mod 32): conflict-free
-constexpr int kChWaveLds = kChT * kChRowT + 2 * 64;   // float2 elements per wave: T + {A_c, theta_c, gm1_c}[64]
+constexpr int kChWaveLds = kChT * kChRowT + 2 * 64;   // float2 elements per wave: T + {A_c, j A_c}[64]
 constexpr int kChRows = kChT - 1 + 4;    // 19 staged rows at 256 taps
 
-template <int CTRL> __device__ __forceinline__ float dpp_quad(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+// quad_perm of both lanes of a packed pair.  One 64-bit update_dpp (expanded to two v_mov_b32_dpp):
+// with two 32-bit mov_dpp calls hipcc (ROCm 7.2) keeps only the first and feeds it to both halves of the
+// consuming v_pk_fma_f32.
+template <int CTRL> __device__ __forceinline__ v2f dpp_quad(v2f v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const long long r = __builtin_amdgcn_update_dpp(0ll, __builtin_bit_cast(long long, v), CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(v2f, r);
+#else
+    return v;   // (the host pass only parses this; the type-generic builtin exists for the device target)
+#endif
 }
 
 template <bool INV>   // INV: channel c sits at +c/64 turn per sample relative to channel 0, else -c/64
@@ -49,73 +63,76 @@ __global__ __launch_bounds__(256, 3) void chan_uniform_kernel(const ChanArgs a) 
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int t = threadIdx.x;
     const int P = a.P, Q = a.Q;
-    const float2* __restrict__ in = a.in;
+    const v2f* __restrict__ in = reinterpret_cast<const v2f*>(a.in);
+    const v2f* __restrict__ hist = reinterpret_cast<const v2f*>(a.hist);
 
     if ((int)blockIdx.x == a.nwg) {
         // history for the next call: the last P samples of hist ++ in
         for (int i = t; i < P; i += 256) {
             const long long g = a.count - P + i;
-            a.hist_next[i] = g < 0 ? a.hist[g + P] : in[g];
+            a.hist_next[i] = g < 0 ? a.hist[g + P] : a.in[g];
         }
         return;
     }
 
     const int l = t & 63, wv = t >> 6;
-    float2* T = lds + wv * kChWaveLds;                                   // [16][68]
-    float4* tab = reinterpret_cast<float4*>(T + kChT * kChRowT);         // [64] {A_c.re, A_c.im, theta_c, gm1_c}
-
-    // consecutive tiles on the same XCD (workgroups are dealt round-robin over the 8 XCDs): neighbours
-    // share 3 of their 19 rows
-    const int per_xcd = a.nwg >> 3;
-    const int wg = (a.nwg & 7) ? (int)blockIdx.x : ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
-    const int gw = wg * 4 + wv, nwaves = a.nwg * 4;
-    const long long tile_pos = (long long)kChT * kChK;                    // stream positions per tile
-
-    // ---- branch role: lane = staged column p ------------------------------------------------------
-    float2 g[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) g[q] = q < Q ? a.gtaps[64 * q + l] : make_float2(0.0f, 0.0f);
-    const int mu = (l - P) & 63;
-    // ---- DFT role: lane = (n' = l >> 2, sub = l & 3) ------------------------------------------------
-    const int nq = l >> 2, sub = l & 3;
-    float2* twl = lds + 4 * kChWaveLds;              // [sub][c0] = exp(+-j 2pi c0 sub / 64), shared by the 4 waves
+    v2f* T = reinterpret_cast<v2f*>(lds + wv * kChWaveLds);                   // [16][68]
+    float4* tab = reinterpret_cast<float4*>(lds + wv * kChWaveLds + kChT * kChRowT);   // [64] {A_c, j A_c} of this tile
+    float4* twl = reinterpret_cast<float4*>(lds + 4 * kChWaveLds);             // [sub][c0] {w, j w}, w = exp(+-j 2pi c0 sub / 64)
+    float2* cst = lds + 4 * kChWaveLds + 128;                                  // [64] {theta_c, gm1_c}
     if (t < 64) {
         float2 w = a.tw64[((t & 15) * (t >> 4)) & 63];   // exp(-j 2pi m / 64); conjugated when INV
         if (INV) w.y = -w.y;
-        twl[t] = w;
+        twl[t] = make_float4(w.x, w.y, -w.y, w.x);
+        cst[t] = make_float2((float)((double)(a.ddelta[t] * (long long)kChK) * 3.4061215800865545e-19), a.gm1[t]);   // 2pi / 2^64
     }
     __syncthreads();                                 // the only workgroup barrier: once per launch
-    const float2* __restrict__ tw = twl + sub * 16;
+
+    // (workgroup -> tile in launch order: dealing consecutive tiles to the same XCD, so that neighbours'
+    // 3 shared rows meet in one L2, measured 8 % SLOWER -- the 64 output rows are then written at 8
+    // distant fronts instead of one)
+    const int gw = (int)blockIdx.x * 4 + wv, nwaves = a.nwg * 4;
+    const long long tile_pos = (long long)kChT * kChK;                    // stream positions per tile
+
+    // ---- branch role: lane = staged column p ------------------------------------------------------
+    v2f g[4], gj[4];                                 // complex taps 64q + p and j * taps
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const float2 gq = q < Q ? a.gtaps[64 * q + l] : make_float2(0.0f, 0.0f);
+        g[q] = mk2(gq.x, gq.y);
+        gj[q] = jtimes(g[q]);
+    }
+    const int mu = (l - P) & 63;
+    // ---- DFT role: lane = (n' = l >> 2, sub = l & 3) ------------------------------------------------
+    const int nq = l >> 2, sub = l & 3;
+    const float4* __restrict__ tw = twl + sub * 16;
     const int c1 = ((sub & 1) << 1) | (sub >> 1);    // radix-4 output this lane keeps (bit-reversed quad index)
-    const float sA = (sub & 2) ? -1.0f : 1.0f, sB = (sub & 1) ? -1.0f : 1.0f;
-    const bool is3 = sub == 3;
-    float2 W;
+    const v2f sA = (sub & 2) ? mk2(-1.0f, -1.0f) : mk2(1.0f, 1.0f), sB = (sub & 1) ? mk2(-1.0f, -1.0f) : mk2(1.0f, 1.0f);
+    // between the two radix-2 stages lane 3 takes the -+j twiddle; W(n') = exp(j 64 n' dphi_0) rides along
+    v2f M, Mj;
     {
         const double2 w = fx_phasor((unsigned long long)(kChK * nq) * a.dphase0);
-        W = make_float2((float)w.x, (float)w.y);
+        const v2f W = mk2((float)w.x, (float)w.y);
+        M = sub == 3 ? pk_mulj<INV>(W) : W;
+        Mj = jtimes(M);
     }
     // ---- channel role: lane = channel c ----------------------------------------------------------
     double2 corr, corr_step;
-    float theta_c, gm1_c;
     {
         const long long del = a.ddelta[l];                      // delta_c (tiny, signed)
         const unsigned long long inc = a.dphase0 + (unsigned long long)del;
         const long long j0 = (long long)gw * tile_pos - P;
         corr = fx_phasor(a.phase0 + a.dphi[l] + (unsigned long long)j0 * a.dphase0 + (unsigned long long)((j0 + a.kcentre) * del));
         corr_step = fx_phasor((unsigned long long)(tile_pos * nwaves) * inc);
-        theta_c = (float)((double)(del * (long long)kChK) * 3.4061215800865545e-19);   // 2pi / 2^64
-        gm1_c = a.gm1[l];
     }
 
-    const float2* __restrict__ in_or_hist = a.count > 0 ? in : a.hist;   // any readable address (P >= 1)
-    for (int wt = gw; wt < a.ntiles; wt += nwaves) {
-        const long long n0 = (long long)wt * kChT;            // first output time of the tile
-        const long long jb = n0 * kChK - P;                    // stream position of row 0, column 0
-        // ---- rows from global memory ------------------------------------------------------------
-        float2 x[kChRows];
+    const v2f* __restrict__ in_or_hist = a.count > 0 ? in : hist;   // any readable address (P >= 1)
+    v2f x[kChRows];
+    auto load_rows = [&](int wt) {
+        const long long jb = (long long)wt * tile_pos - P;     // stream position of row 0, column 0
         if (jb >= 0 && jb + 64 * kChRows <= a.count) {
             // interior tile: 19 independent coalesced loads (rows beyond 15 + Q meet zero taps)
-            const float2* __restrict__ src = in + jb + l;
+            const v2f* __restrict__ src = in + jb + l;
 #pragma unroll
             for (int r = 0; r < kChRows; r++) x[r] = src[64 * r];
         } else {
@@ -124,72 +141,77 @@ __global__ __launch_bounds__(256, 3) void chan_uniform_kernel(const ChanArgs a) 
             for (int r = 0; r < kChRows; r++) {
                 const long long gpos = jb + 64 * r + l;
                 const bool ok = gpos >= -(long long)P && gpos < a.count;
-                const float2* __restrict__ src = gpos < 0 ? a.hist + (gpos + P) : in + gpos;
-                const float2 v = *(ok ? src : in_or_hist);
-                x[r] = ok ? v : make_float2(0.0f, 0.0f);
+                const v2f* __restrict__ src = gpos < 0 ? hist + (gpos + P) : in + gpos;
+                const v2f v = *(ok ? src : in_or_hist);
+                x[r] = ok ? v : mk2(0.0f, 0.0f);
             }
         }
-        tab[l] = make_float4((float)corr.x, (float)corr.y, theta_c, gm1_c);
-        corr = dcmul(corr, corr_step);
+    };
+    for (int wt = gw; wt < a.ntiles; wt += nwaves) {
+        load_rows(wt);
+        const long long n0 = (long long)wt * kChT;            // first output time of the tile
+        {
+            const float cx = (float)corr.x, cy = (float)corr.y;
+            tab[l] = make_float4(cx, cy, -cy, cx);
+            corr = dcmul(corr, corr_step);
+        }
         // ---- branch sums: U[n'][mu] = sum_q g[64q + p] x[row n'+q][p] -------------------------------
 #pragma unroll
         for (int n = 0; n < kChT; n++) {
-            float2 acc = make_float2(0.0f, 0.0f);
+            v2f acc = mk2(0.0f, 0.0f);
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                if (q < Q) {
-                    acc.x = fmaf(g[q].x, x[n + q].x, acc.x);
-                    acc.x = fmaf(-g[q].y, x[n + q].y, acc.x);
-                    acc.y = fmaf(g[q].x, x[n + q].y, acc.y);
-                    acc.y = fmaf(g[q].y, x[n + q].x, acc.y);
-                }
-            }
+            for (int q = 0; q < 4; q++)
+                if (q < Q) acc = pk_cmac(x[n + q], g[q], gj[q], acc);
             T[n * kChRowT + mu] = acc;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // ---- 64-point DFT over mu = sub + 4i: radix-16 in registers, radix-4 across the quad ----------
-        float2 U[16];
+        v2f U[16];
 #pragma unroll
         for (int i = 0; i < 16; i++) U[i] = T[nq * kChRowT + sub + 4 * i];
-        fft16<INV>(U);                               // over i -> group c0 at U[rev16(c0)]
+        pk_fft16<INV>(U);                            // over i -> group c0 at U[rev16(c0)]
         const long long nn = n0 + nq;
         const long long j = nn * kChK - P + a.kcentre;               // window-centre position of this output
         const float jm = (float)(int)(j & 511);
         const float fl = (float)nq;
-        float2* __restrict__ o = a.out + nn;
+        v2f* __restrict__ o = reinterpret_cast<v2f*>(a.out) + nn;
         const bool live = nn < a.nout;
+        // (two copies of the loop: in the full-tile one nothing depends on `live`, so the compiler keeps
+        // it one basic block and overlaps the table reads / DPP hazards of neighbouring groups)
+        auto finish = [&](auto guarded) {
 #pragma unroll
-        for (int c0 = 0; c0 < 16; c0++) {
-            float2 z = U[rev16(c0)];
-            if (c0 != 0) z = cmulc<false>(z, tw[c0]);
-            // stage A: pairs (sub, sub^2); lane 3 takes the +-j twiddle
-            float2 ta = make_float2(fmaf(sA, z.x, dpp_quad<0x4E>(z.x)), fmaf(sA, z.y, dpp_quad<0x4E>(z.y)));
-            {
-                const float2 tj = mulj<INV>(ta);
-                ta.x = is3 ? tj.x : ta.x;
-                ta.y = is3 ? tj.y : ta.y;
+            for (int c0 = 0; c0 < 16; c0++) {
+                v2f z = U[rev16(c0)];
+                if (c0 != 0) {
+                    const float4 w = tw[c0];
+                    z = pk_cmul(z, mk2(w.x, w.y), mk2(w.z, w.w));
+                }
+                // stage A: pairs (sub, sub^2), then lane 3's -+j twiddle (and W) ; stage B: pairs (sub, sub^1)
+                v2f ta = pk_fma(z, sA, dpp_quad<0x4E>(z));
+                ta = pk_cmul(ta, M, Mj);
+                const v2f y = pk_fma(ta, sB, dpp_quad<0xB1>(ta));
+                // A_c(tile), B_c(n') and VOLK's magnitude sawtooth
+                const int c = c0 + 16 * c1;
+                const float4 A = tab[c];
+                const float2 tg = cst[c];
+                const v2f v = pk_cmul(y, mk2(A.x, A.y), mk2(A.z, A.w));
+                const float ang = fl * tg.x;
+                const float gain = fmaf(jm, tg.y, 1.0f);
+                const float brg = fmaf(ang * ang, -0.5f, 1.0f) * gain;
+                const v2f r = pk_fma(v.yx, mk2(-ang * gain, ang * gain), v * mk2(brg, brg));
+                if (!decltype(guarded)::value || live) o[(size_t)c * a.out_stride] = r;
             }
-            // stage B: pairs (sub, sub^1)
-            const float2 y = make_float2(fmaf(sB, ta.x, dpp_quad<0xB1>(ta.x)), fmaf(sB, ta.y, dpp_quad<0xB1>(ta.y)));
-            // rot_c(n') and VOLK's magnitude sawtooth
-            const int c = c0 + 16 * c1;
-            const float4 tc = tab[c];
-            const float ang = fl * tc.z, a2 = ang * ang;
-            const float br = fmaf(a2, -0.5f, 1.0f), bi = fmaf(a2 * ang, -1.0f / 6.0f, ang);
-            const float gain = fmaf(jm, tc.w, 1.0f);
-            const float2 aw = cmulc<false>(make_float2(tc.x, tc.y), W);
-            const float pr = fmaf(aw.x, br, -aw.y * bi) * gain, pi = fmaf(aw.x, bi, aw.y * br) * gain;
-            const float2 r = make_float2(fmaf(y.x, pr, -y.y * pi), fmaf(y.x, pi, y.y * pr));
-            if (live) o[(size_t)c * a.out_stride] = r;
-        }
+        };
+        if (n0 + kChT <= a.nout) finish(std::false_type{});
+        else finish(std::true_type{});
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
 }
 
-size_t chan_uniform_lds_bytes() { return (size_t)(4 * kChWaveLds + 64) * sizeof(float2); }
+size_t chan_uniform_lds_bytes() { return (size_t)(4 * kChWaveLds + 128 + 64) * sizeof(float2); }
 
 int launch_chan_uniform(const ChanArgs& a, int grid, hipStream_t stream) {
     const size_t lds_bytes = chan_uniform_lds_bytes();
