@@ -361,9 +361,10 @@ def main():
     if kinfo["name"] == "fir_fft_kernel":
         flops = 1524.0 * 256 / (4097 - w["ntaps"])
     elif kinfo["name"] == "chan_uniform_kernel":
-        # per lane and 64x64 tile: 128 branch MACs, one radix-16 + four radix-4 butterflies, twiddles,
-        # NCO at staging and per-channel correction: ~1000 FLOP x 256 lanes / 4096 input samples
-        flops = 62.0
+        # per lane and wave tile (16 output times x 64 channels = 1024 input samples per wave): 64 complex
+        # MACs (512), radix-16 (~200), twiddles (~90), radix-4 across the quad (~220), per-channel
+        # rotation (~320): ~1350 FLOP x 64 lanes / 1024 input samples
+        flops = 84.0
     achieved_tf = flops * n / (kms * 1e-3) / 1e12
 
     if rank == 0:
