@@ -33,6 +33,13 @@ template <bool INV> __device__ __forceinline__ v2f pk_mulj(v2f a) {
     return a.yx * (INV ? mk2(-1.0f, 1.0f) : mk2(1.0f, -1.0f));
 }
 
+// a * b (CONJ: a * conj(b)) when no companion of b is at hand: 3 packed instructions
+//   a b      = b.xx a + b.yy (j a),      j a  = a.yx * {-1, 1}
+//   a conj b = b.xx a + b.yy (-j a),    -j a  = a.yx * { 1,-1}
+template <bool CONJ> __device__ __forceinline__ v2f pk_cmulc(v2f a, v2f b) {
+    return pk_fma(b.yy * a.yx, CONJ ? mk2(1.0f, -1.0f) : mk2(-1.0f, 1.0f), b.xx * a);
+}
+
 template <bool INV> __device__ __forceinline__ void pk_fft4(v2f& a0, v2f& a1, v2f& a2, v2f& a3) {
     const v2f t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, d = a1 - a3;
     a0 = t0 + t2;

@@ -13,6 +13,12 @@
 //     hipcc emits v_pk_add/mul/fma_f32 natively (1258 packed ops per TWO segments, no asm):
 //     235 VGPRs -> 2 waves/SIMD, 74 KB LDS; numerically identical, 0.48 ms vs 0.45 ms -- the
 //     eight barriers per pass are exposed at that occupancy;
+//   * the same arithmetic on ext_vector_type(2) values in the forms of cpk.hip.h (hipcc emits
+//     v_pk_add/fma_f32 with op_sel and SGPR-pair constants, no shuffles: 702 packed + far fewer
+//     scalar ops; this is what the channelizer kernel uses): the 64-bit register pairs cost
+//     more VGPRs than the halved issue count buys -- 372 B/lane of scratch at 128 VGPRs
+//     (0.86 ms), still 84 B at 168 VGPRs and 3 waves/SIMD (0.55 ms) vs 0.41 ms scalar; the
+//     grouped decimators 0.36 / 0.43 ms vs 0.33 / 0.36 ms;
 //   * 16-byte loads by lane pairs (as fir_fft_kernel does) in the grouped decimator kernel, with
 //     segments moved to even starts: 248 VGPRs, decim-8 0.36 ms vs 0.33 ms with 8-byte loads;
 //   * non-temporal loads/stores for the sample stream: +-1 %;
