@@ -407,12 +407,27 @@ __global__ __launch_bounds__(kFftNT, 2) void fir_fft_dec_kernel(const FftArgs a)
             float2 y[16];
 #pragma unroll
             for (int k = 0; k < 16; k++) y[k] = cmulc<false>(v[rev16(k)], hf[k]);
-            fft16<true>(y);
+            // Pass C' pruned to the NS = 16/DEC kept outputs n0 = s*DEC:
+            //   Y[s*DEC] = sum_{r < NS} e^{+j 2pi r s / NS} * (sum_{k == r mod NS} y[k])
+            // (16 complex adds at DEC = 8 instead of the 72 of a full radix-16 butterfly)
+            float2 gsum[NS];
+#pragma unroll
+            for (int r = 0; r < NS; r++) {
+                gsum[r] = y[r];
+#pragma unroll
+                for (int k = r + NS; k < 16; k += NS) gsum[r] = cadd(gsum[r], y[k]);
+            }
+            if constexpr (NS == 4) fft4<true>(gsum[0], gsum[1], gsum[2], gsum[3]);
+            if constexpr (NS == 2) {
+                const float2 e = gsum[0], o = gsum[1];
+                gsum[0] = cadd(e, o);
+                gsum[1] = csub(e, o);
+            }
             // staging is only read after the group's last segment (barrier below): no hazard here
 #pragma unroll
             for (int s = 0; s < NS; s++) {
                 const int n0 = s * DEC;
-                stage[(bb * NACT + hi * NS + s) * kFftRow2 + lo] = (n0 == 0) ? y[rev16(0)] : cmulc<true>(y[rev16(n0)], tb[n0]);
+                stage[(bb * NACT + hi * NS + s) * kFftRow2 + lo] = (n0 == 0) ? gsum[0] : cmulc<true>(gsum[s], tb[n0]);
             }
             if (bb + 1 < DEC) {
 #pragma unroll

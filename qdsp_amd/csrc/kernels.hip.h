@@ -26,9 +26,11 @@ template <> struct Smp<2> {
 };
 
 __device__ __forceinline__ void mac(float& acc, float h, float x) { acc = fmaf(h, x, acc); }
+// complex sample x real tap: ONE v_pk_fma_f32 (both lanes are IEEE fmas: bit-identical to two fmaf)
+typedef float v2f_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void mac(float2& acc, float h, float2 x) {
-    acc.x = fmaf(h, x.x, acc.x);
-    acc.y = fmaf(h, x.y, acc.y);
+    const v2f_t r = __builtin_elementwise_fma((v2f_t){h, h}, (v2f_t){x.x, x.y}, (v2f_t){acc.x, acc.y});
+    acc = make_float2(r.x, r.y);
 }
 
 // ---- NCO ------------------------------------------------------------------------------
