@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kFftNT, (DEC == 1 && !ROT) ? 4 : 3) void fir_fft_ke
             } else {
                 v = a.in[g];
                 if (ROT) {
-                    const double2 p = fx_phasor(a.phase0 + (unsigned long long)g * a.dphase);
+                    const double2 p = fx_phasor(a.phase_in0 + (unsigned long long)g * a.dphase);
                     const float gain = fmaf((float)(int)(g & 511), a.gm1, 1.0f);
                     v = cmulc<false>(v, make_float2((float)p.x * gain, (float)p.y * gain));
                 }
@@ -104,10 +104,10 @@ __global__ __launch_bounds__(kFftNT, (DEC == 1 && !ROT) ? 4 : 3) void fir_fft_ke
     tbl[(t >> 4) * 17 + (t & 15)] = a.TB[t];
     const float2* tb = tbl + lo * 17;
 
-    float2 pl = make_float2(1.0f, 0.0f);   // exp(j 2pi t dphase)
+    float2 pl = make_float2(1.0f, 0.0f);   // exp(j 2pi e dphase), e = element of the lane's outputs
     double2 pb = make_double2(1.0, 0.0);   // exp(j 2pi (phase0 + seg0 dphase)) of the current block
     if (ROT) {
-        const double2 p = fx_phasor((unsigned long long)te * a.dphase);
+        const double2 p = fx_phasor((unsigned long long)(DEC == 1 ? te : e0) * a.dphase);
         pl = make_float2((float)p.x, (float)p.y);
         pb = fx_phasor(a.phase0 + (unsigned long long)((long long)blockIdx.x * a.L - a.seg_shift) * a.dphase);
     }
@@ -139,23 +139,40 @@ __global__ __launch_bounds__(kFftNT, (DEC == 1 && !ROT) ? 4 : 3) void fir_fft_ke
             for (int n2 = 0; n2 < 16; n2++) {
                 const long long g = seg0 + n2 * 256 + te;
                 float2 x = make_float2(0.0f, 0.0f);
-                if (g < 0) { if (g + H >= 0) x = a.hist[g + H]; }
-                else if (g < a.count) x = a.in[g];
+                if (g < 0) {
+                    if (g + H >= 0) {
+                        x = a.hist[g + H];
+                        if (ROT) {   // the history is kept rotated: back to raw samples (first segment only)
+                            const double2 p = fx_phasor(a.phase_in0 + (unsigned long long)g * a.dphase);
+                            x = cmulc<true>(x, make_float2((float)p.x, (float)p.y));
+                        }
+                    }
+                } else if (g < a.count) x = a.in[g];
                 v[n2] = x;
             }
         }
+        // ROT: VOLK's magnitude sawtooth 1 + (g mod 512)*gm1 stays on the INPUT samples (a real scale; it
+        // takes two values per lane and segment at g = seg0 + te + 256 n2, since adding 256 toggles bit 8
+        // of g mod 512); the phasor goes on the kept OUTPUTS (positions seg0 + e + 256 n2).
+        float2 q = make_float2(1.0f, 0.0f);
         if (ROT) {
-            const float2 q = cmulc<false>(make_float2((float)pb.x, (float)pb.y), pl);
+            if (a.gm1 != 0.0f) {
+                const int gb = (int)((seg0 + te) & 511);
+                const float g0 = fmaf((float)gb, a.gm1, 1.0f), g1 = fmaf((float)(gb ^ 256), a.gm1, 1.0f);
+                const bool nohist = seg0 >= 0;
 #pragma unroll
-            for (int n2 = 0; n2 < 16; n2++) {
-                const long long g = seg0 + n2 * 256 + te;
-                const float gain = fmaf((float)(int)(g & 511), a.gm1, 1.0f);
-                float2 ph = (n2 == 0) ? q : cmulc<false>(q, a.wtab[n2]);
-                ph = make_float2(ph.x * gain, ph.y * gain);
-                if (interior || g >= 0) v[n2] = cmulc<false>(v[n2], ph);   // history is already rotated
+                for (int n2 = 0; n2 < 16; n2++) {
+                    const float gg = (n2 & 1) ? g1 : g0;
+                    if (nohist || seg0 + n2 * 256 + te >= 0) v[n2] = make_float2(v[n2].x * gg, v[n2].y * gg);   // (history carries its gain)
+                }
             }
+            q = cmulc<false>(make_float2((float)pb.x, (float)pb.y), pl);
             pb = dcmul(pb, a.rot_step);
         }
+        auto rot_out = [&](int n2, float2 y) {
+            if (!ROT) return y;
+            return cmulc<false>(y, (n2 == 0) ? q : cmulc<false>(q, a.wtab[n2]));
+        };
         // ---- pass A (over n2) + twiddle W4096^(t*k0) -----------------------------------
         fft16<false>(v);
         if constexpr (DEC > 1) {
@@ -214,7 +231,7 @@ __global__ __launch_bounds__(kFftNT, (DEC == 1 && !ROT) ? 4 : 3) void fir_fft_ke
                 for (int n2 = 0; n2 < 16; n2++) {
                     const long long p1 = o0 + n2 * 256 + 1;
                     const long long n = p1 / a.decm;
-                    if (n2 * 256 + te >= a.ov && p1 - n * a.decm == 0 && n < a.nout) a.out[n] = v[rev16(n2)];
+                    if (n2 * 256 + te >= a.ov && p1 - n * a.decm == 0 && n < a.nout) a.out[n] = rot_out(n2, v[rev16(n2)]);
                 }
             } else if (interior && a.vec) {
                 float4* __restrict__ o4 = reinterpret_cast<float4*>(a.out + seg0 + (te & ~1)) + half * 8 * 128;
@@ -273,7 +290,7 @@ __global__ __launch_bounds__(kFftNT, (DEC == 1 && !ROT) ? 4 : 3) void fir_fft_ke
                 for (int n2 = 0; n2 < 16; n2++) {
                     const int i = n2 * 256 + e0;
                     const long long n = nb + i / DEC;
-                    if (i >= a.ov && n < a.nout) a.out[n] = v[rev16(n2)];
+                    if (i >= a.ov && n < a.nout) a.out[n] = rot_out(n2, v[rev16(n2)]);
                 }
             }
         }
@@ -308,7 +325,7 @@ __global__ __launch_bounds__(kFftNT, 2) void fir_fft_dec_kernel(const FftArgs a)
             } else {
                 v = a.in[g];
                 if (ROT) {
-                    const double2 p = fx_phasor(a.phase0 + (unsigned long long)g * a.dphase);
+                    const double2 p = fx_phasor(a.phase_in0 + (unsigned long long)g * a.dphase);
                     const float gain = fmaf((float)(int)(g & 511), a.gm1, 1.0f);
                     v = cmulc<false>(v, make_float2((float)p.x * gain, (float)p.y * gain));
                 }
@@ -332,9 +349,9 @@ __global__ __launch_bounds__(kFftNT, 2) void fir_fft_dec_kernel(const FftArgs a)
     tbl[(t >> 4) * 17 + (t & 15)] = a.TB[t];
     const float2* tb = tbl + lo * 17;
 
-    float2 pl = make_float2(1.0f, 0.0f);
+    float2 pl = make_float2(1.0f, 0.0f);   // exp(j 2pi e0 dphase): the lane's outputs sit at elements e0 + 256 n2
     if (ROT) {
-        const double2 p = fx_phasor((unsigned long long)t * a.dphase);
+        const double2 p = fx_phasor((unsigned long long)e0 * a.dphase);
         pl = make_float2((float)p.x, (float)p.y);
     }
 
@@ -350,8 +367,15 @@ __global__ __launch_bounds__(kFftNT, 2) void fir_fft_dec_kernel(const FftArgs a)
                 const long long g = seg0 + n2 * 256 + t;
                 float2 x = make_float2(0.0f, 0.0f);
                 if (b < a.nblocks) {
-                    if (g < 0) { if (g + H >= 0) x = a.hist[g + H]; }
-                    else if (g < a.count) x = a.in[g];
+                    if (g < 0) {
+                        if (g + H >= 0) {
+                            x = a.hist[g + H];
+                            if (ROT) {   // the history is kept rotated: back to raw samples (first segment only)
+                                const double2 p = fx_phasor(a.phase_in0 + (unsigned long long)g * a.dphase);
+                                x = cmulc<true>(x, make_float2((float)p.x, (float)p.y));
+                            }
+                        }
+                    } else if (g < a.count) x = a.in[g];
                 }
                 v[n2] = x;
             }
@@ -362,26 +386,31 @@ __global__ __launch_bounds__(kFftNT, 2) void fir_fft_dec_kernel(const FftArgs a)
 #pragma unroll 1
     for (int grp = blockIdx.x; grp < ngroups; grp += a.nwg) {
         const int b0 = grp * DEC;
-        // NCO phasor of the group's first segment from the exact fixed-point phase (one FP64
-        // sincos per group and lane); later segments follow by an FP64 rotation of L samples.
-        double2 pb = make_double2(1.0, 0.0);
-        if (ROT) pb = fx_phasor(a.phase0 + (unsigned long long)((long long)b0 * a.L - a.seg_shift) * a.dphase);
+        // Output NCO (ROT): every value this lane stores is a kept output of segment b0 + wbb, at positions
+        // seg0 + e0 + 256 n2 -- one exact fixed-point phasor per group and lane (computed here, while few
+        // registers are live), 16 rotations per GROUP (an input-side NCO rotates 16 samples per lane and
+        // SEGMENT).
+        float2 q = make_float2(1.0f, 0.0f);
+        if (ROT) {
+            const long long sego = (long long)(b0 + wbb) * a.L - a.seg_shift;
+            const double2 pb = fx_phasor(a.phase0 + (unsigned long long)sego * a.dphase);
+            q = cmulc<false>(make_float2((float)pb.x, (float)pb.y), pl);
+        }
         float2 v[16], vn[16];
         load_segment(b0, v);
 #pragma unroll 1
         for (int bb = 0; bb < DEC; bb++) {
             const int b = b0 + bb;
-            const long long seg0 = (long long)b * a.L - a.seg_shift;
-            if (ROT) {
-                const float2 q = cmulc<false>(make_float2((float)pb.x, (float)pb.y), pl);
-                pb = dcmul(pb, a.rot_step);
+            if (ROT && a.gm1 != 0.0f) {
+                // VOLK's magnitude sawtooth stays on the input samples (see fir_fft_kernel)
+                const long long seg0 = (long long)b * a.L - a.seg_shift;
+                const int gb = (int)((seg0 + t) & 511);
+                const float g0 = fmaf((float)gb, a.gm1, 1.0f), g1 = fmaf((float)(gb ^ 256), a.gm1, 1.0f);
+                const bool nohist = seg0 >= 0;
 #pragma unroll
                 for (int n2 = 0; n2 < 16; n2++) {
-                    const long long g = seg0 + n2 * 256 + t;
-                    const float gain = fmaf((float)(int)(g & 511), a.gm1, 1.0f);
-                    float2 ph = (n2 == 0) ? q : cmulc<false>(q, a.wtab[n2]);
-                    ph = make_float2(ph.x * gain, ph.y * gain);
-                    if (g >= 0) v[n2] = cmulc<false>(v[n2], ph);   // history is already rotated
+                    const float gg = (n2 & 1) ? g1 : g0;
+                    if (nohist || seg0 + n2 * 256 + t >= 0) v[n2] = make_float2(v[n2].x * gg, v[n2].y * gg);
                 }
             }
             // ---- pass A + twiddle ----------------------------------------------------------
@@ -463,7 +492,9 @@ __global__ __launch_bounds__(kFftNT, 2) void fir_fft_dec_kernel(const FftArgs a)
         for (int n2 = 0; n2 < 16; n2++) {
             const int i = n2 * 256 + e0;
             const long long n = nb + i / DEC;
-            if (b < a.nblocks && i >= a.ov && n < a.nout) a.out[n] = v[rev16(n2)];
+            float2 y = v[rev16(n2)];
+            if (ROT) y = cmulc<false>(y, (n2 == 0) ? q : cmulc<false>(q, a.wtab[n2]));
+            if (b < a.nblocks && i >= a.ov && n < a.nout) a.out[n] = y;
         }
         // next group's pass-A write to `lds` is behind that group's first barrier; its staging
         // writes are behind several more: no extra barrier needed here.

@@ -27,7 +27,7 @@ constexpr int kFftLdsElems = 16 * kFftRow1;  // 4352 >= 256*17 = 4352
 struct FftArgs {
     const float2* in;
     float2* out;
-    const float2* hist;       // H samples (already rotated for the fused VFO)
+    const float2* hist;       // H samples (rotated by the NCO for the fused VFO, as the direct kernels keep it)
     float2* hist_next;
     const float2* Hf;         // [256][16]: Hf[(k0*16+k1)*16 + k2] = FFT(taps reversed)[k0 + 16 k1 + 256 k2] / F
     const float2* TA;         // [256][16]: exp(-j 2pi t k / 4096)
@@ -37,18 +37,21 @@ struct FftArgs {
     int H;                    // history length (ntaps-1 for the FIR, taps per phase for the resampler)
     int dec;                  // 1, 2, 4, 8, 16: decimation handled by pruning the inverse transform
     int decm;                 // dec == 1 only: keep every decm-th output of the full inverse (1 = FIR)
-    int rot;                  // 1: rotate `in` by the NCO while loading
+    int rot;                  // 1: fused VFO -- Hf holds the spectrum of taps * exp(j k dphase), outputs are rotated
     int ov;                   // leading invalid elements of a segment (multiple of dec)
     int seg_shift;            // segment b starts at stream position b*L - seg_shift
     int L;                    // stream positions covered per segment = 4096 - ov
     int nblocks;
     int nwg;                  // persistent workgroups (grid = nwg + 1; the last one hands over history)
     int vec;                  // 1: in/out 16-byte aligned and segments start on even samples -> float4 path
-    // NCO (rot only)
-    unsigned long long phase0, dphase;
-    double2 rot_step;         // exp(j 2pi nwg*L*dphase): block b -> b + nwg
+    // NCO (rot only).  x[j] exp(j phi(j)) filtered by h == exp(j phi(p - (N-1))) * (x filtered by
+    // h[k] exp(j k dphase)) at output position p: the input is never rotated, only the KEPT outputs are.
+    unsigned long long phase_in0;   // phase of in[0] (history hand-over, de-rotation of the history)
+    unsigned long long phase0;      // phase_in0 - (ntaps-1)*dphase: output at position p gets phase0 + p*dphase
+    unsigned long long dphase;
+    double2 rot_step;         // exp(j 2pi nwg*L*dphase): block b -> b + nwg (per-segment kernel)
     float2 wtab[16];          // exp(j 2pi 256*n2*dphase)
-    float gm1;                // |phase_inc| - 1 (VOLK magnitude sawtooth), 0 = off
+    float gm1;                // |phase_inc| - 1 (VOLK magnitude sawtooth: a real scale of the input samples), 0 = off
 };
 
 // Defined in fft_fir.hip (its own translation unit: built with -fno-slp-vectorize, see there).

@@ -69,6 +69,7 @@ struct Engine {
     float2* d_fft_TA = nullptr;
     float2* d_fft_TB = nullptr;
     int fft_ntaps = -1;         // tap count d_fft_H was built for (-1: not built)
+    unsigned long long fft_dphase = 0;   // NCO increment d_fft_H was built for (fused VFO), 0 otherwise
     std::vector<float> taps_host;
     // tuning / introspection
     int R = 0, NT = 0;          // 0 = pick automatically
@@ -357,7 +358,9 @@ bool fft_eligible(const Engine* e, int64_t count) {
 }
 
 int fft_prepare(Engine* e) {
-    if (e->fft_ntaps == e->ntaps && e->d_fft_H) return 0;
+    // fused VFO: the spectrum is that of taps[k] * exp(j k dphase) (fft_fir.hip.h), so it follows the NCO
+    const unsigned long long key_dphase = e->rotate ? e->dphase : 0;
+    if (e->fft_ntaps == e->ntaps && e->d_fft_H && e->fft_dphase == key_dphase) return 0;
     constexpr int F = qk::kFftN;
     const long double two_pi = 6.283185307179586476925286766559005768L;
     std::vector<long double> cs(F), sn(F);
@@ -369,13 +372,25 @@ int fft_prepare(Engine* e) {
     // g[j] = taps[N-1-j]:  c[p] = sum_j g[j] s[p-j] = sum_k taps[k] s[p-(N-1)+k];
     // Hf[k] = sum_j g[j] exp(-j 2pi jk/F) / F
     std::vector<float2> Hp(F), TA(256 * 16), TB(16 * 16);
+    std::vector<long double> gr(N), gi(N);
+    for (int j = 0; j < N; j++) {
+        const long double h = (long double)e->taps_host[N - 1 - j];
+        long double c = 1.0L, sn_ = 0.0L;
+        if (e->rotate) {
+            const long double tt = ldexpl((long double)e->dphase, -64) * (long double)(N - 1 - j);
+            c = cosl(two_pi * (tt - floorl(tt)));
+            sn_ = sinl(two_pi * (tt - floorl(tt)));
+        }
+        gr[j] = h * c;
+        gi[j] = h * sn_;
+    }
     for (int k = 0; k < F; k++) {
         long double re = 0.0L, im = 0.0L;
         for (int j = 0; j < N; j++) {
-            const long double gj = (long double)e->taps_host[N - 1 - j];
             const int idx = (int)(((long long)j * k) % F);
-            re += gj * cs[idx];
-            im -= gj * sn[idx];
+            // (gr + j gi)(cs - j sn)
+            re += gr[j] * cs[idx] + gi[j] * sn[idx];
+            im += gi[j] * cs[idx] - gr[j] * sn[idx];
         }
         const int k0 = k & 15, k1 = (k >> 4) & 15, k2 = k >> 8;
         Hp[(k0 * 16 + k1) * 16 + k2] = make_float2((float)(re / F), (float)(im / F));
@@ -391,8 +406,10 @@ int fft_prepare(Engine* e) {
         HIPCHK(hipMemcpy(e->d_fft_TA, TA.data(), sizeof(float2) * TA.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(e->d_fft_TB, TB.data(), sizeof(float2) * TB.size(), hipMemcpyHostToDevice));
     }
+    HIPCHK(hipDeviceSynchronize());   // (retune / new taps: nothing in flight may still read the old spectrum)
     HIPCHK(hipMemcpy(e->d_fft_H, Hp.data(), sizeof(float2) * F, hipMemcpyHostToDevice));
     e->fft_ntaps = N;
+    e->fft_dphase = key_dphase;
     return 0;
 }
 
@@ -446,7 +463,8 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
     if (nwg > units) nwg = units;
     a.nwg = nwg;
     if (a.rot) {
-        a.phase0 = e->phase;
+        a.phase_in0 = e->phase;
+        a.phase0 = e->phase - (unsigned long long)(e->ntaps - 1) * e->dphase;
         a.dphase = e->dphase;
         a.gm1 = e->volk_gain ? e->gm1 : 0.0f;
         // segment -> next segment handled by the same workgroup: L samples (grouped kernel),
