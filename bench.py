@@ -53,6 +53,8 @@ WORKLOADS = {
     "xlate": dict(ntaps=0, decim=1, rot=True, bytes=16.0, flops=6.0),
     # BASELINE configs[4]: 64 channels at (c - 31.5) fs/64, 256 taps, decimate 64: 8 B in + 64*8/64 B out
     "chan64": dict(ntaps=256, decim=64, rot=True, bytes=16.0, flops=1408.0, nchan=64),
+    # its oversampled variant (SURVEY 8d config 5 "and M = 8"): 8 B in + 64*8/8 B out per input sample
+    "chan64m8": dict(ntaps=256, decim=8, rot=True, bytes=72.0, flops=16384.0, nchan=64),
 }
 
 
@@ -73,9 +75,9 @@ def make_op(ops, name: str, device: int):
     w = WORKLOADS[name]
     if name == "xlate":
         return ops.Xlator(phase_inc=ops.phase_delta(1.0, 0.1234), device=device, max_block=0)
-    if name == "chan64":
+    if name in ("chan64", "chan64m8"):
         incs = [ops.phase_delta(1.0, -(c - 31.5) / 64.0) for c in range(64)]
-        return ops.Channelizer(lowpass_taps(256, 1.0 / 128.0), 1, 64, incs, device=device, max_block=0)
+        return ops.Channelizer(lowpass_taps(256, 1.0 / 128.0), 1, w["decim"], incs, device=device, max_block=0)
     taps = lowpass_taps(w["ntaps"], 1.0 / 16.0) if w["ntaps"] != 63 else None
     if taps is None:
         import numpy as np
@@ -210,7 +212,7 @@ def main():
     w = WORKLOADS[args.workload]
     n = 1 << args.log2n
     op = make_op(ops, args.workload, local_rank)
-    is_chan = args.workload == "chan64"
+    is_chan = args.workload in ("chan64", "chan64m8")
     has_hist = args.workload != "xlate"
     has_nco = w["rot"]
     H = op.history_len if has_hist else 0
@@ -364,7 +366,7 @@ def main():
         # per lane and wave tile (16 output times x 64 channels = 1024 input samples per wave): 64 complex
         # MACs (512), radix-16 (~200), twiddles (~90), radix-4 across the quad (~220), per-channel
         # rotation (~320): ~1350 FLOP x 64 lanes / 1024 input samples
-        flops = 84.0
+        flops = 84.0 * (64 // w["decim"])
     achieved_tf = flops * n / (kms * 1e-3) / 1e12
 
     if rank == 0:
@@ -390,6 +392,7 @@ def main():
                     "xlate_fir_decim8": "fused NCO + 256-tap FIR + decimate-by-8 (BASELINE configs[2])",
                     "xlate": "NCO frequency translator alone",
                     "chan64": "64-channel polyphase channelizer, 256 taps, decimate 64 (BASELINE configs[4])",
+                    "chan64m8": "64-channel polyphase channelizer oversampled by 8: 256 taps, decimate 8 (BASELINE configs[4], M = 8 variant)",
                 }[args.workload],
                 "name": args.workload,
                 "samples_per_gpu_per_step": n,

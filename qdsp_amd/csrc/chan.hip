@@ -40,11 +40,9 @@
 
 namespace qk {
 
-constexpr int kChK = 64;                 // channels == branches == decimation
 constexpr int kChT = 16;                 // output times per wave tile
 constexpr int kChRowT = 68;              // T[n'][mu] row pitch: lanes (n', sub) read 4n' + sub (mod 32): conflict-free
 constexpr int kChWaveLds = kChT * kChRowT + 2 * 64;   // float2 elements per wave: T + {A_c, j A_c}[64]
-constexpr int kChRows = kChT - 1 + 4;    // 19 staged rows at 256 taps
 
 // quad_perm of both lanes of a packed pair.  One 64-bit update_dpp (expanded to two v_mov_b32_dpp):
 // with two 32-bit mov_dpp calls hipcc (ROCm 7.2) keeps only the first and feeds it to both halves of the
@@ -58,7 +56,14 @@ template <int CTRL> __device__ __forceinline__ v2f dpp_quad(v2f v) {
 #endif
 }
 
-template <bool INV>   // INV: channel c sits at +c/64 turn per sample relative to channel 0, else -c/64
+// INV: channel c sits at +c/64 turn per sample relative to channel 0, else -c/64.
+// M: decimation, 64 (critically sampled) or 8 / 16 / 32 (oversampled by 64/M): the tap window then
+// advances M < 64 samples per output, so (a) the 4 rows an output needs are loaded per output (they
+// are not the neighbours' rows any more; the few KB a tile touches stay in L1/L2) and (b) the channel
+// phase exp(+-j 2pi c j/64) at j = M n' - P + k leaves a root of unity exp(+-j 2pi c M n'/64) per
+// output time that the DFT does not cover: its tile part rides in A_c, its in-tile part depends on
+// (c0, n') only and is applied with the wave twiddle.
+template <bool INV, int M>
 __global__ __launch_bounds__(256, 3) void chan_uniform_kernel(const ChanArgs a) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int t = threadIdx.x;
@@ -78,13 +83,20 @@ __global__ __launch_bounds__(256, 3) void chan_uniform_kernel(const ChanArgs a) 
     const int l = t & 63, wv = t >> 6;
     v2f* T = reinterpret_cast<v2f*>(lds + wv * kChWaveLds);                   // [16][68]
     float4* tab = reinterpret_cast<float4*>(lds + wv * kChWaveLds + kChT * kChRowT);   // [64] {A_c, j A_c} of this tile
-    float4* twl = reinterpret_cast<float4*>(lds + 4 * kChWaveLds);             // [sub][c0] {w, j w}, w = exp(+-j 2pi c0 sub / 64)
-    float2* cst = lds + 4 * kChWaveLds + 128;                                  // [64] {theta_c, gm1_c}
+    // Tables indexed by channel c = c0 + 16 c1 are stored at slot 4 c0 + c1 (kSlot): the four lanes of a quad
+    // read c1 = 0..3 of one c0 in the same instruction, and entries 16 apart would share their banks.
+    float4* twl = reinterpret_cast<float4*>(lds + 4 * kChWaveLds);             // [c0][sub] {w, j w}, w = exp(+-j 2pi c0 sub / 64)
+    float2* cst = lds + 4 * kChWaveLds + 128;                                  // [kSlot(c)] {theta_c, gm1_c}
+    float4* rootl = reinterpret_cast<float4*>(lds + 4 * kChWaveLds + 192);     // [i < 64/M] {w, j w}, w = exp(+-j 2pi i M / 64)   (M < 64)
+    auto kSlot = [](int c) { return ((c & 15) << 2) | (c >> 4); };
     if (t < 64) {
-        float2 w = a.tw64[((t & 15) * (t >> 4)) & 63];   // exp(-j 2pi m / 64); conjugated when INV
+        float2 w = a.tw64[((t >> 2) * (t & 3)) & 63];    // exp(-j 2pi m / 64); conjugated when INV
         if (INV) w.y = -w.y;
         twl[t] = make_float4(w.x, w.y, -w.y, w.x);
-        cst[t] = make_float2((float)((double)(a.ddelta[t] * (long long)kChK) * 3.4061215800865545e-19), a.gm1[t]);   // 2pi / 2^64
+        cst[kSlot(t)] = make_float2((float)((double)(a.ddelta[t] * (long long)M) * 3.4061215800865545e-19), a.gm1[t]);   // 2pi / 2^64
+        float2 r = a.tw64[(t * M) & 63];
+        if (INV) r.y = -r.y;
+        rootl[t] = make_float4(r.x, r.y, -r.y, r.x);     // only the first 64/M entries are distinct / used
     }
     __syncthreads();                                 // the only workgroup barrier: once per launch
 
@@ -92,7 +104,7 @@ __global__ __launch_bounds__(256, 3) void chan_uniform_kernel(const ChanArgs a) 
     // 3 shared rows meet in one L2, measured 8 % SLOWER -- the 64 output rows are then written at 8
     // distant fronts instead of one)
     const int gw = (int)blockIdx.x * 4 + wv, nwaves = a.nwg * 4;
-    const long long tile_pos = (long long)kChT * kChK;                    // stream positions per tile
+    const long long tile_pos = (long long)kChT * M;                       // stream positions per tile
 
     // ---- branch role: lane = staged column p ------------------------------------------------------
     v2f g[4], gj[4];                                 // complex taps 64q + p and j * taps
@@ -105,64 +117,73 @@ __global__ __launch_bounds__(256, 3) void chan_uniform_kernel(const ChanArgs a) 
     const int mu = (l - P) & 63;
     // ---- DFT role: lane = (n' = l >> 2, sub = l & 3) ------------------------------------------------
     const int nq = l >> 2, sub = l & 3;
-    const float4* __restrict__ tw = twl + sub * 16;
+    const float4* __restrict__ tw = twl + sub;          // entry c0 at tw[4 c0]
     const int c1 = ((sub & 1) << 1) | (sub >> 1);    // radix-4 output this lane keeps (bit-reversed quad index)
     const v2f sA = (sub & 2) ? mk2(-1.0f, -1.0f) : mk2(1.0f, 1.0f), sB = (sub & 1) ? mk2(-1.0f, -1.0f) : mk2(1.0f, 1.0f);
     // between the two radix-2 stages lane 3 takes the -+j twiddle; W(n') = exp(j 64 n' dphi_0) rides along
-    v2f M, Mj;
+    v2f Mq, Mqj;
     {
-        const double2 w = fx_phasor((unsigned long long)(kChK * nq) * a.dphase0);
+        const double2 w = fx_phasor((unsigned long long)(M * nq) * a.dphase0);
         const v2f W = mk2((float)w.x, (float)w.y);
-        M = sub == 3 ? pk_mulj<INV>(W) : W;
-        Mj = jtimes(M);
+        Mq = sub == 3 ? pk_mulj<INV>(W) : W;
+        Mqj = jtimes(Mq);
     }
     // ---- channel role: lane = channel c ----------------------------------------------------------
     double2 corr, corr_step;
     {
+        // rot_c at the tile's first output = channel c's own NCO at the window start j0, + kc delta_c, + the
+        // +-c P/64 turn the DFT's branch numbering (mu = p - P) left out
         const long long del = a.ddelta[l];                      // delta_c (tiny, signed)
-        const unsigned long long inc = a.dphase0 + (unsigned long long)del;
+        const long long sc = INV ? (long long)l : -(long long)l;
+        const unsigned long long inc = a.dphase0 + (unsigned long long)del + ((unsigned long long)sc << 58);   // == dphase_c
         const long long j0 = (long long)gw * tile_pos - P;
-        corr = fx_phasor(a.phase0 + a.dphi[l] + (unsigned long long)j0 * a.dphase0 + (unsigned long long)((j0 + a.kcentre) * del));
+        corr = fx_phasor(a.phase0 + a.dphi[l] + (unsigned long long)j0 * inc + (unsigned long long)(a.kcentre * del) +
+                         ((unsigned long long)(sc * P) << 58));
         corr_step = fx_phasor((unsigned long long)(tile_pos * nwaves) * inc);
     }
 
     const v2f* __restrict__ in_or_hist = a.count > 0 ? in : hist;   // any readable address (P >= 1)
-    v2f x[kChRows];
-    auto load_rows = [&](int wt) {
-        const long long jb = (long long)wt * tile_pos - P;     // stream position of row 0, column 0
-        if (jb >= 0 && jb + 64 * kChRows <= a.count) {
-            // interior tile: 19 independent coalesced loads (rows beyond 15 + Q meet zero taps)
-            const v2f* __restrict__ src = in + jb + l;
-#pragma unroll
-            for (int r = 0; r < kChRows; r++) x[r] = src[64 * r];
-        } else {
-            // first / last tiles: history in front, zeros behind; still branch-free per row
-#pragma unroll
-            for (int r = 0; r < kChRows; r++) {
-                const long long gpos = jb + 64 * r + l;
-                const bool ok = gpos >= -(long long)P && gpos < a.count;
-                const v2f* __restrict__ src = gpos < 0 ? hist + (gpos + P) : in + gpos;
-                const v2f v = *(ok ? src : in_or_hist);
-                x[r] = ok ? v : mk2(0.0f, 0.0f);
-            }
-        }
+    constexpr int kSpan = (kChT - 1) * M + 64 * 4;   // input samples a tile's windows cover (1216 at M = 64)
+    // one sample of the first / last tiles' windows: history in front, zeros behind (branch-free)
+    auto sample = [&](long long jb, int off) -> v2f {
+        const long long gpos = jb + off;
+        const bool ok = gpos >= -(long long)P && gpos < a.count;
+        const v2f* __restrict__ src = gpos < 0 ? hist + (gpos + P) : in + gpos;
+        const v2f v = *(ok ? src : in_or_hist);
+        return ok ? v : mk2(0.0f, 0.0f);
     };
     for (int wt = gw; wt < a.ntiles; wt += nwaves) {
-        load_rows(wt);
         const long long n0 = (long long)wt * kChT;            // first output time of the tile
+        const long long jb = n0 * M - P + l;                   // stream position of this lane's column in row 0
+        const bool interior = jb - l >= 0 && jb - l + kSpan <= a.count;
         {
             const float cx = (float)corr.x, cy = (float)corr.y;
-            tab[l] = make_float4(cx, cy, -cy, cx);
+            tab[kSlot(l)] = make_float4(cx, cy, -cy, cx);
             corr = dcmul(corr, corr_step);
         }
-        // ---- branch sums: U[n'][mu] = sum_q g[64q + p] x[row n'+q][p] -------------------------------
+        // ---- branch sums: U[n'][mu] = sum_q g[64q + p] x[M n' + 64 q + p] --------------------------------
+        // Lane p only ever needs its column at stride M: x_i = x[jb + M i], and output n' uses x_{n' + (64/M) q}.
+        // 16 + 3*64/M coalesced 512-byte loads per tile (19 at M = 64, where the rows of neighbouring
+        // outputs coincide; 40 at M = 8), a sliding window in registers.
+        {
+            constexpr int RQ = 64 / M;
+            constexpr int NX = kChT + 3 * RQ;
+            v2f x[NX];
+            if (interior) {
 #pragma unroll
-        for (int n = 0; n < kChT; n++) {
-            v2f acc = mk2(0.0f, 0.0f);
+                for (int r = 0; r < NX; r++) x[r] = in[jb + M * r];
+            } else {
 #pragma unroll
-            for (int q = 0; q < 4; q++)
-                if (q < Q) acc = pk_cmac(x[n + q], g[q], gj[q], acc);
-            T[n * kChRowT + mu] = acc;
+                for (int r = 0; r < NX; r++) x[r] = sample(jb, M * r);
+            }
+#pragma unroll
+            for (int n = 0; n < kChT; n++) {
+                v2f acc = mk2(0.0f, 0.0f);
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (q < Q) acc = pk_cmac(x[n + RQ * q], g[q], gj[q], acc);
+                T[n * kChRowT + mu] = acc;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -173,7 +194,7 @@ __global__ __launch_bounds__(256, 3) void chan_uniform_kernel(const ChanArgs a) 
         for (int i = 0; i < 16; i++) U[i] = T[nq * kChRowT + sub + 4 * i];
         pk_fft16<INV>(U);                            // over i -> group c0 at U[rev16(c0)]
         const long long nn = n0 + nq;
-        const long long j = nn * kChK - P + a.kcentre;               // window-centre position of this output
+        const long long j = nn * M - P + a.kcentre;                  // window-centre position of this output
         const float jm = (float)(int)(j & 511);
         const float fl = (float)nq;
         v2f* __restrict__ o = reinterpret_cast<v2f*>(a.out) + nn;
@@ -185,17 +206,21 @@ __global__ __launch_bounds__(256, 3) void chan_uniform_kernel(const ChanArgs a) 
             for (int c0 = 0; c0 < 16; c0++) {
                 v2f z = U[rev16(c0)];
                 if (c0 != 0) {
-                    const float4 w = tw[c0];
+                    const float4 w = tw[4 * c0];
                     z = pk_cmul(z, mk2(w.x, w.y), mk2(w.z, w.w));
+                    if constexpr (M != 64) {   // exp(+-j 2pi c0 M n'/64) (c1 drops out: 16 M is a multiple of 64)
+                        const float4 r = rootl[(c0 * nq) & (64 / M - 1)];
+                        z = pk_cmul(z, mk2(r.x, r.y), mk2(r.z, r.w));
+                    }
                 }
                 // stage A: pairs (sub, sub^2), then lane 3's -+j twiddle (and W) ; stage B: pairs (sub, sub^1)
                 v2f ta = pk_fma(z, sA, dpp_quad<0x4E>(z));
-                ta = pk_cmul(ta, M, Mj);
+                ta = pk_cmul(ta, Mq, Mqj);
                 const v2f y = pk_fma(ta, sB, dpp_quad<0xB1>(ta));
                 // A_c(tile), B_c(n') and VOLK's magnitude sawtooth
                 const int c = c0 + 16 * c1;
-                const float4 A = tab[c];
-                const float2 tg = cst[c];
+                const float4 A = tab[4 * c0 + c1];
+                const float2 tg = cst[4 * c0 + c1];
                 const v2f v = pk_cmul(y, mk2(A.x, A.y), mk2(A.z, A.w));
                 const float ang = fl * tg.x;
                 const float gain = fmaf(jm, tg.y, 1.0f);
@@ -211,12 +236,20 @@ __global__ __launch_bounds__(256, 3) void chan_uniform_kernel(const ChanArgs a) 
     }
 }
 
-size_t chan_uniform_lds_bytes() { return (size_t)(4 * kChWaveLds + 128 + 64) * sizeof(float2); }
+size_t chan_uniform_lds_bytes() { return (size_t)(4 * kChWaveLds + 128 + 64 + 128) * sizeof(float2); }
 
 int launch_chan_uniform(const ChanArgs& a, int grid, hipStream_t stream) {
     const size_t lds_bytes = chan_uniform_lds_bytes();
-    if (a.inv) hipLaunchKernelGGL(chan_uniform_kernel<true>, dim3(grid), dim3(256), lds_bytes, stream, a);
-    else hipLaunchKernelGGL(chan_uniform_kernel<false>, dim3(grid), dim3(256), lds_bytes, stream, a);
+#define QK_CHAN(m)                                                                                              \
+    case m:                                                                                                     \
+        if (a.inv) hipLaunchKernelGGL((chan_uniform_kernel<true, m>), dim3(grid), dim3(256), lds_bytes, stream, a);  \
+        else hipLaunchKernelGGL((chan_uniform_kernel<false, m>), dim3(grid), dim3(256), lds_bytes, stream, a);       \
+        break;
+    switch (a.M) {
+        QK_CHAN(64) QK_CHAN(32) QK_CHAN(16) QK_CHAN(8)
+        default: return -1;
+    }
+#undef QK_CHAN
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }

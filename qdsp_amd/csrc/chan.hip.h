@@ -12,10 +12,11 @@ struct ChanArgs {
     const float2* gtaps;       // prototype taps * exp(j k dphase0), zero padded to 256
     const float2* tw64;        // exp(-j 2pi m / 64), m = 0..63
     long long count;           // input samples of this call
-    long long nout;            // outputs per channel of this call (count / 64)
+    long long nout;            // outputs per channel of this call (count / M)
     long long out_stride;      // samples between channel rows of `out`
     int P;                     // taps per phase == history length (== ntaps: interp is 1)
     int Q;                     // ceil(ntaps / 64) <= 4
+    int M;                     // decimation: 64 (critically sampled) or 8 / 16 / 32 (oversampled)
     int ntiles;                // wave tiles of 16 output times: ceil(nout / 16)
     int nwg;                   // persistent workgroups of 4 independent waves (grid = nwg + 1: the last hands over history)
     int kcentre;               // tap index the per-channel deviation is evaluated at ((ntaps-1)/2)

@@ -737,7 +737,8 @@ void chan_destroy(Chan* c) {
 // channels' fixed-point phase increments equal to channel 0's plus c * (+-2^58) to within
 // float rounding of the (cos, sin) pairs they came from.  Fills sign / deviations.
 bool chan_uniform_plan(const Chan* c, int* inv, long long* ddelta) {
-    if (c->nchan != 64 || c->interp != 1 || c->decim != 64 || c->ntaps < 1 || c->ntaps > 256) return false;
+    if (c->nchan != 64 || c->interp != 1 || c->ntaps < 1 || c->ntaps > 256) return false;
+    if (c->decim != 64 && c->decim != 32 && c->decim != 16 && c->decim != 8) return false;
     const unsigned long long d0 = c->vfo[0]->dphase;
     const long long tol = (long long)(18446744073709551616.0 * 4e-7);
     for (int sign = 1; sign >= -1; sign -= 2) {
@@ -803,6 +804,7 @@ int chan_launch_uniform(Chan* c, const void* d_in, int64_t count, int64_t nout, 
     a.out_stride = out_stride;
     a.P = P;
     a.Q = (c->ntaps + 63) / 64;
+    a.M = c->decim;
     a.ntiles = (int)((nout + 15) / 16);
     int nwg = 256 * env_int("QDSP_HIP_CHAN_WG_PER_CU", 12);  // 3 resident per CU, 4 rounds
     if (nwg > (a.ntiles + 3) / 4) nwg = (a.ntiles + 3) / 4;
