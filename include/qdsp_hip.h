@@ -122,7 +122,8 @@ int qdsp_hip_fir_f32_process_dev(void* h, const void* d_in, int64_t count, void*
 int qdsp_hip_fir_f32_process_ex(void* h, const void* in, int in_on_device, int count, void* out,
                                 int out_on_device);
 int qdsp_hip_fir_f32_set_taps(void* h, const float* taps, int ntaps);
-int qdsp_hip_fir_f32_set_mode(void* h, int mode); /* accepted; FIR<float> always runs direct form */
+int qdsp_hip_fir_f32_set_mode(void* h, int mode); /* as for cf32; the overlap-save form carries two real
+                                                    * segments per complex transform (auto: >= 96 taps) */
 int qdsp_hip_fir_f32_reset(void* h);
 int qdsp_hip_fir_f32_history_len(void* h);
 int qdsp_hip_fir_f32_get_history(void* h, float* hist);
@@ -173,7 +174,7 @@ int qdsp_hip_decim_f32_process_ex(void* h, const void* in, int in_on_device, int
                                   int out_on_device);
 int qdsp_hip_decim_f32_configure(void* h, const float* taps, int ntaps, int interp, int decim);
 int64_t qdsp_hip_decim_f32_out_size(void* h, int64_t count);
-int qdsp_hip_decim_f32_set_mode(void* h, int mode); /* accepted; real data always runs direct form */
+int qdsp_hip_decim_f32_set_mode(void* h, int mode); /* as for cf32 (interp 1; auto: >= 32 taps per branch) */
 int qdsp_hip_decim_f32_reset(void* h);
 int qdsp_hip_decim_f32_history_len(void* h);
 int qdsp_hip_decim_f32_get_history(void* h, float* hist);

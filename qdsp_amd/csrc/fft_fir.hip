@@ -51,7 +51,10 @@ __host__ __device__ constexpr int pos1(int e) { return (e >> 1) + 136 * (e & 1);
 // placed so that the wanted positions (p == -1 mod DEC) are the elements with i == 0 mod DEC,
 // i.e. the last radix-16 digit n0 is a multiple of DEC: the inverse transform keeps only
 // those 16/DEC values of n0, and passes B'/A' run on 256/DEC lanes.
-template <int DEC, bool ROT>
+//   REAL     : FIR<float> / PolyphaseResampler<float> (real samples, real taps): a real filter keeps the
+//              real and imaginary parts of its input apart, so TWO consecutive real segments ride one
+//              complex transform as re / im (segment 2b -> re, 2b+1 -> im); loads and stores are 4-byte.
+template <int DEC, bool ROT, bool REAL = false>
 __global__ __launch_bounds__(kFftNT, (DEC == 1 && !ROT) ? 4 : 3) void fir_fft_kernel(const FftArgs a) {
     __shared__ __attribute__((aligned(16))) float2 lds[kFftLdsElems + 16 * 17];
     float2* tbl = lds + kFftLdsElems;  // pass-B twiddles W256^(lo*k), rows padded to 17
@@ -69,6 +72,16 @@ __global__ __launch_bounds__(kFftNT, (DEC == 1 && !ROT) ? 4 : 3) void fir_fft_ke
 
     if ((int)blockIdx.x == a.nwg) {
         // history hand-over (filter.h:71 / resampling.h:129): last H samples of hist ++ in
+        if constexpr (REAL) {
+            const float* inr = reinterpret_cast<const float*>(a.in);
+            const float* hr = reinterpret_cast<const float*>(a.hist);
+            float* hn = reinterpret_cast<float*>(a.hist_next);
+            for (int i = t; i < H; i += kFftNT) {
+                const long long g = a.count - H + i;
+                hn[i] = g < 0 ? hr[g + H] : inr[g];
+            }
+            return;
+        }
         for (int i = t; i < H; i += kFftNT) {
             const long long g = a.count - H + i;
             float2 v;
@@ -113,11 +126,30 @@ __global__ __launch_bounds__(kFftNT, (DEC == 1 && !ROT) ? 4 : 3) void fir_fft_ke
     }
 
     for (int b = blockIdx.x; b < a.nblocks; b += a.nwg) {
-        const long long seg0 = (long long)b * a.L - a.seg_shift;  // stream position of element 0
-        const bool interior = seg0 >= 0 && seg0 + kFftN <= a.count;
+        const long long seg0 = (long long)(REAL ? 2 * b : b) * a.L - a.seg_shift;  // stream position of element 0
+        const long long segB = seg0 + a.L;                         // REAL: the second segment of the pair
+        const bool interior = seg0 >= 0 && (REAL ? segB : seg0) + kFftN <= a.count;
         float2 v[16];
         // ---- load: the lane ends up with elements n2*256 + te, n2 = 0..15 ------------------
-        if (interior && a.vec) {
+        if constexpr (REAL) {
+            const float* __restrict__ inr = reinterpret_cast<const float*>(a.in);
+            const float* __restrict__ hr = reinterpret_cast<const float*>(a.hist);
+            if (interior) {
+#pragma unroll
+                for (int n2 = 0; n2 < 16; n2++) v[n2] = make_float2(inr[seg0 + n2 * 256 + te], inr[segB + n2 * 256 + te]);
+            } else {
+#pragma unroll
+                for (int n2 = 0; n2 < 16; n2++) {
+                    const long long gA = seg0 + n2 * 256 + te, gB = segB + n2 * 256 + te;
+                    float xa = 0.0f, xb = 0.0f;
+                    if (gA < 0) { if (gA + H >= 0) xa = hr[gA + H]; }
+                    else if (gA < a.count) xa = inr[gA];
+                    if (gB < 0) { if (gB + H >= 0) xb = hr[gB + H]; }
+                    else if (gB < a.count) xb = inr[gB];
+                    v[n2] = make_float2(xa, xb);
+                }
+            }
+        } else if (interior && a.vec) {
             // rows half*8 + r, elements (te & ~1, +1); row pitch 256 samples = 128 float4
             const float4* __restrict__ p4 = reinterpret_cast<const float4*>(a.in + seg0 + (te & ~1)) + half * 8 * 128;
 #pragma unroll
@@ -224,7 +256,23 @@ __global__ __launch_bounds__(kFftNT, (DEC == 1 && !ROT) ? 4 : 3) void fir_fft_ke
             // ---- pass A' (over k0) and store the L valid outputs --------------------------
             fft16<true>(v);
             const long long o0 = seg0 + te;  // output index == stream position (element n2*256 + te)
-            if (a.decm > 1) {
+            if constexpr (REAL) {
+                float* __restrict__ outr = reinterpret_cast<float*>(a.out);
+#pragma unroll
+                for (int n2 = 0; n2 < 16; n2++) {
+                    if (n2 * 256 + te < a.ov) continue;
+                    const float2 y = v[rev16(n2)];
+                    const long long pA = o0 + n2 * 256, pB = pA + a.L;
+                    if (a.decm > 1) {   // resampler: y[n'] sits at stream position n'*decm - 1
+                        const long long nA = (pA + 1) / a.decm, nB = (pB + 1) / a.decm;
+                        if (pA + 1 - nA * a.decm == 0 && nA < a.nout) outr[nA] = y.x;
+                        if (pB + 1 - nB * a.decm == 0 && nB < a.nout) outr[nB] = y.y;
+                    } else {
+                        if (pA < a.nout) outr[pA] = y.x;
+                        if (pB < a.nout) outr[pB] = y.y;
+                    }
+                }
+            } else if (a.decm > 1) {
                 // Any integer decimation: the full inverse ran; keep the positions p == -1 (mod decm)
                 // (y[n'] sits at stream position n'*decm - 1) -- strided 8-byte stores, 1/decm of them.
 #pragma unroll
@@ -506,7 +554,8 @@ int launch_fir_fft(const FftArgs& a, int grid, hipStream_t stream) {
     const bool r = a.rot != 0;
     switch (a.dec) {
         case 1:  // FIR, or any-decimation resampler / VFO through the strided store (a.decm)
-            if (r) hipLaunchKernelGGL((fir_fft_kernel<1, true>), dim3(grid), dim3(kFftNT), 0, stream, a);
+            if (a.real2) hipLaunchKernelGGL((fir_fft_kernel<1, false, true>), dim3(grid), dim3(kFftNT), 0, stream, a);
+            else if (r) hipLaunchKernelGGL((fir_fft_kernel<1, true>), dim3(grid), dim3(kFftNT), 0, stream, a);
             else hipLaunchKernelGGL((fir_fft_kernel<1, false>), dim3(grid), dim3(kFftNT), 0, stream, a);
             break;
         case 2:  // half the outputs are kept: the per-segment pruned inverse (128 active lanes) is enough

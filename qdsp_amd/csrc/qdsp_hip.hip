@@ -336,7 +336,13 @@ constexpr int kFftMaxTaps = 2049;   // keeps >= 2048 valid outputs per 4096-poin
 // DEC the overlap-save kernel would run with for this engine, 0 if it cannot: 1 = full inverse
 // (the FIR, and any other integer decimation through a strided store), 2/4/8/16 = pruned inverse.
 int fft_dec(const Engine* e) {
-    if (e->ch != 2 || e->L != 1 || e->ntaps < 2 || e->ntaps > kFftMaxTaps) return 0;
+    if (e->L != 1 || e->ntaps < 2 || e->ntaps > kFftMaxTaps) return 0;
+    if (e->ch == 1) {
+        // real data: two real segments per complex transform (full inverse; decimators keep every M-th output)
+        if (e->kind == KIND_FIR) return 1;
+        if (e->kind == KIND_DECIM && e->M >= 2) return 1;
+        return 0;
+    }
     if (e->kind == KIND_FIR) return 1;
     if (e->kind == KIND_DECIM || e->kind == KIND_VFO) {
         if (e->M == 2 || e->M == 4 || e->M == 8 || e->M == 16) return e->M;
@@ -353,7 +359,17 @@ bool fft_eligible(const Engine* e, int64_t count) {
     // auto: long filters on calls big enough to fill the chip with 4096-point segments
     // (measured crossovers, 2^27 samples: FIR from ~24 taps; decimators / VFO from ~64 taps whatever
     // the decimation -- scripts/tune.py)
-    const int min_taps = e->M > 1 ? env_int("QDSP_HIP_FFT_MIN_TAPS_DECIM", 64) : env_int("QDSP_HIP_FFT_MIN_TAPS", 24);
+    // real data (two segments per transform, 305 Gs/s whatever the taps at 2^26 samples): the direct form
+    // moves half the bytes per sample and stays ahead to ~96 taps (445 Gs/s at 63, 164 at 256); a real
+    // decimator keeps 1/M of a full inverse, so the direct form wins until ~32 taps per branch
+    // (decimate-by-8, 256 taps: 324 vs 321 Gs/s)
+    int min_taps;
+    if (e->ch == 1) {
+        min_taps = env_int("QDSP_HIP_FFT_MIN_TAPS_REAL", 96);
+        if (e->M > 1 && min_taps < 32 * e->M) min_taps = 32 * e->M;
+    } else {
+        min_taps = e->M > 1 ? env_int("QDSP_HIP_FFT_MIN_TAPS_DECIM", 64) : env_int("QDSP_HIP_FFT_MIN_TAPS", 24);
+    }
     return e->ntaps >= min_taps && count >= env_int("QDSP_HIP_FFT_MIN_COUNT", 1 << 16);
 }
 
@@ -453,6 +469,11 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
         a.L = qk::kFftN - a.ov;
         const int per_block = a.L / a.dec;
         a.nblocks = (int)((nout + per_block - 1) / per_block);
+    }
+    if (e->ch == 1) {   // real data: one workgroup iteration = a PAIR of real segments
+        a.real2 = 1;
+        a.vec = 0;
+        a.nblocks = (a.nblocks + 1) / 2;
     }
     // FIR: 4 workgroups resident per CU (124 VGPRs, 37 KB LDS), 16 queued per CU for balance.
     // Decimators work in groups of `dec` segments, 2 resident per CU (70 KB LDS).

@@ -609,3 +609,47 @@ def test_channelizer_time_sharded_halo(ops, gold, mode):
     torch.cuda.synchronize()
     for c in (0, 5, 33, 63):
         assert rel_rms(y2[c], y[c][cut // 64:]) < 2e-6, c
+
+
+@pytest.mark.parametrize("ntaps", [63, 256, 1000])
+def test_fir_f32_fft_path_matches_direct(ops, gold, ntaps):
+    """FIR<float> on big calls: two real segments ride one complex overlap-save transform as re / im
+    (fft_fir.hip REAL).  Same operator and state as the direct form: compare against the FP64 oracle,
+    the direct kernel, and across a mid-stream switch of form (history carried in either direction)."""
+    n = 300_001
+    rng = np.random.default_rng(ntaps)
+    x = rng.standard_normal(n).astype(np.float32)
+    taps = gold["taps63"] if ntaps == 63 else gold["taps256"] if ntaps == 256 else O.lowpass_taps_f64(1000, 0.02).astype(np.float32)
+    f = ops.Fir(taps, complex_data=False)
+    f.set_mode(f.FFT)
+    y = f.process(dev(x)).cpu().numpy()
+    assert f.last_kernel()["name"] == "fir_fft_kernel" and y.dtype == np.float32 and y.shape == (n,)
+    want = O.Fir(taps, complex_data=False, acc=O.ACC_F64).process(x)
+    assert rel_rms(y, want) < 2e-6
+    d = ops.Fir(taps, complex_data=False)
+    d.set_mode(d.DIRECT)
+    assert rel_rms(y, d.process(dev(x)).cpu().numpy()) < 2e-6
+    # ragged calls, switching form: FFT (big), direct (small), FFT again
+    g = ops.Fir(taps, complex_data=False)
+    cuts = [0, 140_003, 140_003 + 777, n]
+    parts = []
+    for i, (a, b) in enumerate(zip(cuts, cuts[1:])):
+        g.set_mode(g.DIRECT if i == 1 else g.FFT)
+        parts.append(g.process(dev(x[a:b])).cpu().numpy())
+    assert rel_rms(np.concatenate(parts), want) < 2e-6
+
+
+@pytest.mark.parametrize("M", [2, 5, 8])
+def test_resampler_f32_fft_path(ops, gold, M):
+    """PolyphaseResampler<float>, interp 1: the same transform, every M-th output kept."""
+    n = 400_000
+    x = np.random.default_rng(M).standard_normal(n).astype(np.float32)
+    taps = gold["taps256"]
+    r = ops.Resampler(taps, 1, M, complex_data=False)
+    r.set_mode(r.FFT)
+    cuts = [0, 200_000, n]                       # multiples of M: the per-block phase restart (H4) lands the same
+    y = np.concatenate([r.process(dev(x[a:b])).cpu().numpy() for a, b in zip(cuts, cuts[1:])])
+    assert r.last_kernel()["name"] == "fir_fft_kernel"
+    o = O.Resampler(taps, 1, M, complex_data=False, acc=O.ACC_F64)
+    want = np.concatenate([o.process(x[a:b]) for a, b in zip(cuts, cuts[1:])])
+    assert y.shape == want.shape and rel_rms(y, want) < 2e-6
