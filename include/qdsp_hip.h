@@ -283,6 +283,24 @@ int qdsp_hip_chan_cf32_advance(void* h, int64_t n);
 int qdsp_hip_chan_cf32_channels(void* h);
 void qdsp_hip_chan_cf32_destroy(void* h);
 
+/* ---- element-wise two-input blocks: Add / Substract / Multiply (src/dsp/math.h:7-145) ---- */
+/* out[i] = a[i] op b[i] over `count` samples; complex_data: samples are interleaved {re, im}
+ * pairs and QDSP_HIP_MATH_MUL is the complex product (volk_32fc_x2_multiply_32fc, math.h:127),
+ * add / subtract are per float (math.h:33,80).  Results are bit-identical to VOLK's generic
+ * kernels (separately rounded products and sums).  Stateless apart from staging buffers.
+ * process: host pointers, synchronous; process_ex: each side host or device (1 = device);
+ * process_dev: asynchronous on hip_stream, pointers 16-byte aligned. */
+#define QDSP_HIP_MATH_ADD 0
+#define QDSP_HIP_MATH_SUB 1
+#define QDSP_HIP_MATH_MUL 2
+int qdsp_hip_math_create(void** h, int device, int op, int complex_data, int max_block);
+int qdsp_hip_math_process(void* h, const void* a, const void* b, int count, void* out);
+int qdsp_hip_math_process_ex(void* h, const void* a, int a_dev, const void* b, int b_dev, int count,
+                             void* out, int out_dev);
+int qdsp_hip_math_process_dev(void* h, const void* d_a, const void* d_b, int64_t count, void* d_out,
+                              void* hip_stream);
+void qdsp_hip_math_destroy(void* h);
+
 /* ---- synthetic IQ source (measurement harness) ------------------------------ */
 /* Counter-based uniform [-1,1) per float component, generated on device so benchmarks are
  * HBM->HBM.  Bit-identical to oracle_synth_iq() for the same (first_sample, seed). */

@@ -52,6 +52,10 @@ def lib():
         L.oracle_resamp_build_phases.argtypes = [fp, C.c_int, C.c_int, fp]
         L.oracle_xlator_phase_delta.restype = None
         L.oracle_xlator_phase_delta.argtypes = [C.c_float, C.c_float, fp]
+        L.oracle_math_f32.restype = None
+        L.oracle_math_f32.argtypes = [C.c_int, fp, fp, fp, C.c_long]
+        L.oracle_mul_cf32.restype = None
+        L.oracle_mul_cf32.argtypes = [fp, fp, fp, C.c_long]
         L.oracle_rotator_cf32.restype = None
         L.oracle_rotator_cf32.argtypes = [fp, fp, fp, fp, C.c_long]
         L.oracle_rotator_cf32_f64.restype = None
@@ -219,6 +223,22 @@ class Vfo:
 
     def process(self, x) -> np.ndarray:
         return self.rs.process(self.xl.process(x))
+
+
+def math_op(op: int, a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """Add (0) / Substract (1) / Multiply (2) of two streams, src/dsp/math.h, VOLK-generic arithmetic.
+    complex64 inputs: add / subtract per float, multiply = complex product; float32: per element."""
+    cplx = np.iscomplexobj(a)
+    dt = np.complex64 if cplx else np.float32
+    x, y = np.ascontiguousarray(a, dtype=dt), np.ascontiguousarray(b, dtype=dt)
+    assert x.shape == y.shape
+    out = np.empty_like(x)
+    xf, yf, of = x.view(np.float32), y.view(np.float32), out.view(np.float32)
+    if cplx and op == 2:
+        lib().oracle_mul_cf32(_fp(xf), _fp(yf), _fp(of), x.size)
+    else:
+        lib().oracle_math_f32(op, _fp(xf), _fp(yf), _fp(of), xf.size)
+    return out
 
 
 def synth_iq(first_sample: int, count: int, seed: int = 1234) -> np.ndarray:

@@ -477,3 +477,22 @@ void oracle_synth_iq(float* out, long first_sample, long count, uint32_t seed) {
 }
 
 int oracle_abi_version(void) { return 1; }
+
+/* ---- element-wise two-input blocks (src/dsp/math.h) ------------------------------------------
+ * Add<T>::run       math.h:33 (volk_32fc_x2_add_32fc) / :36 (volk_32f_x2_add_32f)
+ * Substract<T>::run math.h:80,83 (volk_32f_x2_subtract_32f on 2*count floats for complex / stereo)
+ * Multiply<T>::run  math.h:127 (volk_32fc_x2_multiply_32fc) / :130 (volk_32f_x2_multiply_32f)
+ * VOLK generic kernels: one operation per element; the complex product is
+ * (ar*br - ai*bi) + j(ar*bi + ai*br) with every product and sum rounded on its own (this file is
+ * built with -ffp-contract=off).  op: 0 add, 1 subtract, 2 multiply. */
+void oracle_math_f32(int op, const float* a, const float* b, float* out, long n) {
+    for (long i = 0; i < n; i++) out[i] = op == 0 ? a[i] + b[i] : op == 1 ? a[i] - b[i] : a[i] * b[i];
+}
+void oracle_mul_cf32(const float* a, const float* b, float* out, long n) {
+    for (long i = 0; i < n; i++) {
+        const float ar = a[2 * i], ai = a[2 * i + 1], br = b[2 * i], bi = b[2 * i + 1];
+        const float rr = ar * br, ii = ai * bi, ri = ar * bi, ir = ai * br;
+        out[2 * i] = rr - ii;
+        out[2 * i + 1] = ri + ir;
+    }
+}

@@ -144,6 +144,11 @@ def load():
     sig(p + "_advance", i32, vp, i64)
     sig(p + "_channels", i32, vp)
     sig(p + "_destroy", None, vp)
+    sig("qdsp_hip_math_create", i32, pvp, i32, i32, i32, i32)
+    sig("qdsp_hip_math_process", i32, vp, vp, vp, i32, vp)
+    sig("qdsp_hip_math_process_ex", i32, vp, vp, i32, vp, i32, i32, vp, i32)
+    sig("qdsp_hip_math_process_dev", i32, vp, vp, vp, i64, vp, vp)
+    sig("qdsp_hip_math_destroy", None, vp)
     sig("qdsp_hip_synth_iq_dev", i32, i32, vp, i64, i64, C.c_uint32, vp)
     sig("qdsp_hip_last_kernel", i32, vp, C.c_char_p, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32))
     sig("qdsp_hip_time_process_dev", i32, vp, vp, i64, vp, vp, i32, fp)

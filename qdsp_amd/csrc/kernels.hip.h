@@ -57,6 +57,51 @@ __device__ __forceinline__ float2 rotate(float2 x, double2 p, long long g, float
 }
 __device__ __forceinline__ float rotate(float x, double2, long long, float) { return x; }  // CH==1: unused
 
+// ---- element-wise two-input blocks (src/dsp/math.h: Add / Substract / Multiply) -------------
+// out = a (+, -, *) b over `n4` float4s (+ a scalar tail); CPLX: * is the complex product of
+// interleaved pairs.  Products and sums are separately rounded, as VOLK's generic kernels compute
+// them: bit-identical to the C oracle.  (`#pragma clang fp contract(off)` on plain operators is what
+// keeps them apart: HIP's __fmul_rn / __fadd_rn are inline operators compiled under the default
+// contraction mode and still fuse into FMAs after inlining.)
+struct EwArgs {
+    const float* a;
+    const float* b;
+    float* out;
+    long long n;     // floats
+};
+template <int OP, bool CPLX> __device__ __forceinline__ float4 ew4(float4 x, float4 y) {
+#pragma clang fp contract(off)
+    if (OP == 0) return make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+    if (OP == 1) return make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w);
+    if (!CPLX) return make_float4(x.x * y.x, x.y * y.y, x.z * y.z, x.w * y.w);
+    return make_float4(x.x * y.x - x.y * y.y, x.x * y.y + x.y * y.x, x.z * y.z - x.w * y.w, x.z * y.w + x.w * y.z);
+}
+template <int OP, bool CPLX>
+__global__ __launch_bounds__(256) void ew_kernel(const EwArgs a) {
+    const long long n4 = a.n >> 2;
+    const float4* __restrict__ a4 = reinterpret_cast<const float4*>(a.a);
+    const float4* __restrict__ b4 = reinterpret_cast<const float4*>(a.b);
+    float4* __restrict__ o4 = reinterpret_cast<float4*>(a.out);
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) o4[i] = ew4<OP, CPLX>(a4[i], b4[i]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma clang fp contract(off)
+        // tail (< 4 floats; an even count for complex data)
+        for (long long i = n4 << 2; i < a.n; i += CPLX ? 2 : 1) {
+            if (CPLX && OP == 2) {
+                const float xr = a.a[i], xi = a.a[i + 1], yr = a.b[i], yi = a.b[i + 1];
+                a.out[i] = xr * yr - xi * yi;
+                a.out[i + 1] = xr * yi + xi * yr;
+            } else {
+                for (int k = 0; k < (CPLX ? 2 : 1); k++) {
+                    const float x = a.a[i + k], y = a.b[i + k];
+                    a.out[i + k] = OP == 0 ? x + y : OP == 1 ? x - y : x * y;
+                }
+            }
+        }
+    }
+}
+
 // ---- direct-form core -----------------------------------------------------------------
 struct CoreArgs {
     const void* in;       // count samples

@@ -16,6 +16,8 @@
 //   graph_check chain  <in.cf32> <out.cf32> <block> <taps.f32> <sampleRate> <freq> <inSR> <outSR>
 //                      source -> FrequencyXlator -> FIR -> PolyphaseResampler -> sink: three GPU
 //                      blocks in a row, the two links between them device-resident
+//   graph_check math   <in.cf32> <out.cf32> <block> add|sub|mul <sampleRate> <freq>
+//                      source -> Splitter -> { FrequencyXlator, identity } -> Add | Substract | Multiply -> sink
 //   graph_check split  <in.cf32> <out_prefix> <block> <n> <inSR> <outSR> <bw>
 //                      source -> Splitter -> n x VFO(offset_i = (i - (n-1)/2) * inSR/n) -> sinks
 #include <atomic>
@@ -29,6 +31,7 @@
 #include <vector>
 
 #include <dsp/filter.h>
+#include <dsp/math.h>
 #include <dsp/processing.h>
 #include <dsp/resampling.h>
 #include <dsp/routing.h>
@@ -296,6 +299,51 @@ int main(int argc, char** argv) {
         };
         int rc = runGraph<complex_t>(in, out, block, [&](stream<complex_t>* s) { return new Chain(s, &taps, sr, f, inSR, outSR); });
         return rc;
+    }
+    if (mode == "math" && argc >= 8) {
+        // source -> Splitter -> { FrequencyXlator, identity } -> Add | Substract | Multiply -> sink:
+        // out = op(x * nco, x), both inputs of the math block arrive over (device-resident) links
+        const std::string opname = argv[5];
+        const float sr = (float)atof(argv[6]), f = (float)atof(argv[7]);
+        Feed<complex_t> feed;
+        feed.data = readAll<complex_t>(in);
+        feed.block = block;
+        const long nblocks = (long)((feed.data.size() + block - 1) / block);
+        HandlerSource<complex_t> src(Feed<complex_t>::pull, &feed);
+        Splitter<complex_t> split(&src.out);
+        stream<complex_t> la, lb;
+        split.bindStream(&la);
+        split.bindStream(&lb);
+        FrequencyXlator<complex_t> xl(&la, sr, f);
+        Collect<complex_t> col;
+        int rc = 0;
+        auto runWith = [&](auto& blk) {
+            HandlerSink<complex_t> sink(&blk.out, Collect<complex_t>::push, &col);
+            sink.start();
+            blk.start();
+            xl.start();
+            split.start();
+            src.start();
+            const auto t0 = std::chrono::steady_clock::now();
+            while (col.blocks.load() < nblocks) {
+                std::this_thread::sleep_for(std::chrono::milliseconds(1));
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) { fprintf(stderr, "math graph timed out\n"); rc = 3; break; }
+            }
+            src.stop();
+            split.stop();
+            xl.stop();
+            blk.stop();
+            sink.stop();
+        };
+        if (opname == "add") { Add<complex_t> blk(&xl.out, &lb); runWith(blk); }
+        else if (opname == "sub") { Substract<complex_t> blk(&xl.out, &lb); runWith(blk); }
+        else if (opname == "mul") { Multiply<complex_t> blk(&xl.out, &lb); runWith(blk); }
+        else { fprintf(stderr, "math op must be add|sub|mul\n"); return 2; }
+        if (rc) { return rc; }
+        std::ofstream o(out, std::ios::binary);
+        o.write(reinterpret_cast<const char*>(col.data.data()), (std::streamsize)(col.data.size() * sizeof(complex_t)));
+        printf("math %s ok: %zu in, %zu out\n", opname.c_str(), feed.data.size(), col.data.size());
+        return 0;
     }
     if (mode == "split" && argc >= 9) {
         const int n = atoi(argv[5]);

@@ -394,3 +394,47 @@ def device_info(device: int = 0) -> dict:
 
 
 __all__ = ["Fir", "Resampler", "Xlator", "Vfo", "Channelizer", "synth_iq", "phase_delta", "device_info"]
+
+
+class Math:
+    """Add / Substract / Multiply of two streams (src/dsp/math.h:7-145): qdsp_hip_math_*."""
+
+    ADD, SUB, MUL = 0, 1, 2
+
+    def __init__(self, op: int, complex_data: bool = True, device: int = 0, max_block: int = 1_000_000):
+        self._L = capi.load()
+        self._h = C.c_void_p()
+        self.complex_data = complex_data
+        capi.check(self._L.qdsp_hip_math_create(C.byref(self._h), device, int(op), int(complex_data), max_block), "qdsp_hip_math_create")
+
+    def close(self):
+        if self._h:
+            self._L.qdsp_hip_math_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def process(self, a, b, out=None):
+        if _is_torch(a):
+            import torch
+
+            dt = torch.complex64 if self.complex_data else torch.float32
+            assert a.is_cuda and b.is_cuda and a.dtype == dt and b.dtype == dt and a.numel() == b.numel()
+            assert a.is_contiguous() and b.is_contiguous()
+            if out is None:
+                out = torch.empty_like(a)
+            stream = torch.cuda.current_stream(a.device).cuda_stream
+            capi.check(self._L.qdsp_hip_math_process_dev(self._h, a.data_ptr(), b.data_ptr(), a.numel(), out.data_ptr(), stream),
+                       "qdsp_hip_math_process_dev")
+            return out
+        dt = np.complex64 if self.complex_data else np.float32
+        x, y = np.ascontiguousarray(a, dtype=dt), np.ascontiguousarray(b, dtype=dt)
+        assert x.size == y.size
+        o = np.empty_like(x)
+        capi.check(self._L.qdsp_hip_math_process(self._h, x.ctypes.data, y.ctypes.data, x.size, o.ctypes.data), "qdsp_hip_math_process")
+        return o
+

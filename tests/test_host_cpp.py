@@ -68,6 +68,7 @@ def test_headers_keep_the_reference_surface():
         "dsp/window.h": ["generic_window", "BlackmanWindow", "BlackmanBandpassWindow", "RRCTaps", "getTapCount", "createTaps"],
         "dsp/types.h": ["struct complex_t", "struct stereo_t", "FL_M_PI 3.1415926535f", "fastPhase", "fastAmplitude", "conj()"],
         "dsp/routing.h": ["class Splitter", "bindStream", "unbindStream", "setInput"],
+        "dsp/math.h": ["class Add", "class Substract", "class Multiply", "stream<T> out", "a_count != b_count"],
         "dsp/source.h": ["class SineSource", "setBlockSize", "getBlockSize", "setFrequency", "class HandlerSource", "setHandler"],
         "dsp/sink.h": ["class HandlerSink", "class NullSink", "class FileSink"],
         "wav.h": ["class WavWriter", "writeSamples"], "wavreader.h": ["class WavReader", "readSamples", "getSampleRate", "isValid"],
@@ -203,6 +204,21 @@ def test_graph_splitter_to_vfos(harness, data):
         v = O.Vfo(float(off), 2.4e6, 240e3, 200e3, exact_nco=True, volk_gain=True)
         want = np.concatenate([v.process(x[j:j + b]) for j in range(0, len(x), b)])
         assert len(y) == len(want) and rel_rms(y, want) < 3e-6, i
+
+
+@gpu
+@pytest.mark.parametrize("op", ["add", "sub", "mul"])
+def test_graph_math_blocks(harness, data, op):
+    """source -> Splitter -> { FrequencyXlator, identity } -> Add | Substract | Multiply -> sink
+    (src/dsp/math.h): both inputs of the math block arrive over links, one of them device-resident."""
+    d, x = data
+    b = 30_000
+    run([harness, "math", str(d / "x.cf32"), str(d / f"ym_{op}.cf32"), str(b), op, "48000", "1234"])
+    y = np.fromfile(d / f"ym_{op}.cf32", dtype=np.complex64)
+    xl = O.Xlator(48000.0, 1234.0, exact=True, volk_gain=True)
+    a = np.concatenate([xl.process(x[i:i + b]) for i in range(0, len(x), b)])
+    want = O.math_op({"add": 0, "sub": 1, "mul": 2}[op], a, x)
+    assert len(y) == len(want) and rel_rms(y, want) < 2e-6
 
 
 @gpu

@@ -180,3 +180,21 @@ def test_empty_and_tiny_blocks(gold):
     assert np.array_equal(y, gold["fir_taps63"][:100]) or rel_rms(y, gold["fir_taps63"][:100]) == 0.0
     r = O.Resampler(gold["taps63"], 1, 8)
     assert len(r.process(gold["x"][:7])) == 0  # 7*1/8 = 0 outputs, history still advances
+
+
+def test_math_blocks_known_answers():
+    """src/dsp/math.h: Add / Substract per float, Multiply<complex_t> = complex product, every product
+    and sum rounded on its own (VOLK generic)."""
+    a = np.array([1 + 2j, 3 - 1j, 0.5 + 0.25j], dtype=np.complex64)
+    b = np.array([2 - 1j, 1 + 1j, -4 + 8j], dtype=np.complex64)
+    assert np.array_equal(O.math_op(0, a, b), np.array([3 + 1j, 4 + 0j, -3.5 + 8.25j], dtype=np.complex64))
+    assert np.array_equal(O.math_op(1, a, b), np.array([-1 + 3j, 2 - 2j, 4.5 - 7.75j], dtype=np.complex64))
+    assert np.array_equal(O.math_op(2, a, b), np.array([4 + 3j, 4 + 2j, -4 + 3j], dtype=np.complex64))
+    assert np.array_equal(O.math_op(2, np.float32([1, 2, 3]), np.float32([4, 5, 6])), np.float32([4, 10, 18]))
+    # separately rounded: differs from a fused evaluation on inputs chosen to show it
+    x = np.array([1.0000001 + 1.0000002j], dtype=np.complex64)
+    y = np.array([1.0000003 - 0.9999999j], dtype=np.complex64)
+    xr, xi, yr, yi = (np.float32(v) for v in (x.real[0], x.imag[0], y.real[0], y.imag[0]))
+    want = np.complex64(complex(np.float32(np.float32(xr * yr) - np.float32(xi * yi)), np.float32(np.float32(xr * yi) + np.float32(xi * yr))))
+    assert O.math_op(2, x, y)[0] == want
+
