@@ -350,6 +350,168 @@ __global__ __launch_bounds__(NT) void resamp_any_kernel(const AnyArgs a) {
     }
 }
 
+// ---- small-interp rational resampler -----------------------------------------------------
+// PolyphaseResampler<T>::run, interp L in {2,3,4,5,10}, decim M <= 8 (src/dsp/resampling.h:121-125):
+//   y[n] = sum_t phases[(n*M) % L][t] * s[(n*M)/L - P + t],   s = hist ++ in.
+// For n = L*j + c the phase (c*M) % L and the offset e_c = (c*M)/L do not depend on j:
+//   y[L*j + c] = sum_k h_c[k] * s[D + M*j + e_c - P + k]
+// i.e. L decimate-by-M filters ("sub-filters" c) over the SAME input.  The tile's input is staged once,
+// de-interleaved by M as in fir_core_kernel, and every lane runs all L sub-filters for its R consecutive j
+// with fir_core's sliding register window -- taps are wave-uniform (SGPRs) and each LDS read feeds R
+// FMAs, where resamp_any_kernel fetched a per-lane tap from memory for every MAC (3/2, 189 taps:
+// 40 -> 186 Gs/s out).  The lane ends up with R*L consecutive outputs, which go out through LDS so the
+// stores are coalesced.  R is odd, so the stride-R lane pattern needs no LDS padding and windows may start
+// at any offset.
+struct LmArgs {
+    const void* in;
+    void* out;
+    const void* hist;      // P samples
+    void* hist_next;
+    const float* taps;     // [c][m][q] = h_c[q*M + m], h_c = phases[(c*M) % L], zero padded to M*Q
+    const float* taps_t;   // M == 1 only: [q][c] = h_c[q]
+    long long count, nout;
+    int M, P, Q;           // Q = ceil(P / M)
+    int e[10];             // e_c = (c*M) / L
+    int sb;                // LDS branch stride (elements)
+    int nblocks;
+    unsigned long long phase0, dphase;
+    double2 rot_nt;        // exp(j*2pi*NT*dphase)   (ROT only)
+    float gm1;
+};
+
+template <int CH, int R, int NT, bool ROT, int L>
+__global__ __launch_bounds__(NT) void resamp_lm_kernel(const LmArgs a) {
+    static_assert(R % 2 == 1, "odd R: conflict-free stride-R LDS reads without padding");
+    using T = typename Smp<CH>::T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* lds = reinterpret_cast<T*>(smem_raw);
+    const int t = threadIdx.x;
+    const T* __restrict__ in = static_cast<const T*>(a.in);
+    const T* __restrict__ hist = static_cast<const T*>(a.hist);
+    const int P = a.P, M = a.M, Q = a.Q;
+
+    if ((int)blockIdx.x == a.nblocks) {
+        T* __restrict__ hn = static_cast<T*>(a.hist_next);
+        for (int i = t; i < P; i += NT) {
+            const long long g = a.count - P + i;
+            T v;
+            if (g < 0) {
+                v = hist[g + P];
+            } else {
+                v = in[g];
+                if (ROT) v = rotate(v, phasor_fx(a.phase0 + (unsigned long long)g * a.dphase), g, a.gm1);
+            }
+            hn[i] = v;
+        }
+        return;
+    }
+
+    constexpr int TJ = NT * R;                               // j values per tile (TJ*L outputs)
+    const long long j0 = (long long)blockIdx.x * TJ;
+    const long long base = j0 * M - P;                       // stream position of staged element 0
+    const int V = TJ + Q + 1;                                // elements per branch (e_c < M adds at most one)
+    const int U = V * M;
+    {
+        double2 ph;
+        if (ROT) ph = phasor_fx(a.phase0 + (unsigned long long)(base + t) * a.dphase);
+        for (int u = t; u < U; u += NT) {
+            const long long g = base + u;
+            T v = Smp<CH>::zero();
+            if (g < 0) {
+                if (g + P >= 0) v = hist[g + P];
+            } else if (g < a.count) {
+                v = in[g];
+                if (ROT) v = rotate(v, ph, g, a.gm1);
+            }
+            const int vv = u / M, m = u - vv * M;
+            lds[m * a.sb + vv] = v;
+            if (ROT) ph = cmul(ph, a.rot_nt);
+        }
+    }
+    __syncthreads();
+
+    T acc[L][R];
+#pragma unroll
+    for (int c = 0; c < L; c++)
+#pragma unroll
+        for (int p = 0; p < R; p++) acc[c][p] = Smp<CH>::zero();
+    if (M == 1) {
+        // pure interpolation: every sub-filter reads the SAME window (e_c = 0), so one LDS read feeds L*R
+        // FMAs; taps come transposed ([q][c]: L consecutive scalars per tap position)
+        const T* B = lds + t * R;
+        const float* __restrict__ ht = a.taps_t;
+        T win[R];
+#pragma unroll
+        for (int p = 0; p < R; p++) win[p] = B[p];
+        for (int q0 = 0; q0 < Q; q0 += R) {
+            const T* Bn = B + q0 + R;
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                if (q0 + j < Q) {
+#pragma unroll
+                    for (int c = 0; c < L; c++) {
+                        const float h = ht[(q0 + j) * L + c];
+#pragma unroll
+                        for (int p = 0; p < R; p++) mac(acc[c][p], h, win[(p + j) % R]);
+                    }
+                    win[j] = Bn[j];
+                }
+            }
+        }
+    } else
+#pragma unroll
+    for (int c = 0; c < L; c++) {
+        for (int m = 0; m < M; m++) {
+            // tap k = q*M + m of sub-filter c meets staged sample e_c + M*j + k: branch (e_c + m) % M, element j + q + (e_c + m) / M
+            const int em = a.e[c] + m;
+            const int ob = em / M, mb = em - ob * M;
+            const T* B = lds + mb * a.sb + t * R + ob;
+            const float* __restrict__ hp = a.taps + ((size_t)c * M + m) * Q;
+            T win[R];
+#pragma unroll
+            for (int p = 0; p < R; p++) win[p] = B[p];
+            int q0 = 0;
+            for (; q0 + R <= Q; q0 += R) {
+                const T* Bn = B + q0 + R;
+#pragma unroll
+                for (int j = 0; j < R; j++) {
+                    const float h = hp[q0 + j];
+#pragma unroll
+                    for (int p = 0; p < R; p++) mac(acc[c][p], h, win[(p + j) % R]);
+                    win[j] = Bn[j];
+                }
+            }
+            if (q0 < Q) {
+                const T* Bn = B + q0 + R;
+#pragma unroll
+                for (int j = 0; j < R; j++) {
+                    if (q0 + j < Q) {
+                        const float h = hp[q0 + j];
+#pragma unroll
+                        for (int p = 0; p < R; p++) mac(acc[c][p], h, win[(p + j) % R]);
+                        win[j] = Bn[j];
+                    }
+                }
+            }
+        }
+    }
+
+    // The lane holds R*L consecutive outputs; stored straight from registers every instruction would
+    // write 64 separate 8-byte pieces R*L*8 bytes apart (L2-request-bound, as the channelizer's first
+    // version was).  Pass them through LDS (the staged input is dead) and store coalesced.
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < R; p++)
+#pragma unroll
+        for (int c = 0; c < L; c++) lds[(t * R + p) * L + c] = acc[c][p];
+    __syncthreads();
+    T* __restrict__ out = static_cast<T*>(a.out);
+    const long long n0 = j0 * L;                               // first output of the tile
+    long long rem = a.nout - n0;
+    if (rem > (long long)TJ * L) rem = (long long)TJ * L;
+    for (int i = t; i < (int)rem; i += NT) out[n0 + i] = lds[i];
+}
+
 // ---- stand-alone NCO mixer ------------------------------------------------------------
 struct XlateArgs {
     const float2* in;

@@ -52,7 +52,9 @@ struct Engine {
     bool volk_gain = true;     // emulate the VOLK rotator's magnitude sawtooth (see rotate())
     float gm1 = 0.0f;          // |phase_inc| - 1
     // device state
-    float* d_taps = nullptr;    // core layout (branch-major) or phases [L][P]
+    float* d_taps = nullptr;
+    float* d_taps_lm = nullptr;  // resamp_lm_kernel's per-sub-filter branch-major taps (small interp only)
+    size_t taps_lm_t_off = 0;    // offset (floats) of the transposed copy used when decim == 1    // core layout (branch-major) or phases [L][P]
     float* d_hist[2] = {nullptr, nullptr};
     int cur = 0;
     size_t hist_cap = 0;        // samples
@@ -117,6 +119,13 @@ int64_t out_size(const Engine* e, int64_t count) {
 
 bool use_core(const Engine* e) { return e->L == 1 && e->M <= 16 && !env_int("QDSP_HIP_FORCE_ANY", 0); }
 
+// interp / decim pairs served by resamp_lm_kernel (kernels.hip.h)
+bool use_lm(const Engine* e) {
+    if (e->kind == KIND_FIR || !e->has_filter) return false;
+    if (!(e->L == 2 || e->L == 3 || e->L == 4 || e->L == 5 || e->L == 10)) return false;
+    return e->M >= 1 && e->M <= 8 && env_int("QDSP_HIP_NO_LM", 0) == 0;
+}
+
 int upload_taps(Engine* e, const float* taps, int ntaps) {
     // FIR: h[k] pairs with s[n - (ntaps-1) + k]  -> core with M=1, Q=ntaps, H=ntaps-1
     // resampler L==1: tapPhases[0][t] = taps[t]   -> core with M, Q=ceil(P/M), H=P
@@ -137,6 +146,26 @@ int upload_taps(Engine* e, const float* taps, int ntaps) {
     if (e->d_taps) { HIPCHK(hipFree(e->d_taps)); e->d_taps = nullptr; }
     HIPCHK(hipMalloc(&e->d_taps, host.size() * sizeof(float)));
     HIPCHK(hipMemcpy(e->d_taps, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (e->d_taps_lm) { HIPCHK(hipFree(e->d_taps_lm)); e->d_taps_lm = nullptr; }
+    if (use_lm(e)) {
+        // sub-filter c of resamp_lm_kernel: h_c = phases[(c*M) % L], stored branch-major [c][m][q] = h_c[q*M + m]
+        const int L = e->L, M = e->M, P = e->P, Q = (P + M - 1) / M;
+        std::vector<float> lm((size_t)L * M * Q, 0.0f);
+        for (int c = 0; c < L; c++) {
+            const float* hc = host.data() + (size_t)((c * M) % L) * P;
+            for (int k = 0; k < P; k++) lm[((size_t)c * M + k % M) * Q + k / M] = hc[k];
+        }
+        // M == 1: the same taps transposed, [q][c], behind the first table
+        const size_t n1 = lm.size();
+        if (M == 1) {
+            lm.resize(2 * n1);
+            for (int c = 0; c < L; c++)
+                for (int q = 0; q < Q; q++) lm[n1 + (size_t)q * L + c] = lm[(size_t)c * Q + q];
+        }
+        e->taps_lm_t_off = M == 1 ? n1 : 0;
+        HIPCHK(hipMalloc(&e->d_taps_lm, lm.size() * sizeof(float)));
+        HIPCHK(hipMemcpy(e->d_taps_lm, lm.data(), lm.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     return 0;
 }
 
@@ -234,6 +263,7 @@ void destroy(Engine* e) {
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     if (e->d_taps) (void)hipFree(e->d_taps);
+    if (e->d_taps_lm) (void)hipFree(e->d_taps_lm);
     if (e->d_fft_H) (void)hipFree(e->d_fft_H);
     if (e->d_fft_TA) (void)hipFree(e->d_fft_TA);
     if (e->d_fft_TB) (void)hipFree(e->d_fft_TB);
@@ -308,6 +338,58 @@ template <int CH, bool ROT> int launch_core(Engine* e, qk::CoreArgs& a, hipStrea
 #undef QK_GEOM
 #undef QK_CASE
     return QDSP_HIP_EINVAL;
+}
+
+template <int CH, bool ROT> int launch_lm(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d_out, hipStream_t s) {
+    qk::LmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = d_in;
+    a.out = d_out;
+    a.hist = e->d_hist[e->cur];
+    a.hist_next = e->d_hist[e->cur ^ 1];
+    a.taps = e->d_taps_lm;
+    a.taps_t = e->d_taps_lm + e->taps_lm_t_off;
+    a.count = count;
+    a.nout = nout;
+    a.M = e->M;
+    a.P = e->P;
+    a.Q = (e->P + e->M - 1) / e->M;
+    for (int c = 0; c < e->L; c++) a.e[c] = (c * e->M) / e->L;
+    a.phase0 = e->phase;
+    a.dphase = e->dphase;
+    a.gm1 = e->volk_gain ? e->gm1 : 0.0f;
+    constexpr int NT = 128;
+    // R*L accumulators per lane: 10 .. 30 complex values
+    auto go = [&](auto Rc, auto Lc) -> int {
+        constexpr int R = decltype(Rc)::value, LL = decltype(Lc)::value;
+        constexpr int TJ = NT * R;
+        const int V = TJ + a.Q + 1;
+        int sb = V;
+        if ((sb & 15) == 0) sb += 1;                    // keep the M branch bases off one bank for the de-interleaving writes
+        a.sb = sb;
+        size_t lds = (size_t)a.M * sb * CH * sizeof(float);
+        const size_t lds_out = (size_t)TJ * LL * CH * sizeof(float);      // the tile's outputs pass through LDS too
+        if (lds < lds_out) lds = lds_out;
+        if (lds > (size_t)kMaxDynLds) return QDSP_HIP_EINVAL;
+        a.nblocks = (int)((nout + (long long)TJ * LL - 1) / ((long long)TJ * LL));
+        unit_of_fx(a.dphase, (long double)NT, &a.rot_nt.x, &a.rot_nt.y);
+        hipLaunchKernelGGL((qk::resamp_lm_kernel<CH, R, NT, ROT, LL>), dim3(a.nblocks + 1), dim3(NT), lds, s, a);
+        HIPCHK(hipGetLastError());
+        e->last.name = "resamp_lm_kernel";
+        e->last.grid = a.nblocks + 1;
+        e->last.block = NT;
+        e->last.lds = (int)lds;
+        return 0;
+    };
+    using std::integral_constant;
+    switch (e->L) {
+        case 2: return go(integral_constant<int, 5>{}, integral_constant<int, 2>{});
+        case 3: return go(integral_constant<int, 5>{}, integral_constant<int, 3>{});
+        case 4: return go(integral_constant<int, 3>{}, integral_constant<int, 4>{});
+        case 5: return go(integral_constant<int, 3>{}, integral_constant<int, 5>{});
+        case 10: return go(integral_constant<int, 3>{}, integral_constant<int, 10>{});
+        default: return QDSP_HIP_EINVAL;
+    }
 }
 
 template <int CH, bool ROT> int launch_any(Engine* e, qk::AnyArgs& a, hipStream_t s) {
@@ -567,6 +649,10 @@ int64_t process_dev(Engine* e, const void* d_in, int64_t count, void* d_out, voi
         a.gm1 = e->volk_gain ? e->gm1 : 0.0f;
         if (e->ch == 2) rc = e->rotate ? launch_core<2, true>(e, a, s) : launch_core<2, false>(e, a, s);
         else rc = launch_core<1, false>(e, a, s);
+        if (rc == 0) e->cur ^= 1;
+    } else if (use_lm(e) && e->d_taps_lm) {
+        if (e->ch == 2) rc = e->rotate ? launch_lm<2, true>(e, d_in, count, nout, d_out, s) : launch_lm<2, false>(e, d_in, count, nout, d_out, s);
+        else rc = launch_lm<1, false>(e, d_in, count, nout, d_out, s);
         if (rc == 0) e->cur ^= 1;
     } else {
         qk::AnyArgs a;

@@ -340,7 +340,9 @@ def test_resampler_256_decim8_and_f32(ops, gold):
     assert rel_rms(y, gold["rsf32_1_8"]) < 2e-6
 
 
-@pytest.mark.parametrize("LM", [(1, 1), (1, 3), (1, 5), (1, 10), (1, 16), (1, 17), (1, 64), (5, 1), (7, 4), (160, 147), (3, 1000)])
+@pytest.mark.parametrize("LM", [(1, 1), (1, 3), (1, 5), (1, 10), (1, 16), (1, 17), (1, 64), (5, 1), (7, 4), (160, 147), (3, 1000),
+                                # interp 2/3/4/5/10 with decim <= 8: resamp_lm_kernel (L sub-filters on one staged tile)
+                                (2, 1), (2, 3), (3, 2), (3, 8), (4, 5), (5, 4), (5, 7), (10, 1), (10, 3)])
 def test_resampler_ratios_vs_f64(ops, LM):
     L, M = LM
     rng = np.random.default_rng(L * 1000 + M)
@@ -671,4 +673,29 @@ def test_math_blocks_bit_exact(ops, op):
         assert np.array_equal(f.process(ar, br), O.math_op(op, ar, br))
         assert np.array_equal(f.process(dev(ar), dev(br)).cpu().numpy(), O.math_op(op, ar, br))
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("LM", [(2, 3), (3, 2), (10, 1)])
+def test_resampler_small_interp_kernel_details(ops, gold, LM):
+    """resamp_lm_kernel: same results as the general kernel it replaces (QDSP_HIP_NO_LM), real data,
+    ragged multi-block streams with the per-block phase restart (H4), and the fused NCO."""
+    L, M = LM
+    taps = (gold["taps63"] * L).astype(np.float32)
+    x = O.synth_iq(0, 150_000, seed=L * 10 + M)
+    sizes = [50_001, 3, 99_996]
+    r = ops.Resampler(taps, L, M)
+    y = run_blocks(r, x, sizes)
+    assert r.last_kernel()["name"] == "resamp_lm_kernel"
+    want = run_blocks(O.Resampler(taps, L, M, acc=O.ACC_F64), x, sizes)
+    assert len(y) == len(want) and rel_rms(y, want) < 1e-6
+    xr = np.ascontiguousarray(x.real)
+    yr = run_blocks(ops.Resampler(taps, L, M, complex_data=False), xr, sizes)
+    assert rel_rms(yr, run_blocks(O.Resampler(taps, L, M, complex_data=False, acc=O.ACC_F64), xr, sizes)) < 1e-6
+    inc = ops.phase_delta(48000.0, 1234.0)
+    v = ops.Vfo(taps, L, M, inc)
+    yv = run_blocks(v, x, sizes)
+    assert v.last_kernel()["name"] == "resamp_lm_kernel"
+    xl, rs = O.Xlator(48000.0, 1234.0, exact=True, volk_gain=True), O.Resampler(taps, L, M, acc=O.ACC_F64)
+    wv = np.concatenate([rs.process(xl.process(x[a:b])) for a, b in zip(np.cumsum([0] + sizes)[:-1], np.cumsum(sizes))])
+    assert len(yv) == len(wv) and rel_rms(yv, wv) < 2e-6
 
