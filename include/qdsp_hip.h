@@ -93,7 +93,8 @@ int qdsp_hip_fir_cf32_set_taps(void* h, const float* taps, int ntaps);
  * with one fused multiply-add each (bit-identical to a k-ordered fmaf chain).
  * QDSP_HIP_FIR_FFT: 4096-point overlap-save fast convolution (~135 FLOP/sample instead of
  * 4*ntaps; FP32 FFT rounding, ~3e-7 RMS relative to the direct form).  QDSP_HIP_FIR_AUTO
- * (default): FFT for >= 48 taps on calls of >= 65536 samples, direct form otherwise. */
+ * (default): FFT for >= 8 taps on calls of >= 65536 samples (it runs at copy speed whatever the
+ * taps; measured crossover), direct form otherwise. */
 #define QDSP_HIP_FIR_AUTO 0
 #define QDSP_HIP_FIR_DIRECT 1
 #define QDSP_HIP_FIR_FFT 2
@@ -153,8 +154,9 @@ int qdsp_hip_decim_cf32_configure(void* h, const float* taps, int ntaps, int int
 int64_t qdsp_hip_decim_cf32_out_size(void* h, int64_t count); /* calcOutSize, :95-97 */
 /* QDSP_HIP_FIR_AUTO / _DIRECT / _FFT as for the FIR.  The overlap-save path serves interp == 1
  * with any decimation >= 2 (decim in {2, 4, 8, 16}: pruned inverse transform; others: full
- * inverse, every decim-th output stored); AUTO takes it from 64 taps on calls of >= 65536
- * samples.  interp > 1 is direct form whatever the mode. */
+ * inverse, every decim-th output stored); AUTO takes it on calls of >= 65536 samples from 112
+ * taps for decim < 7 and at any length from decim 7 up (measured crossovers).  interp > 1 is
+ * direct form whatever the mode. */
 int qdsp_hip_decim_cf32_set_mode(void* h, int mode);
 int qdsp_hip_decim_cf32_reset(void* h);
 int qdsp_hip_decim_cf32_history_len(void* h); /* = taps per phase */

@@ -438,9 +438,8 @@ bool fft_eligible(const Engine* e, int64_t count) {
     int mode = e->fir_mode ? e->fir_mode : env_int("QDSP_HIP_FIR_MODE", 0);
     if (mode == 1) return false;
     if (mode == 2) return true;
-    // auto: long filters on calls big enough to fill the chip with 4096-point segments
-    // (measured crossovers, 2^27 samples: FIR from ~24 taps; decimators / VFO from ~64 taps whatever
-    // the decimation -- scripts/tune.py)
+    // auto: calls big enough to fill the chip with 4096-point segments, and filters past the measured
+    // crossover of the two forms
     // real data (two segments per transform, 305 Gs/s whatever the taps at 2^26 samples): the direct form
     // moves half the bytes per sample and stays ahead to ~96 taps (445 Gs/s at 63, 164 at 256); a real
     // decimator keeps 1/M of a full inverse, so the direct form wins until ~32 taps per branch
@@ -449,8 +448,17 @@ bool fft_eligible(const Engine* e, int64_t count) {
     if (e->ch == 1) {
         min_taps = env_int("QDSP_HIP_FFT_MIN_TAPS_REAL", 96);
         if (e->M > 1 && min_taps < 32 * e->M) min_taps = 32 * e->M;
+    } else if (e->M == 1) {
+        // FIR: the overlap-save kernel (a copy-speed 4.8 TB/s whatever the taps) beats the tile-per-block
+        // direct form from 8 taps on (2^26 samples: 0.222 vs 0.256 ms at 7 taps, 0.225 vs 0.394 at 127)
+        min_taps = env_int("QDSP_HIP_FFT_MIN_TAPS", 8);
     } else {
-        min_taps = e->M > 1 ? env_int("QDSP_HIP_FFT_MIN_TAPS_DECIM", 64) : env_int("QDSP_HIP_FFT_MIN_TAPS", 24);
+        // decimators (scripts/tune_small.py, profiles/r01_tune_small.txt): the direct form slows down with the
+        // decimation (LDS-capacity-bound de-interleaved tiles): M = 2 / 4 / 5 it wins to ~110 taps
+        // (0.20 / 0.16 / 0.18 ms vs 0.24 / 0.18 / 0.22), from M = 7 the overlap-save form wins at any length
+        // (M = 8: 0.16 vs 0.25-0.29 ms; M = 16: 0.17 vs 0.45-0.49 ms)
+        const int dflt = e->M >= 7 ? 2 : 112;
+        min_taps = env_int("QDSP_HIP_FFT_MIN_TAPS_DECIM", dflt);
     }
     return e->ntaps >= min_taps && count >= env_int("QDSP_HIP_FFT_MIN_COUNT", 1 << 16);
 }
