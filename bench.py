@@ -149,7 +149,15 @@ def cpu_baseline(name: str, seconds: float):
         t.join()
     dt = time.perf_counter() - t0
     assert all(res)
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+    except OSError:
+        pass
     return {
+        "cpu_model": model,
+        "host_cores_visible": avail,
         "value": round(cores * per_thread / dt / 1e6, 3),
         "unit": "Msamples/s",
         "cores": cores,
