@@ -154,9 +154,11 @@ int qdsp_hip_decim_cf32_configure(void* h, const float* taps, int ntaps, int int
 int64_t qdsp_hip_decim_cf32_out_size(void* h, int64_t count); /* calcOutSize, :95-97 */
 /* QDSP_HIP_FIR_AUTO / _DIRECT / _FFT as for the FIR.  The overlap-save path serves interp == 1
  * with any decimation >= 2 (decim in {2, 4, 8, 16}: pruned inverse transform; others: full
- * inverse, every decim-th output stored); AUTO takes it on calls of >= 65536 samples from 112
- * taps for decim < 7 and at any length from decim 7 up (measured crossovers).  interp > 1 is
- * direct form whatever the mode. */
+ * inverse, every decim-th output stored).  AUTO (measured crossovers): short filters (<= 128 taps,
+ * decim 2..8, 10, 12) run a strided-window direct kernel; longer ones, and other decimations, the
+ * overlap-save path on calls of >= 65536 samples; the rest the de-interleaved direct form.
+ * QDSP_HIP_FIR_DIRECT always means that last, k-ordered form.  interp > 1 is direct form whatever
+ * the mode. */
 int qdsp_hip_decim_cf32_set_mode(void* h, int mode);
 int qdsp_hip_decim_cf32_reset(void* h);
 int qdsp_hip_decim_cf32_history_len(void* h); /* = taps per phase */

@@ -350,6 +350,113 @@ __global__ __launch_bounds__(NT) void resamp_any_kernel(const AnyArgs a) {
     }
 }
 
+// ---- short-filter integer decimator ---------------------------------------------------------
+// y[n'] = sum_k h[k] * s[M n' - P + k],  s = hist ++ in      (PolyphaseResampler<T>::run, interp 1,
+// src/dsp/resampling.h:121-125), for the filters an SDR chain is made of: decimate by 2..8 with
+// 7..~128 taps.  fir_core_kernel de-interleaves its tile into M branches, which at these sizes costs
+// more than the arithmetic (runtime u / M per staged sample, M*(R+Q) window reads for M*Q*R MACs, tiles
+// capped by LDS: 0.15-0.29 ms per 2^26 samples, and slower the larger M).  Here the tile is staged as
+// it lies in memory (one pad element per M*R so the stride-M*R lane pattern falls on distinct banks),
+// lane t owns R consecutive outputs and walks its M*(R-1)+P samples ONCE: sample i feeds output r with
+// tap i - M r.  Taps come zero-padded by M*(R-1) on both sides so no tap index is ever tested, in
+// chunks of M*R consecutive scalars per output (s_load_dwordx8/x16 into SGPRs).  Accumulation is in tap
+// order with one FMA per tap (the padding adds exact zeros), so results equal the k-ordered fmaf chain;
+// the one difference: a NaN/Inf sample up to M*(R-1) positions outside an output's window meets a zero
+// tap there (0 * Inf = NaN) and reaches that output too.
+struct WinArgs {
+    const void* in;
+    void* out;
+    const void* hist;      // P samples
+    void* hist_next;
+    const float* taps;     // zero-padded: hp[k + M*(R-1)] = h[k], length nchunks*M*R + M*(R-1)
+    long long count, nout;
+    int P;
+    int nchunks;           // ceil((M*(R-1) + P) / (M*R))
+    int nblocks;
+    unsigned long long phase0, dphase;
+    double2 rot_nt;        // exp(j*2pi*NT*dphase)   (ROT only)
+    float gm1;
+};
+
+template <int CH, int M, int R, int NT, bool ROT>
+__global__ __launch_bounds__(NT) void decim_win_kernel(const WinArgs a) {
+    using T = typename Smp<CH>::T;
+    constexpr int MR = M * R;                       // samples between the windows of neighbouring lanes
+    constexpr int PAD = (MR % 2 == 0) ? 1 : 0;      // lane stride MR + PAD elements must be odd
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* lds = reinterpret_cast<T*>(smem_raw);
+    const int t = threadIdx.x;
+    const T* __restrict__ in = static_cast<const T*>(a.in);
+    const T* __restrict__ hist = static_cast<const T*>(a.hist);
+    const int P = a.P;
+
+    if ((int)blockIdx.x == a.nblocks) {
+        T* __restrict__ hn = static_cast<T*>(a.hist_next);
+        for (int i = t; i < P; i += NT) {
+            const long long g = a.count - P + i;
+            T v;
+            if (g < 0) {
+                v = hist[g + P];
+            } else {
+                v = in[g];
+                if (ROT) v = rotate(v, phasor_fx(a.phase0 + (unsigned long long)g * a.dphase), g, a.gm1);
+            }
+            hn[i] = v;
+        }
+        return;
+    }
+
+    constexpr int TILE = NT * R;
+    const long long n0 = (long long)blockIdx.x * TILE;
+    const long long base = n0 * M - P;              // stream position of staged element 0
+    const int U = TILE * M + a.nchunks * MR;        // staged span: every chunk any lane reads (zero taps beyond P)
+    {
+        double2 ph;
+        if (ROT) ph = phasor_fx(a.phase0 + (unsigned long long)(base + t) * a.dphase);
+        for (int u = t; u < U; u += NT) {
+            const long long g = base + u;
+            T v = Smp<CH>::zero();
+            if (g < 0) {
+                if (g + P >= 0) v = hist[g + P];
+            } else if (g < a.count) {
+                v = in[g];
+                if (ROT) v = rotate(v, ph, g, a.gm1);
+            }
+            lds[u + (PAD ? u / MR : 0)] = v;
+            if (ROT) ph = cmul(ph, a.rot_nt);
+        }
+    }
+    __syncthreads();
+
+    T acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = Smp<CH>::zero();
+    const T* B = lds + t * (MR + PAD);
+    for (int c = 0; c < a.nchunks; c++) {
+        const T* Bc = B + c * (MR + PAD);
+        const float* __restrict__ hp = a.taps + c * MR;          // hp[u - M r + M (R-1)] pairs sample c*MR + u with output r
+        T x[MR];
+#pragma unroll
+        for (int u = 0; u < MR; u++) x[u] = Bc[u];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+#pragma unroll
+            for (int u = 0; u < MR; u++) mac(acc[r], hp[u + M * (R - 1 - r)], x[u]);
+        }
+    }
+
+    T* __restrict__ out = static_cast<T*>(a.out);
+    const long long n = n0 + (long long)t * R;
+    if (n + R <= a.nout) {
+#pragma unroll
+        for (int r = 0; r < R; r++) out[n + r] = acc[r];
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if (n + r < a.nout) out[n + r] = acc[r];
+    }
+}
+
 // ---- small-interp rational resampler -----------------------------------------------------
 // PolyphaseResampler<T>::run, interp L in {2,3,4,5,10}, decim M <= 8 (src/dsp/resampling.h:121-125):
 //   y[n] = sum_t phases[(n*M) % L][t] * s[(n*M)/L - P + t],   s = hist ++ in.

@@ -119,6 +119,22 @@ int64_t out_size(const Engine* e, int64_t count) {
 
 bool use_core(const Engine* e) { return e->L == 1 && e->M <= 16 && !env_int("QDSP_HIP_FORCE_ANY", 0); }
 
+// decimators served by decim_win_kernel (kernels.hip.h): interp 1, short filters.  Outputs per lane and the
+// tap limit from scripts/tune_win.py / tune_small.py (2^26 samples): chunks of M*R <= 10 samples are the sweet
+// spot; past ~100-128 taps the overlap-save kernels take over (their pruned forms at M = 4, 8, 16 earlier).
+int win_R(int M) {
+    const int r = env_int("QDSP_HIP_WIN_R", 0);      // experiments: 1, 2, 4 or 8 where instantiated
+    if (r == 1 || r == 2 || r == 4 || r == 8) return r;
+    return M <= 2 ? 4 : M <= 5 ? 2 : 1;
+}
+bool use_win(const Engine* e) {
+    if (e->kind == KIND_FIR || !e->has_filter || e->L != 1) return false;
+    const int M = e->M;
+    if (!((M >= 2 && M <= 8) || M == 10 || M == 12)) return false;   // (M = 16: a tie with the pruned overlap-save form)
+    const int max_taps = env_int("QDSP_HIP_WIN_MAX_TAPS", (M == 4 || M == 8) ? 96 : 128);
+    return e->P <= max_taps && env_int("QDSP_HIP_NO_WIN", 0) == 0;
+}
+
 // interp / decim pairs served by resamp_lm_kernel (kernels.hip.h)
 bool use_lm(const Engine* e) {
     if (e->kind == KIND_FIR || !e->has_filter) return false;
@@ -147,6 +163,15 @@ int upload_taps(Engine* e, const float* taps, int ntaps) {
     HIPCHK(hipMalloc(&e->d_taps, host.size() * sizeof(float)));
     HIPCHK(hipMemcpy(e->d_taps, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
     if (e->d_taps_lm) { HIPCHK(hipFree(e->d_taps_lm)); e->d_taps_lm = nullptr; }
+    if (use_win(e)) {
+        // decim_win_kernel: hp[k + M*(R-1)] = h[k], zeros around (d_taps_lm doubles as its table)
+        const int M = e->M, R = win_R(M), MR = M * R, P = e->P;
+        const int nchunks = (M * (R - 1) + P + MR - 1) / MR;
+        std::vector<float> w((size_t)nchunks * MR + (size_t)M * (R - 1) + 16, 0.0f);
+        for (int k = 0; k < P; k++) w[(size_t)k + M * (R - 1)] = taps[k];
+        HIPCHK(hipMalloc(&e->d_taps_lm, w.size() * sizeof(float)));
+        HIPCHK(hipMemcpy(e->d_taps_lm, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     if (use_lm(e)) {
         // sub-filter c of resamp_lm_kernel: h_c = phases[(c*M) % L], stored branch-major [c][m][q] = h_c[q*M + m]
         const int L = e->L, M = e->M, P = e->P, Q = (P + M - 1) / M;
@@ -340,6 +365,53 @@ template <int CH, bool ROT> int launch_core(Engine* e, qk::CoreArgs& a, hipStrea
     return QDSP_HIP_EINVAL;
 }
 
+template <int CH, bool ROT> int launch_win(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d_out, hipStream_t s) {
+    qk::WinArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = d_in;
+    a.out = d_out;
+    a.hist = e->d_hist[e->cur];
+    a.hist_next = e->d_hist[e->cur ^ 1];
+    a.taps = e->d_taps_lm;
+    a.count = count;
+    a.nout = nout;
+    a.P = e->P;
+    a.phase0 = e->phase;
+    a.dphase = e->dphase;
+    a.gm1 = e->volk_gain ? e->gm1 : 0.0f;
+    constexpr int NT = 256;
+    auto go = [&](auto Mc, auto Rc) -> int {
+        constexpr int M = decltype(Mc)::value, R = decltype(Rc)::value, MR = M * R;
+        constexpr int TILE = NT * R;
+        a.nchunks = (M * (R - 1) + a.P + MR - 1) / MR;
+        const int U = TILE * M + a.nchunks * MR;
+        const size_t lds = (size_t)(U + U / MR + 1) * CH * sizeof(float);
+        if (lds > (size_t)kMaxDynLds) return QDSP_HIP_EINVAL;
+        a.nblocks = (int)((nout + TILE - 1) / TILE);
+        unit_of_fx(a.dphase, (long double)NT, &a.rot_nt.x, &a.rot_nt.y);
+        hipLaunchKernelGGL((qk::decim_win_kernel<CH, M, R, NT, ROT>), dim3(a.nblocks + 1), dim3(NT), lds, s, a);
+        HIPCHK(hipGetLastError());
+        e->last.name = "decim_win_kernel";
+        e->last.grid = a.nblocks + 1;
+        e->last.block = NT;
+        e->last.lds = (int)lds;
+        return 0;
+    };
+    using std::integral_constant;
+    const int R = win_R(e->M);
+#define QK_WIN(m, r) if (e->M == m && R == r) return go(integral_constant<int, m>{}, integral_constant<int, r>{});
+    QK_WIN(2, 2) QK_WIN(2, 4) QK_WIN(2, 8)
+    QK_WIN(3, 2) QK_WIN(3, 4)
+    QK_WIN(4, 1) QK_WIN(4, 2) QK_WIN(4, 4)
+    QK_WIN(5, 1) QK_WIN(5, 2) QK_WIN(5, 4)
+    QK_WIN(6, 1) QK_WIN(6, 2)
+    QK_WIN(7, 1)
+    QK_WIN(8, 1) QK_WIN(8, 2)
+    QK_WIN(10, 1) QK_WIN(12, 1)
+#undef QK_WIN
+    return QDSP_HIP_EINVAL;
+}
+
 template <int CH, bool ROT> int launch_lm(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d_out, hipStream_t s) {
     qk::LmArgs a;
     memset(&a, 0, sizeof(a));
@@ -432,6 +504,8 @@ int fft_dec(const Engine* e) {
     }
     return 0;
 }
+
+int mode_of(const Engine* e) { return e->fir_mode ? e->fir_mode : env_int("QDSP_HIP_FIR_MODE", 0); }
 
 bool fft_eligible(const Engine* e, int64_t count) {
     if (!fft_dec(e)) return false;
@@ -636,8 +710,14 @@ int64_t process_dev(Engine* e, const void* d_in, int64_t count, void* d_out, voi
     int rc = 0;
     if (!e->has_filter) {
         rc = launch_xlate(e, d_in, count, d_out, s);
-    } else if (fft_eligible(e, count)) {
+    } else if (fft_eligible(e, count) && !(mode_of(e) == 0 && use_win(e) && e->d_taps_lm)) {
         rc = launch_fft(e, d_in, count, nout, d_out, s);
+        if (rc == 0) e->cur ^= 1;
+    } else if (use_win(e) && e->d_taps_lm && mode_of(e) == 0) {
+        // AUTO only: QDSP_HIP_FIR_DIRECT keeps meaning fir_core_kernel (the form the bit-exactness tests pin),
+        // QDSP_HIP_FIR_FFT the overlap-save kernels
+        if (e->ch == 2) rc = e->rotate ? launch_win<2, true>(e, d_in, count, nout, d_out, s) : launch_win<2, false>(e, d_in, count, nout, d_out, s);
+        else rc = launch_win<1, false>(e, d_in, count, nout, d_out, s);
         if (rc == 0) e->cur ^= 1;
     } else if (use_core(e)) {
         qk::CoreArgs a;

@@ -14,7 +14,7 @@ def timeit(op, x, out, iters=10):
 
 n = 1 << 26
 x = ops.synth_iq(n, seed=1)
-for M in (1, 2, 4, 5, 8, 16):
+for M in (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16):
     for ntaps in (7, 15, 31, 63, 127):
         taps = bench.lowpass_taps(ntaps, 0.4 / max(M, 2))
         row = []

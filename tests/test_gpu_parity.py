@@ -699,3 +699,30 @@ def test_resampler_small_interp_kernel_details(ops, gold, LM):
     wv = np.concatenate([rs.process(xl.process(x[a:b])) for a, b in zip(np.cumsum([0] + sizes)[:-1], np.cumsum(sizes))])
     assert len(yv) == len(wv) and rel_rms(yv, wv) < 2e-6
 
+
+
+@pytest.mark.parametrize("M", [2, 3, 4, 5, 6, 7, 8, 10, 12])
+def test_decimator_short_filter_kernel(ops, gold, M):
+    """decim_win_kernel (AUTO, short filters): bit-identical to the k-ordered fmaf chain (zero-padded taps add
+    exact zeros), ragged blocks incl. blocks shorter than the history, real data, and the fused NCO."""
+    rng = np.random.default_rng(M)
+    x = O.synth_iq(0, 120_000, seed=M)
+    for ntaps in (5, 63, 96):
+        taps = rng.standard_normal(ntaps).astype(np.float32)
+        sizes = [M * 1001, M * 3, M * 7000]          # multiples of M: every input sample is consumed (H4)
+        r = ops.Resampler(taps, 1, M)
+        y = run_blocks(r, x, sizes)
+        assert r.last_kernel()["name"] == "decim_win_kernel", (M, ntaps)
+        assert np.array_equal(y, run_blocks(O.Resampler(taps, 1, M, acc=O.ACC_FMA), x, sizes)), (M, ntaps)
+    xr = np.ascontiguousarray(x.real)
+    yr = run_blocks(ops.Resampler(taps, 1, M, complex_data=False), xr, sizes)
+    assert np.array_equal(yr, run_blocks(O.Resampler(taps, 1, M, complex_data=False, acc=O.ACC_FMA), xr, sizes))
+    inc = ops.phase_delta(48000.0, -2500.0)
+    v = ops.Vfo(gold["taps63"], 1, M, inc)
+    yv = run_blocks(v, x, sizes)
+    assert v.last_kernel()["name"] == "decim_win_kernel"
+    xl, rs = O.Xlator(48000.0, -2500.0, exact=True, volk_gain=True), O.Resampler(gold["taps63"], 1, M, acc=O.ACC_F64)
+    edges = np.cumsum([0] + [sizes[i % 3] for i in range(64)])
+    edges = edges[edges < len(x)].tolist() + [len(x)]
+    wv = np.concatenate([rs.process(xl.process(x[a:b])) for a, b in zip(edges, edges[1:])])
+    assert len(yv) == len(wv) and rel_rms(yv, wv) < 2e-6
