@@ -726,3 +726,33 @@ def test_decimator_short_filter_kernel(ops, gold, M):
     edges = edges[edges < len(x)].tolist() + [len(x)]
     wv = np.concatenate([rs.process(xl.process(x[a:b])) for a, b in zip(edges, edges[1:])])
     assert len(yv) == len(wv) and rel_rms(yv, wv) < 2e-6
+
+
+def test_degenerate_block_sizes_every_kernel(ops, gold):
+    """Empty blocks, single samples and blocks shorter than the history, through every kernel family
+    (strided-window and de-interleaved direct forms, small-interp and general resamplers, overlap-save
+    forced on tiny calls, real data): state must carry exactly as in one big call."""
+    x = O.synth_iq(0, 9_000, seed=321)
+    sizes = [0, 1, 2, 0, 17, 300, 1, 4096, 0, 4583]
+    assert sum(sizes) == len(x)
+    cases = [
+        ("win", lambda: ops.Resampler(gold["taps63"], 1, 5), lambda: O.Resampler(gold["taps63"], 1, 5, acc=O.ACC_F64)),
+        ("core", lambda: ops.Resampler(gold["taps256"], 1, 3), lambda: O.Resampler(gold["taps256"], 1, 3, acc=O.ACC_F64)),
+        ("lm", lambda: ops.Resampler(gold["taps63"], 3, 2), lambda: O.Resampler(gold["taps63"], 3, 2, acc=O.ACC_F64)),
+        ("any", lambda: ops.Resampler(gold["taps63"], 7, 9), lambda: O.Resampler(gold["taps63"], 7, 9, acc=O.ACC_F64)),
+        ("fir", lambda: ops.Fir(gold["taps256"]), lambda: O.Fir(gold["taps256"], acc=O.ACC_F64)),
+    ]
+    for name, mk, mko in cases:
+        for mode in (0, 2):
+            op = mk()
+            op.set_mode(mode)
+            y = np.concatenate([np.array(op.process(x[a:a + n])) for a, n in zip(np.cumsum([0] + sizes[:-1]), sizes)])
+            o = mko()
+            # the reference restarts its phase counter every block (H4): feed the oracle the same blocks
+            want = np.concatenate([o.process(x[a:a + n]) for a, n in zip(np.cumsum([0] + sizes[:-1]), sizes)])
+            assert len(y) == len(want) and rel_rms(y, want) < 2e-6, (name, mode)
+    xr = np.ascontiguousarray(x.real)
+    f = ops.Fir(gold["taps256"], complex_data=False)
+    f.set_mode(f.FFT)
+    y = np.concatenate([np.array(f.process(xr[a:a + n])) for a, n in zip(np.cumsum([0] + sizes[:-1]), sizes)])
+    assert rel_rms(y, O.Fir(gold["taps256"], complex_data=False, acc=O.ACC_F64).process(xr)) < 2e-6
