@@ -252,6 +252,11 @@ def main():
     else:
         fn = getattr(capi.load(), op._prefix + "_process_dev")
 
+    # the ring exchange of every step, built once (float32 views: a plain dtype for RCCL)
+    p2p_ops = None
+    if world > 1 and H and not rehearse:
+        p2p_ops = [dist.P2POp(dist.isend, tail_f, (rank + 1) % world), dist.P2POp(dist.irecv, halo_f, (rank - 1) % world)]
+
     def step():
         if world > 1 and H:
             # ring halo: my tail -> next rank's history; previous rank's tail -> mine
@@ -265,10 +270,7 @@ def main():
                     r.wait()
                 halo.copy_(halo_h)
             else:
-                reqs = dist.batch_isend_irecv([   # float32 views: plain dtype for RCCL
-                    dist.P2POp(dist.isend, tail_f, (rank + 1) % world),
-                    dist.P2POp(dist.irecv, halo_f, (rank - 1) % world),
-                ])
+                reqs = dist.batch_isend_irecv(p2p_ops)
                 for r in reqs:
                     r.wait()
             # ... and is copied (2 KB, device to device, same stream) into the filter's history
