@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kFftNT, (DEC == 1 && !ROT) ? 4 : 3) void fir_fft_ke
                     if (n2 * 256 + te < a.ov) continue;
                     const float2 y = v[rev16(n2)];
                     const long long pA = o0 + n2 * 256, pB = pA + a.L;
-                    if (a.decm > 1) {   // resampler: y[n'] sits at stream position n'*decm - 1
+                    if (a.strided) {    // resampler: y[n'] sits at stream position n'*decm - 1
                         const long long nA = (pA + 1) / a.decm, nB = (pB + 1) / a.decm;
                         if (pA + 1 - nA * a.decm == 0 && nA < a.nout) outr[nA] = y.x;
                         if (pB + 1 - nB * a.decm == 0 && nB < a.nout) outr[nB] = y.y;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(kFftNT, (DEC == 1 && !ROT) ? 4 : 3) void fir_fft_ke
                         if (pB < a.nout) outr[pB] = y.y;
                     }
                 }
-            } else if (a.decm > 1) {
+            } else if (a.strided) {
                 // Any integer decimation: the full inverse ran; keep the positions p == -1 (mod decm)
                 // (y[n'] sits at stream position n'*decm - 1) -- strided 8-byte stores, 1/decm of them.
 #pragma unroll

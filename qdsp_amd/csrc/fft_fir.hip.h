@@ -36,7 +36,8 @@ struct FftArgs {
     long long nout;           // outputs of this call
     int H;                    // history length (ntaps-1 for the FIR, taps per phase for the resampler)
     int dec;                  // 1, 2, 4, 8, 16: decimation handled by pruning the inverse transform
-    int decm;                 // dec == 1 only: keep every decm-th output of the full inverse (1 = FIR)
+    int decm;                 // dec == 1 only: keep every decm-th output of the full inverse
+    int strided;              // dec == 1 only: resampler semantics -- y[n'] sits at stream position n'*decm - 1 (0 = FIR: y[n] at n)
     int rot;                  // 1: fused VFO -- Hf holds the spectrum of taps * exp(j k dphase), outputs are rotated
     int ov;                   // leading invalid elements of a segment (multiple of dec)
     int seg_shift;            // segment b starts at stream position b*L - seg_shift

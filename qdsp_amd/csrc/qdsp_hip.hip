@@ -494,13 +494,13 @@ int fft_dec(const Engine* e) {
     if (e->ch == 1) {
         // real data: two real segments per complex transform (full inverse; decimators keep every M-th output)
         if (e->kind == KIND_FIR) return 1;
-        if (e->kind == KIND_DECIM && e->M >= 2) return 1;
+        if (e->kind == KIND_DECIM) return 1;
         return 0;
     }
     if (e->kind == KIND_FIR) return 1;
     if (e->kind == KIND_DECIM || e->kind == KIND_VFO) {
         if (e->M == 2 || e->M == 4 || e->M == 8 || e->M == 16) return e->M;
-        if (e->M >= 3) return 1;
+        return 1;   // any other decimation, 1 included (the pure xlating FIR / a resampler at equal rates)
     }
     return 0;
 }
@@ -522,6 +522,10 @@ bool fft_eligible(const Engine* e, int64_t count) {
     if (e->ch == 1) {
         min_taps = env_int("QDSP_HIP_FFT_MIN_TAPS_REAL", 96);
         if (e->M > 1 && min_taps < 32 * e->M) min_taps = 32 * e->M;
+    } else if (e->M == 1 && e->kind != KIND_FIR) {
+        // equal-rate resampler / pure xlating FIR: full inverse + per-element store (0.52 ms per 2^27 samples)
+        // against the tile-per-block direct form (0.51 ms at 7 taps, 0.63 at 63)
+        min_taps = env_int("QDSP_HIP_FFT_MIN_TAPS", 24);
     } else if (e->M == 1) {
         // FIR: the overlap-save kernel (a copy-speed 4.8 TB/s whatever the taps) beats the tile-per-block
         // direct form from 8 taps on (2^26 samples: 0.222 vs 0.256 ms at 7 taps, 0.225 vs 0.394 at 127)
@@ -615,6 +619,7 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
         // any-decimation resampler / VFO: y[n'] sits at stream position n'*M - 1.  Even overlap and
         // an even segment start (two samples before the first valid position) keep 16-byte loads.
         a.decm = e->M;
+        a.strided = 1;
         a.ov = (e->ntaps - 1 + 1) & ~1;
         a.seg_shift = a.ov + 2;
         a.L = qk::kFftN - a.ov;

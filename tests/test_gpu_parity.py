@@ -756,3 +756,25 @@ def test_degenerate_block_sizes_every_kernel(ops, gold):
     f.set_mode(f.FFT)
     y = np.concatenate([np.array(f.process(xr[a:a + n])) for a, n in zip(np.cumsum([0] + sizes[:-1]), sizes)])
     assert rel_rms(y, O.Fir(gold["taps256"], complex_data=False, acc=O.ACC_F64).process(xr)) < 2e-6
+
+
+def test_equal_rate_resampler_and_xlating_fir_fft_path(ops, gold):
+    """decimation 1 through the overlap-save kernel: PolyphaseResampler at equal rates (one more sample of
+    delay than the FIR) and the VFO without decimation (a pure frequency-xlating FIR)."""
+    taps = gold["taps256"]
+    x = O.synth_iq(0, 300_000, seed=8)
+    cuts = [0, 170_001, 300_000]
+    r = ops.Resampler(taps, 1, 1)
+    y = np.concatenate([r.process(dev(x[a:b])).cpu().numpy() for a, b in zip(cuts, cuts[1:])])
+    assert r.last_kernel()["name"] == "fir_fft_kernel"
+    o = O.Resampler(taps, 1, 1, acc=O.ACC_F64)
+    assert rel_rms(y, np.concatenate([o.process(x[a:b]) for a, b in zip(cuts, cuts[1:])])) < 2e-6
+    inc = ops.phase_delta(1.0, 0.0625)
+    v = ops.Vfo(taps, 1, 1, inc)
+    yv = np.concatenate([v.process(dev(x[a:b])).cpu().numpy() for a, b in zip(cuts, cuts[1:])])
+    assert v.last_kernel()["name"] == "fir_fft_kernel"
+    xl, rs = O.Xlator(1.0, 0.0625, exact=True, volk_gain=True), O.Resampler(taps, 1, 1, acc=O.ACC_F64)
+    assert rel_rms(yv, np.concatenate([rs.process(xl.process(x[a:b])) for a, b in zip(cuts, cuts[1:])])) < 2e-6
+    d = ops.Vfo(taps, 1, 1, inc)
+    d.set_mode(d.DIRECT)
+    assert rel_rms(yv, np.concatenate([d.process(dev(x[a:b])).cpu().numpy() for a, b in zip(cuts, cuts[1:])])) < 2e-6
