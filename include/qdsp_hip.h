@@ -154,8 +154,8 @@ int qdsp_hip_decim_cf32_configure(void* h, const float* taps, int ntaps, int int
 int64_t qdsp_hip_decim_cf32_out_size(void* h, int64_t count); /* calcOutSize, :95-97 */
 /* QDSP_HIP_FIR_AUTO / _DIRECT / _FFT as for the FIR.  The overlap-save path serves interp == 1
  * with any decimation >= 2 (decim in {2, 4, 8, 16}: pruned inverse transform; others: full
- * inverse, every decim-th output stored).  AUTO (measured crossovers): short filters (<= 128 taps,
- * decim 2..8, 10, 12) run a strided-window direct kernel; longer ones, and other decimations, the
+ * inverse, every decim-th output stored).  AUTO (measured crossovers): short and medium filters
+ * (decim 2..8, 10, 12, 16; up to 150..256 taps) run a strided-window direct kernel; longer ones, and other decimations, the
  * overlap-save path on calls of >= 65536 samples; the rest the de-interleaved direct form.
  * QDSP_HIP_FIR_DIRECT always means that last, k-ordered form.  interp > 1 is direct form whatever
  * the mode. */

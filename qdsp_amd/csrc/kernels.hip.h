@@ -102,6 +102,48 @@ __global__ __launch_bounds__(256) void ew_kernel(const EwArgs a) {
     }
 }
 
+// ---- tile staging shared by the direct-form kernels ------------------------------------------
+// hist ++ in (rotated by the NCO if ROT) for stream positions base .. base+U-1 -> put(u, sample).
+// Eight independent loads are issued before the first is consumed: written as one load per loop trip
+// the compiler leaves them serialised (load, wait, LDS store, next load), and a tile's ~35 loads per
+// lane then cost ~35 memory latencies -- several times the arithmetic of the tile.
+template <int CH, int NT, bool ROT, class PUT>
+__device__ __forceinline__ void stage_tile(const typename Smp<CH>::T* __restrict__ in, const typename Smp<CH>::T* __restrict__ hist,
+                                           int H, long long count, long long base, int U, unsigned long long phase0,
+                                           unsigned long long dphase, double2 rot_nt, float gm1, PUT put) {
+    using T = typename Smp<CH>::T;
+    const int t = threadIdx.x;
+    double2 ph;
+    if (ROT) ph = phasor_fx(phase0 + (unsigned long long)(base + t) * dphase);
+    constexpr int K = 8;
+    for (int u0 = t; u0 < U; u0 += NT * K) {
+        T v[K];
+        if (base + u0 - t >= 0 && base + u0 - t + NT * K <= count) {       // block-uniform: the whole batch is plain input
+#pragma unroll
+            for (int k = 0; k < K; k++) v[k] = in[base + u0 + k * NT];
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const long long g = base + u0 + k * NT;
+                T x = Smp<CH>::zero();
+                if (g < 0) { if (g + H >= 0) x = hist[g + H]; }
+                else if (g < count) x = in[g];
+                v[k] = x;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int u = u0 + k * NT;
+            const long long g = base + u;
+            if (ROT) {
+                if (g >= 0 && g < count) v[k] = rotate(v[k], ph, g, gm1);   // history is already rotated
+                ph = cmul(ph, rot_nt);
+            }
+            if (u < U) put(u, v[k]);
+        }
+    }
+}
+
 // ---- direct-form core -----------------------------------------------------------------
 struct CoreArgs {
     const void* in;       // count samples
@@ -410,22 +452,8 @@ __global__ __launch_bounds__(NT) void decim_win_kernel(const WinArgs a) {
     const long long n0 = (long long)blockIdx.x * TILE;
     const long long base = n0 * M - P;              // stream position of staged element 0
     const int U = TILE * M + a.nchunks * MR;        // staged span: every chunk any lane reads (zero taps beyond P)
-    {
-        double2 ph;
-        if (ROT) ph = phasor_fx(a.phase0 + (unsigned long long)(base + t) * a.dphase);
-        for (int u = t; u < U; u += NT) {
-            const long long g = base + u;
-            T v = Smp<CH>::zero();
-            if (g < 0) {
-                if (g + P >= 0) v = hist[g + P];
-            } else if (g < a.count) {
-                v = in[g];
-                if (ROT) v = rotate(v, ph, g, a.gm1);
-            }
-            lds[u + (PAD ? u / MR : 0)] = v;
-            if (ROT) ph = cmul(ph, a.rot_nt);
-        }
-    }
+    stage_tile<CH, NT, ROT>(in, hist, P, a.count, base, U, a.phase0, a.dphase, a.rot_nt, a.gm1,
+                            [&](int u, T v) { lds[u + (PAD ? u / MR : 0)] = v; });
     __syncthreads();
 
     T acc[R];
@@ -456,6 +484,11 @@ __global__ __launch_bounds__(NT) void decim_win_kernel(const WinArgs a) {
             if (n + r < a.nout) out[n + r] = acc[r];
     }
 }
+
+// (Tried for LONG filters too -- 256 taps at decimation 8 is only 128 FLOP per input sample, 0.13 ms of
+// FMAs per 2^27 samples: chunks of 8 samples, R tap octets per chunk as s_load_dwordx8.  Measured 0.37 ms
+// at R = 4 (LDS bandwidth equals the FMA rate: each staged sample is read by P/(M R) = 8 lanes) and
+// 0.56 ms at R = 8 (512 B of LDS per lane: 4 waves per CU), against 0.30 ms for the overlap-save kernel.)
 
 // ---- small-interp rational resampler -----------------------------------------------------
 // PolyphaseResampler<T>::run, interp L in {2,3,4,5,10}, decim M <= 8 (src/dsp/resampling.h:121-125):
@@ -518,23 +551,10 @@ __global__ __launch_bounds__(NT) void resamp_lm_kernel(const LmArgs a) {
     const long long base = j0 * M - P;                       // stream position of staged element 0
     const int V = TJ + Q + 1;                                // elements per branch (e_c < M adds at most one)
     const int U = V * M;
-    {
-        double2 ph;
-        if (ROT) ph = phasor_fx(a.phase0 + (unsigned long long)(base + t) * a.dphase);
-        for (int u = t; u < U; u += NT) {
-            const long long g = base + u;
-            T v = Smp<CH>::zero();
-            if (g < 0) {
-                if (g + P >= 0) v = hist[g + P];
-            } else if (g < a.count) {
-                v = in[g];
-                if (ROT) v = rotate(v, ph, g, a.gm1);
-            }
-            const int vv = u / M, m = u - vv * M;
-            lds[m * a.sb + vv] = v;
-            if (ROT) ph = cmul(ph, a.rot_nt);
-        }
-    }
+    stage_tile<CH, NT, ROT>(in, hist, P, a.count, base, U, a.phase0, a.dphase, a.rot_nt, a.gm1, [&](int u, T v) {
+        const int vv = u / M, m = u - vv * M;
+        lds[m * a.sb + vv] = v;
+    });
     __syncthreads();
 
     T acc[L][R];

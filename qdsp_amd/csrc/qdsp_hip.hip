@@ -122,16 +122,23 @@ bool use_core(const Engine* e) { return e->L == 1 && e->M <= 16 && !env_int("QDS
 // decimators served by decim_win_kernel (kernels.hip.h): interp 1, short filters.  Outputs per lane and the
 // tap limit from scripts/tune_win.py / tune_small.py (2^26 samples): chunks of M*R <= 10 samples are the sweet
 // spot; past ~100-128 taps the overlap-save kernels take over (their pruned forms at M = 4, 8, 16 earlier).
-int win_R(int M) {
+int win_R(int M, int P) {
     const int r = env_int("QDSP_HIP_WIN_R", 0);      // experiments: 1, 2, 4 or 8 where instantiated
     if (r == 1 || r == 2 || r == 4 || r == 8) return r;
-    return M <= 2 ? 4 : M <= 5 ? 2 : 1;
+    if (M <= 3) return 4;
+    if (M == 4) return P > 96 ? 4 : 2;
+    if (M <= 6) return 2;
+    if (M == 8) return P > 63 ? 2 : 1;
+    return 1;
 }
 bool use_win(const Engine* e) {
     if (e->kind == KIND_FIR || !e->has_filter || e->L != 1) return false;
     const int M = e->M;
-    if (!((M >= 2 && M <= 8) || M == 10 || M == 12)) return false;   // (M = 16: a tie with the pruned overlap-save form)
-    const int max_taps = env_int("QDSP_HIP_WIN_MAX_TAPS", (M == 4 || M == 8) ? 96 : 128);
+    if (!((M >= 2 && M <= 8) || M == 10 || M == 12 || M == 16)) return false;
+    // where the overlap-save forms take over (per 2^26 samples they run 0.25 / 0.24 / 0.19 / 0.24 / 0.23 / 0.23 /
+    // 0.165 / 0.24 / 0.24 / 0.17 ms at decimation 2 / 3 / 4 / 5 / 6 / 7 / 8 / 10 / 12 / 16)
+    static const int limit[17] = {0, 0, 150, 192, 160, 256, 256, 160, 200, 0, 192, 0, 224, 0, 0, 0, 256};
+    const int max_taps = env_int("QDSP_HIP_WIN_MAX_TAPS", limit[M]);
     return e->P <= max_taps && env_int("QDSP_HIP_NO_WIN", 0) == 0;
 }
 
@@ -165,7 +172,7 @@ int upload_taps(Engine* e, const float* taps, int ntaps) {
     if (e->d_taps_lm) { HIPCHK(hipFree(e->d_taps_lm)); e->d_taps_lm = nullptr; }
     if (use_win(e)) {
         // decim_win_kernel: hp[k + M*(R-1)] = h[k], zeros around (d_taps_lm doubles as its table)
-        const int M = e->M, R = win_R(M), MR = M * R, P = e->P;
+        const int M = e->M, P = e->P, R = win_R(M, P), MR = M * R;
         const int nchunks = (M * (R - 1) + P + MR - 1) / MR;
         std::vector<float> w((size_t)nchunks * MR + (size_t)M * (R - 1) + 16, 0.0f);
         for (int k = 0; k < P; k++) w[(size_t)k + M * (R - 1)] = taps[k];
@@ -398,7 +405,7 @@ template <int CH, bool ROT> int launch_win(Engine* e, const void* d_in, int64_t 
         return 0;
     };
     using std::integral_constant;
-    const int R = win_R(e->M);
+    const int R = win_R(e->M, e->P);
 #define QK_WIN(m, r) if (e->M == m && R == r) return go(integral_constant<int, m>{}, integral_constant<int, r>{});
     QK_WIN(2, 2) QK_WIN(2, 4) QK_WIN(2, 8)
     QK_WIN(3, 2) QK_WIN(3, 4)
@@ -407,7 +414,7 @@ template <int CH, bool ROT> int launch_win(Engine* e, const void* d_in, int64_t 
     QK_WIN(6, 1) QK_WIN(6, 2)
     QK_WIN(7, 1)
     QK_WIN(8, 1) QK_WIN(8, 2)
-    QK_WIN(10, 1) QK_WIN(12, 1)
+    QK_WIN(10, 1) QK_WIN(12, 1) QK_WIN(16, 1)
 #undef QK_WIN
     return QDSP_HIP_EINVAL;
 }

@@ -8,8 +8,8 @@ import bench
 from qdsp_amd import ops
 n = 1 << 26
 x = ops.synth_iq(n, seed=1)
-for M, Rs in ((2, (2, 4, 8)), (3, (2, 4)), (4, (1, 2, 4)), (5, (1, 2, 4)), (6, (1, 2)), (8, (1, 2))):
-    for ntaps in (15, 63, 127):
+for M, Rs in ((2, (2, 4, 8)), (3, (2, 4)), (4, (1, 2, 4)), (5, (1, 2, 4)), (6, (1, 2)), (8, (1, 2)), (16, (1,))):
+    for ntaps in (15, 63, 127, 191):
         row = []
         for R in Rs:
             os.environ["QDSP_HIP_WIN_R"] = str(R)
