@@ -402,9 +402,9 @@ __global__ __launch_bounds__(NT) void resamp_any_kernel(const AnyArgs a) {
 // lane t owns R consecutive outputs and walks its M*(R-1)+P samples ONCE: sample i feeds output r with
 // tap i - M r.  Taps come zero-padded by M*(R-1) on both sides so no tap index is ever tested, in
 // chunks of M*R consecutive scalars per output (s_load_dwordx8/x16 into SGPRs).  Accumulation is in tap
-// order with one FMA per tap (the padding adds exact zeros), so results equal the k-ordered fmaf chain;
-// the one difference: a NaN/Inf sample up to M*(R-1) positions outside an output's window meets a zero
-// tap there (0 * Inf = NaN) and reaches that output too.
+// order with one FMA per tap, so results equal the k-ordered fmaf chain bit for bit; the first and last
+// chunks, where some (sample, output) pairs fall outside the window, test the tap index instead of relying
+// on the zero padding, so a NaN/Inf sample stays inside the windows that hold it.
 struct WinArgs {
     const void* in;
     void* out;
@@ -412,8 +412,9 @@ struct WinArgs {
     void* hist_next;
     const float* taps;     // zero-padded: hp[k + M*(R-1)] = h[k], length nchunks*M*R + M*(R-1)
     long long count, nout;
-    int P;
-    int nchunks;           // ceil((M*(R-1) + P) / (M*R))
+    int P;                 // window start / history length: taps per phase for the resampler, ntaps-1 for FIR<T>
+    int ntaps;
+    int nchunks;           // ceil((M*(R-1) + ntaps) / (M*R))
     int nblocks;
     unsigned long long phase0, dphase;
     double2 rot_nt;        // exp(j*2pi*NT*dphase)   (ROT only)
@@ -466,10 +467,25 @@ __global__ __launch_bounds__(NT) void decim_win_kernel(const WinArgs a) {
         T x[MR];
 #pragma unroll
         for (int u = 0; u < MR; u++) x[u] = Bc[u];
+        if (c * MR >= M * (R - 1) && (c + 1) * MR <= a.ntaps) {
+            // every (sample, output) pair of the chunk meets a real tap
 #pragma unroll
-        for (int r = 0; r < R; r++) {
+            for (int r = 0; r < R; r++) {
 #pragma unroll
-            for (int u = 0; u < MR; u++) mac(acc[r], hp[u + M * (R - 1 - r)], x[u]);
+                for (int u = 0; u < MR; u++) mac(acc[r], hp[u + M * (R - 1 - r)], x[u]);
+            }
+        } else {
+            // first / last chunks: a sample outside an output's window must not reach it even as 0 * x
+            // (0 * Inf = NaN): the reference's sum never touches it
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+#pragma unroll
+                for (int u = 0; u < MR; u++) {
+                    const int k = c * MR + u - M * r;
+                    const T xz = (k >= 0 && k < a.ntaps) ? x[u] : Smp<CH>::zero();   // a select, not a branch per FMA
+                    mac(acc[r], hp[u + M * (R - 1 - r)], xz);
+                }
+            }
         }
     }
 

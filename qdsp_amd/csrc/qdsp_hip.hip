@@ -125,6 +125,7 @@ bool use_core(const Engine* e) { return e->L == 1 && e->M <= 16 && !env_int("QDS
 int win_R(int M, int P) {
     const int r = env_int("QDSP_HIP_WIN_R", 0);      // experiments: 1, 2, 4 or 8 where instantiated
     if (r == 1 || r == 2 || r == 4 || r == 8) return r;
+    if (M == 1) return 8;
     if (M <= 3) return 4;
     if (M == 4) return P > 96 ? 4 : 2;
     if (M <= 6) return 2;
@@ -132,12 +133,13 @@ int win_R(int M, int P) {
     return 1;
 }
 bool use_win(const Engine* e) {
-    if (e->kind == KIND_FIR || !e->has_filter || e->L != 1) return false;
+    if (!e->has_filter || e->L != 1) return false;
     const int M = e->M;
-    if (!((M >= 2 && M <= 8) || M == 10 || M == 12 || M == 16)) return false;
+    if (!((M >= 1 && M <= 8) || M == 10 || M == 12 || M == 16)) return false;
     // where the overlap-save forms take over (per 2^26 samples they run 0.25 / 0.24 / 0.19 / 0.24 / 0.23 / 0.23 /
     // 0.165 / 0.24 / 0.24 / 0.17 ms at decimation 2 / 3 / 4 / 5 / 6 / 7 / 8 / 10 / 12 / 16)
-    static const int limit[17] = {0, 0, 150, 192, 160, 256, 256, 160, 200, 0, 192, 0, 224, 0, 0, 0, 256};
+    // ([1] = FIR<T> and equal-rate resamplers below the overlap-save threshold: 0.22 ms against 0.25 de-interleaved)
+    static const int limit[17] = {0, 7, 150, 192, 160, 256, 256, 160, 200, 0, 192, 0, 224, 0, 0, 0, 256};
     const int max_taps = env_int("QDSP_HIP_WIN_MAX_TAPS", limit[M]);
     return e->P <= max_taps && env_int("QDSP_HIP_NO_WIN", 0) == 0;
 }
@@ -382,7 +384,8 @@ template <int CH, bool ROT> int launch_win(Engine* e, const void* d_in, int64_t 
     a.taps = e->d_taps_lm;
     a.count = count;
     a.nout = nout;
-    a.P = e->P;
+    a.P = e->H;                  // window start / history length: P for the resampler, ntaps-1 for FIR<T>
+    a.ntaps = e->P;
     a.phase0 = e->phase;
     a.dphase = e->dphase;
     a.gm1 = e->volk_gain ? e->gm1 : 0.0f;
@@ -390,7 +393,7 @@ template <int CH, bool ROT> int launch_win(Engine* e, const void* d_in, int64_t 
     auto go = [&](auto Mc, auto Rc) -> int {
         constexpr int M = decltype(Mc)::value, R = decltype(Rc)::value, MR = M * R;
         constexpr int TILE = NT * R;
-        a.nchunks = (M * (R - 1) + a.P + MR - 1) / MR;
+        a.nchunks = (M * (R - 1) + e->P + MR - 1) / MR;
         const int U = TILE * M + a.nchunks * MR;
         const size_t lds = (size_t)(U + U / MR + 1) * CH * sizeof(float);
         if (lds > (size_t)kMaxDynLds) return QDSP_HIP_EINVAL;
@@ -407,6 +410,7 @@ template <int CH, bool ROT> int launch_win(Engine* e, const void* d_in, int64_t 
     using std::integral_constant;
     const int R = win_R(e->M, e->P);
 #define QK_WIN(m, r) if (e->M == m && R == r) return go(integral_constant<int, m>{}, integral_constant<int, r>{});
+    QK_WIN(1, 4) QK_WIN(1, 8)
     QK_WIN(2, 2) QK_WIN(2, 4) QK_WIN(2, 8)
     QK_WIN(3, 2) QK_WIN(3, 4)
     QK_WIN(4, 1) QK_WIN(4, 2) QK_WIN(4, 4)
