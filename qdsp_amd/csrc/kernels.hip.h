@@ -249,22 +249,7 @@ __global__ __launch_bounds__(NT) void fir_core_kernel(const CoreArgs a) {
             staged = true;
         }
     }
-    if (!staged) {
-        double2 ph;
-        if (ROT) ph = phasor_fx(a.phase0 + (unsigned long long)(base + t) * a.dphase);
-        for (int u = t; u < U; u += NT) {
-            const long long g = base + u;
-            T v = Smp<CH>::zero();
-            if (g < 0) {
-                v = hist[g + H];
-            } else if (g < a.count) {
-                v = in[g];
-                if (ROT) v = rotate(v, ph, g, a.gm1);
-            }
-            put(u, v);
-            if (ROT) ph = cmul(ph, a.rot_nt);
-        }
-    }
+    if (!staged) stage_tile<CH, NT, ROT>(in, hist, H, a.count, base, U, a.phase0, a.dphase, a.rot_nt, a.gm1, put);
     __syncthreads();
 
     // ---- sliding-window dot products ------------------------------------------------------
@@ -328,6 +313,7 @@ struct AnyArgs {
     int tile;              // outputs per block
     int nblocks;
     unsigned long long phase0, dphase;
+    double2 rot_nt;        // exp(j*2pi*NT*dphase)   (ROT only)
     float gm1;
 };
 
@@ -366,17 +352,7 @@ __global__ __launch_bounds__(NT) void resamp_any_kernel(const AnyArgs a) {
     const long long lo = (n0 * a.M) / a.L - P;           // first staged sample
     const long long hi = ((n1 - 1) * a.M) / a.L;         // one past the last needed sample
     const int span = (int)(hi - lo);
-    for (int u = t; u < span; u += NT) {
-        const long long g = lo + u;
-        T v = Smp<CH>::zero();
-        if (g < 0) {
-            v = hist[g + P];
-        } else if (g < a.count) {
-            v = in[g];
-            if (ROT) v = rotate(v, phasor_fx(a.phase0 + (unsigned long long)g * a.dphase), g, a.gm1);
-        }
-        lds[u] = v;
-    }
+    stage_tile<CH, NT, ROT>(in, hist, P, a.count, lo, span, a.phase0, a.dphase, a.rot_nt, a.gm1, [&](int u, T v) { lds[u] = v; });
     __syncthreads();
 
     T* __restrict__ out = static_cast<T*>(a.out);

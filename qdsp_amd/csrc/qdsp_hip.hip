@@ -486,6 +486,7 @@ template <int CH, bool ROT> int launch_any(Engine* e, qk::AnyArgs& a, hipStream_
     a.tile = (int)tile;
     a.nblocks = (int)((a.nout + tile - 1) / tile);
     const size_t lds = (size_t)span_of(tile) * CH * sizeof(float);
+    unit_of_fx(a.dphase, (long double)NT, &a.rot_nt.x, &a.rot_nt.y);
     hipLaunchKernelGGL((qk::resamp_any_kernel<CH, NT, ROT>), dim3(a.nblocks + 1), dim3(NT), lds, s, a);
     HIPCHK(hipGetLastError());
     e->last.name = "resamp_any_kernel";
