@@ -256,17 +256,39 @@ __global__ __launch_bounds__(kFftNT, (DEC == 1 && !ROT) ? 4 : 3) void fir_fft_ke
             // ---- pass A' (over k0) and store the L valid outputs --------------------------
             fft16<true>(v);
             const long long o0 = seg0 + te;  // output index == stream position (element n2*256 + te)
+            // strided stores: element i of a segment starting at s sits at position p = s + i and is output
+            // n' iff p + 1 == n' * decm.  One 64-bit division per segment (s + 1 = q0 * decm + r0), then per
+            // element x = r0 + i < decm + 4096 goes through a 32-bit multiply-high (16 64-bit divisions per
+            // lane and segment were ~20 % of the kernel's instructions).
+            auto seg_split = [&](long long s1, long long& q0, int& r0) {
+                q0 = s1 / a.decm;
+                long long r = s1 - q0 * a.decm;
+                if (r < 0) { r += a.decm; q0 -= 1; }
+                r0 = (int)r;
+            };
+            auto out_index = [&](long long q0, int r0, int i, long long& n) -> bool {   // true: element i is an output, n its index
+                const unsigned x = (unsigned)(r0 + i);
+                const unsigned q = a.decm_inv ? (unsigned)(((unsigned long long)x * a.decm_inv) >> 32) : x / (unsigned)a.decm;
+                n = q0 + q;
+                return x - q * (unsigned)a.decm == 0;
+            };
             if constexpr (REAL) {
                 float* __restrict__ outr = reinterpret_cast<float*>(a.out);
+                long long qA = 0, qB = 0;
+                int rA = 0, rB = 0;
+                if (a.strided) {
+                    seg_split(seg0 + 1, qA, rA);
+                    seg_split(segB + 1, qB, rB);
+                }
 #pragma unroll
                 for (int n2 = 0; n2 < 16; n2++) {
                     if (n2 * 256 + te < a.ov) continue;
                     const float2 y = v[rev16(n2)];
                     const long long pA = o0 + n2 * 256, pB = pA + a.L;
                     if (a.strided) {    // resampler: y[n'] sits at stream position n'*decm - 1
-                        const long long nA = (pA + 1) / a.decm, nB = (pB + 1) / a.decm;
-                        if (pA + 1 - nA * a.decm == 0 && nA < a.nout) outr[nA] = y.x;
-                        if (pB + 1 - nB * a.decm == 0 && nB < a.nout) outr[nB] = y.y;
+                        long long nA, nB;
+                        if (out_index(qA, rA, n2 * 256 + te, nA) && nA < a.nout) outr[nA] = y.x;
+                        if (out_index(qB, rB, n2 * 256 + te, nB) && nB < a.nout) outr[nB] = y.y;
                     } else {
                         if (pA < a.nout) outr[pA] = y.x;
                         if (pB < a.nout) outr[pB] = y.y;
@@ -275,11 +297,13 @@ __global__ __launch_bounds__(kFftNT, (DEC == 1 && !ROT) ? 4 : 3) void fir_fft_ke
             } else if (a.strided) {
                 // Any integer decimation: the full inverse ran; keep the positions p == -1 (mod decm)
                 // (y[n'] sits at stream position n'*decm - 1) -- strided 8-byte stores, 1/decm of them.
+                long long q0;
+                int r0;
+                seg_split(seg0 + 1, q0, r0);
 #pragma unroll
                 for (int n2 = 0; n2 < 16; n2++) {
-                    const long long p1 = o0 + n2 * 256 + 1;
-                    const long long n = p1 / a.decm;
-                    if (n2 * 256 + te >= a.ov && p1 - n * a.decm == 0 && n < a.nout) a.out[n] = rot_out(n2, v[rev16(n2)]);
+                    long long n;
+                    if (n2 * 256 + te >= a.ov && out_index(q0, r0, n2 * 256 + te, n) && n < a.nout) a.out[n] = rot_out(n2, v[rev16(n2)]);
                 }
             } else if (interior && a.vec) {
                 float4* __restrict__ o4 = reinterpret_cast<float4*>(a.out + seg0 + (te & ~1)) + half * 8 * 128;

@@ -37,6 +37,7 @@ struct FftArgs {
     int H;                    // history length (ntaps-1 for the FIR, taps per phase for the resampler)
     int dec;                  // 1, 2, 4, 8, 16: decimation handled by pruning the inverse transform
     int decm;                 // dec == 1 only: keep every decm-th output of the full inverse
+    unsigned decm_inv;        // floor(2^32 / decm) + 1: x / decm == (x * decm_inv) >> 32 for x < 2^32 / decm (0: divide)
     int strided;              // dec == 1 only: resampler semantics -- y[n'] sits at stream position n'*decm - 1 (0 = FIR: y[n] at n)
     int rot;                  // 1: fused VFO -- Hf holds the spectrum of taps * exp(j k dphase), outputs are rotated
     int ov;                   // leading invalid elements of a segment (multiple of dec)

@@ -631,6 +631,7 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
         // any-decimation resampler / VFO: y[n'] sits at stream position n'*M - 1.  Even overlap and
         // an even segment start (two samples before the first valid position) keep 16-byte loads.
         a.decm = e->M;
+        a.decm_inv = (e->M >= 2 && (unsigned long long)(e->M + 4096) * (unsigned long long)e->M < (1ULL << 32)) ? (unsigned)((1ULL << 32) / (unsigned)e->M) + 1u : 0u;
         a.strided = 1;
         a.ov = (e->ntaps - 1 + 1) & ~1;
         a.seg_shift = a.ov + 2;

@@ -778,3 +778,20 @@ def test_equal_rate_resampler_and_xlating_fir_fft_path(ops, gold):
     d = ops.Vfo(taps, 1, 1, inc)
     d.set_mode(d.DIRECT)
     assert rel_rms(yv, np.concatenate([d.process(dev(x[a:b])).cpu().numpy() for a, b in zip(cuts, cuts[1:])])) < 2e-6
+
+
+@pytest.mark.parametrize("M", [3, 7, 100, 4097, 70_000])
+def test_any_decimation_strided_store(ops, gold, M):
+    """Full inverse + every M-th output kept (fft_fir.hip strided store): the output index comes from one
+    64-bit division per segment and a 32-bit multiply-high per element (plain division past 2^16)."""
+    n = 300_000
+    x = O.synth_iq(0, n, seed=M % 97)
+    taps = O.lowpass_taps_f64(200, 0.05).astype(np.float32)
+    r = ops.Resampler(taps, 1, M)
+    r.set_mode(r.FFT)
+    cuts = [0, (n // 2 // M) * M, n]
+    y = np.concatenate([r.process(dev(x[a:b])).cpu().numpy() for a, b in zip(cuts, cuts[1:])])
+    assert r.last_kernel()["name"] == "fir_fft_kernel"
+    o = O.Resampler(taps, 1, M, acc=O.ACC_F64)
+    want = np.concatenate([o.process(x[a:b]) for a, b in zip(cuts, cuts[1:])])
+    assert y.shape == want.shape and len(y) >= 3 and rel_rms(y, want) < 2e-6
