@@ -136,10 +136,10 @@ bool use_win(const Engine* e) {
     if (!e->has_filter || e->L != 1) return false;
     const int M = e->M;
     if (!((M >= 1 && M <= 8) || M == 10 || M == 12 || M == 16)) return false;
-    // where the overlap-save forms take over (per 2^26 samples they run 0.25 / 0.24 / 0.19 / 0.24 / 0.23 / 0.23 /
-    // 0.165 / 0.24 / 0.24 / 0.17 ms at decimation 2 / 3 / 4 / 5 / 6 / 7 / 8 / 10 / 12 / 16)
+    // where the overlap-save forms take over (per 2^26 samples they run 0.25 / 0.19 / 0.15 / 0.17 ms at decimation
+    // 2 / 4 / 8 / 16 -- pruned inverse -- and 0.20-0.21 ms at every other decimation: full inverse, strided store)
     // ([1] = FIR<T> and equal-rate resamplers below the overlap-save threshold: 0.22 ms against 0.25 de-interleaved)
-    static const int limit[17] = {0, 7, 150, 192, 160, 256, 256, 160, 200, 0, 192, 0, 224, 0, 0, 0, 256};
+    static const int limit[17] = {0, 7, 150, 150, 160, 200, 256, 160, 200, 0, 192, 0, 224, 0, 0, 0, 256};
     const int max_taps = env_int("QDSP_HIP_WIN_MAX_TAPS", limit[M]);
     return e->P <= max_taps && env_int("QDSP_HIP_NO_WIN", 0) == 0;
 }
