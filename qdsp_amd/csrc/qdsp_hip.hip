@@ -477,20 +477,34 @@ template <int CH, bool ROT> int launch_lm(Engine* e, const void* d_in, int64_t c
 
 template <int CH, bool ROT> int launch_any(Engine* e, qk::AnyArgs& a, hipStream_t s) {
     constexpr int NT = 256;
-    // Tile = as many outputs as keep the staged input span inside the LDS budget.
-    const long long max_elems = kMaxDynLds / (CH * (int)sizeof(float));
-    long long tile = 4LL * NT;
+    // the phase table rides in LDS when it leaves at least half of the budget to the samples
+    int Pp = (a.P + 3) & ~3;
+    if (((Pp >> 2) & 1) == 0) Pp += 4;
+    const long long tap_bytes = (long long)a.L * Pp * (long long)sizeof(float);
+    const bool lt = tap_bytes <= kMaxDynLds / 2 && env_int("QDSP_HIP_ANY_NO_LDS_TAPS", 0) == 0;
+    a.Pp = Pp;
+    a.tap_bytes = lt ? (int)tap_bytes : 0;
+    // Tile = as many outputs as keep the staged input span inside what is left of the LDS budget.
+    const long long max_elems = (kMaxDynLds - a.tap_bytes) / (CH * (int)sizeof(float));
+    long long tile = (long long)env_int("QDSP_HIP_ANY_TILE", 8) * NT;
     auto span_of = [&](long long t) { return ((t - 1) * a.M) / a.L + a.P + 2; };
     while (tile > 1 && span_of(tile) > max_elems) tile /= 2;
     if (span_of(tile) > max_elems) return QDSP_HIP_EINVAL;  // taps per phase beyond LDS
     a.tile = (int)tile;
     a.nblocks = (int)((a.nout + tile - 1) / tile);
-    const size_t lds = (size_t)span_of(tile) * CH * sizeof(float);
+    a.step_d = (int)(((long long)NT * a.M) / a.L);
+    a.step_p = (int)(((long long)NT * a.M) % a.L);
+    int nwg = 256 * 8;
+    if (nwg > a.nblocks) nwg = a.nblocks;
+    if (nwg < 1) nwg = 1;
+    a.nwg = nwg;
+    const size_t lds = (size_t)a.tap_bytes + (size_t)span_of(tile) * CH * sizeof(float);
     unit_of_fx(a.dphase, (long double)NT, &a.rot_nt.x, &a.rot_nt.y);
-    hipLaunchKernelGGL((qk::resamp_any_kernel<CH, NT, ROT>), dim3(a.nblocks + 1), dim3(NT), lds, s, a);
+    if (lt) hipLaunchKernelGGL((qk::resamp_any_kernel<CH, NT, ROT, true>), dim3(nwg + 1), dim3(NT), lds, s, a);
+    else hipLaunchKernelGGL((qk::resamp_any_kernel<CH, NT, ROT, false>), dim3(nwg + 1), dim3(NT), lds, s, a);
     HIPCHK(hipGetLastError());
     e->last.name = "resamp_any_kernel";
-    e->last.grid = a.nblocks + 1;
+    e->last.grid = nwg + 1;
     e->last.block = NT;
     e->last.lds = (int)lds;
     return 0;
