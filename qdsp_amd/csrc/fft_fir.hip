@@ -55,7 +55,7 @@ __host__ __device__ constexpr int pos1(int e) { return (e >> 1) + 136 * (e & 1);
 //              real and imaginary parts of its input apart, so TWO consecutive real segments ride one
 //              complex transform as re / im (segment 2b -> re, 2b+1 -> im); loads and stores are 4-byte.
 template <int DEC, bool ROT, bool REAL = false>
-__global__ __launch_bounds__(kFftNT, (DEC == 1 && !ROT) ? 4 : 3) void fir_fft_kernel(const FftArgs a) {
+__global__ __launch_bounds__(kFftNT, (DEC == 1 && !ROT && !REAL) ? 4 : 3) void fir_fft_kernel(const FftArgs a) {
     __shared__ __attribute__((aligned(16))) float2 lds[kFftLdsElems + 16 * 17];
     float2* tbl = lds + kFftLdsElems;  // pass-B twiddles W256^(lo*k), rows padded to 17
     const int t = threadIdx.x;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(kFftNT, (DEC == 1 && !ROT) ? 4 : 3) void fir_fft_ke
             const long long g = a.count - H + i;
             float2 v;
             if (g < 0) {
-                v = a.hist[g + H];
+                v = a.hist_keep[g + H];
             } else {
                 v = a.in[g];
                 if (ROT) {
@@ -171,15 +171,8 @@ __global__ __launch_bounds__(kFftNT, (DEC == 1 && !ROT) ? 4 : 3) void fir_fft_ke
             for (int n2 = 0; n2 < 16; n2++) {
                 const long long g = seg0 + n2 * 256 + te;
                 float2 x = make_float2(0.0f, 0.0f);
-                if (g < 0) {
-                    if (g + H >= 0) {
-                        x = a.hist[g + H];
-                        if (ROT) {   // the history is kept rotated: back to raw samples (first segment only)
-                            const double2 p = fx_phasor(a.phase_in0 + (unsigned long long)g * a.dphase);
-                            x = cmulc<true>(x, make_float2((float)p.x, (float)p.y));
-                        }
-                    }
-                } else if (g < a.count) x = a.in[g];
+                if (g < 0) { if (g + H >= 0) x = a.hist[g + H]; }   // (ROT: the host side hands over the history de-rotated)
+                else if (g < a.count) x = a.in[g];
                 v[n2] = x;
             }
         }
@@ -393,7 +386,7 @@ __global__ __launch_bounds__(kFftNT, 2) void fir_fft_dec_kernel(const FftArgs a)
             const long long g = a.count - H + i;
             float2 v;
             if (g < 0) {
-                v = a.hist[g + H];
+                v = a.hist_keep[g + H];
             } else {
                 v = a.in[g];
                 if (ROT) {
@@ -439,15 +432,8 @@ __global__ __launch_bounds__(kFftNT, 2) void fir_fft_dec_kernel(const FftArgs a)
                 const long long g = seg0 + n2 * 256 + t;
                 float2 x = make_float2(0.0f, 0.0f);
                 if (b < a.nblocks) {
-                    if (g < 0) {
-                        if (g + H >= 0) {
-                            x = a.hist[g + H];
-                            if (ROT) {   // the history is kept rotated: back to raw samples (first segment only)
-                                const double2 p = fx_phasor(a.phase_in0 + (unsigned long long)g * a.dphase);
-                                x = cmulc<true>(x, make_float2((float)p.x, (float)p.y));
-                            }
-                        }
-                    } else if (g < a.count) x = a.in[g];
+                    if (g < 0) { if (g + H >= 0) x = a.hist[g + H]; }   // (ROT: de-rotated by the host side)
+                    else if (g < a.count) x = a.in[g];
                 }
                 v[n2] = x;
             }
@@ -455,18 +441,21 @@ __global__ __launch_bounds__(kFftNT, 2) void fir_fft_dec_kernel(const FftArgs a)
     };
 
     const int ngroups = (a.nblocks + DEC - 1) / DEC;
+    // Output NCO: exact fixed-point phase of this lane's segment in the workgroup's FIRST group (one FP64
+    // sincos per launch), then an FP64 rotation per group.  (A sincos per group cost 20 spilled VGPRs in
+    // the group loop: its temporaries on top of the two 16-value tables.)
+    double2 pbg = make_double2(1.0, 0.0);
+    if (ROT) pbg = fx_phasor(a.phase0 + (unsigned long long)((long long)((int)blockIdx.x * DEC + wbb) * a.L - a.seg_shift) * a.dphase);
 #pragma unroll 1
     for (int grp = blockIdx.x; grp < ngroups; grp += a.nwg) {
         const int b0 = grp * DEC;
         // Output NCO (ROT): every value this lane stores is a kept output of segment b0 + wbb, at positions
-        // seg0 + e0 + 256 n2 -- one exact fixed-point phasor per group and lane (computed here, while few
-        // registers are live), 16 rotations per GROUP (an input-side NCO rotates 16 samples per lane and
+        // seg0 + e0 + 256 n2 -- 16 rotations per GROUP (an input-side NCO rotates 16 samples per lane and
         // SEGMENT).
         float2 q = make_float2(1.0f, 0.0f);
         if (ROT) {
-            const long long sego = (long long)(b0 + wbb) * a.L - a.seg_shift;
-            const double2 pb = fx_phasor(a.phase0 + (unsigned long long)sego * a.dphase);
-            q = cmulc<false>(make_float2((float)pb.x, (float)pb.y), pl);
+            q = cmulc<false>(make_float2((float)pbg.x, (float)pbg.y), pl);
+            pbg = dcmul(pbg, a.rot_step);      // this workgroup's next group: nwg*DEC segments further
         }
         float2 v[16], vn[16];
         load_segment(b0, v);

@@ -27,7 +27,8 @@ constexpr int kFftLdsElems = 16 * kFftRow1;  // 4352 >= 256*17 = 4352
 struct FftArgs {
     const float2* in;
     float2* out;
-    const float2* hist;       // H samples (rotated by the NCO for the fused VFO, as the direct kernels keep it)
+    const float2* hist;       // H raw samples preceding in[0] (fused VFO: de-rotated by the caller from the rotated form the handle keeps)
+    const float2* hist_keep;  // the same H samples in the form the handle keeps them (rotated for the fused VFO): source of the hand-over
     float2* hist_next;
     const float2* Hf;         // [256][16]: Hf[(k0*16+k1)*16 + k2] = FFT(taps reversed)[k0 + 16 k1 + 256 k2] / F
     const float2* TA;         // [256][16]: exp(-j 2pi t k / 4096)
@@ -52,7 +53,7 @@ struct FftArgs {
     unsigned long long phase_in0;   // phase of in[0] (history hand-over, de-rotation of the history)
     unsigned long long phase0;      // phase_in0 - (ntaps-1)*dphase: output at position p gets phase0 + p*dphase
     unsigned long long dphase;
-    double2 rot_step;         // exp(j 2pi nwg*L*dphase): block b -> b + nwg (per-segment kernel)
+    double2 rot_step;         // exp(j 2pi nwg*L*dphase): block b -> b + nwg (per-segment kernel); x dec for the grouped kernel
     float2 wtab[16];          // exp(j 2pi 256*n2*dphase)
     float gm1;                // |phase_inc| - 1 (VOLK magnitude sawtooth: a real scale of the input samples), 0 = off
 };

@@ -53,6 +53,8 @@ struct Engine {
     float gm1 = 0.0f;          // |phase_inc| - 1
     // device state
     float* d_taps = nullptr;
+    float* d_hist_raw = nullptr;  // overlap-save VFO: the history de-rotated for the current call
+    int hist_raw_cap = 0;
     float* d_taps_lm = nullptr;  // resamp_lm_kernel's per-sub-filter branch-major taps (small interp only)
     size_t taps_lm_t_off = 0;    // offset (floats) of the transposed copy used when decim == 1    // core layout (branch-major) or phases [L][P]
     float* d_hist[2] = {nullptr, nullptr};
@@ -298,6 +300,7 @@ void destroy(Engine* e) {
     (void)hipDeviceSynchronize();
     if (e->d_taps) (void)hipFree(e->d_taps);
     if (e->d_taps_lm) (void)hipFree(e->d_taps_lm);
+    if (e->d_hist_raw) (void)hipFree(e->d_hist_raw);
     if (e->d_fft_H) (void)hipFree(e->d_fft_H);
     if (e->d_fft_TA) (void)hipFree(e->d_fft_TA);
     if (e->d_fft_TB) (void)hipFree(e->d_fft_TB);
@@ -623,6 +626,9 @@ int fft_prepare(Engine* e) {
     return 0;
 }
 
+int launch_xlate_inc(Engine* e, const void* d_in, int64_t count, void* d_out, unsigned long long phase0, unsigned long long dphase, float gm1,
+                     hipStream_t s);
+
 int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d_out, hipStream_t s) {
     int rc = fft_prepare(e);
     if (rc) return rc;
@@ -631,7 +637,26 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
     a.in = static_cast<const float2*>(d_in);
     a.out = static_cast<float2*>(d_out);
     a.hist = reinterpret_cast<const float2*>(e->d_hist[e->cur]);
+    a.hist_keep = a.hist;
     a.hist_next = reinterpret_cast<float2*>(e->d_hist[e->cur ^ 1]);
+    if (e->rotate && e->H > 0) {
+        // The history is kept rotated (the direct kernels and *_set_history_dev use that form; a call may switch
+        // form with its size), the overlap-save kernels filter RAW samples: de-rotate the H samples once per call
+        // into a side buffer -- exp(-j phi(g)), g = -H .. -1 -- instead of carrying an FP64 sincos in the first
+        // segment's load path of the big kernel (its registers cost the grouped kernel 20 spilled VGPRs).
+        if (!e->d_hist_raw || e->hist_raw_cap < e->H) {
+            if (e->d_hist_raw) HIPCHK(hipFree(e->d_hist_raw));
+            e->d_hist_raw = nullptr;
+            HIPCHK(hipMalloc(&e->d_hist_raw, (size_t)e->H * sizeof(float2)));
+            e->hist_raw_cap = e->H;
+        }
+        const unsigned long long ph_first = e->phase - (unsigned long long)e->H * e->dphase;   // phase of history sample 0
+        const Launch keep = e->last;
+        rc = launch_xlate_inc(e, e->d_hist[e->cur], e->H, e->d_hist_raw, 0ULL - ph_first, 0ULL - e->dphase, 0.0f, s);
+        e->last = keep;
+        if (rc) return rc;
+        a.hist = reinterpret_cast<const float2*>(e->d_hist_raw);
+    }
     a.Hf = e->d_fft_H;
     a.TA = e->d_fft_TA;
     a.TB = e->d_fft_TB;
@@ -684,9 +709,8 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
         a.phase0 = e->phase - (unsigned long long)(e->ntaps - 1) * e->dphase;
         a.dphase = e->dphase;
         a.gm1 = e->volk_gain ? e->gm1 : 0.0f;
-        // segment -> next segment handled by the same workgroup: L samples (grouped kernel),
-        // nwg*L samples (per-segment kernel)
-        unit_of_fx(e->dphase, grouped ? (long double)a.L : (long double)nwg * (long double)a.L, &a.rot_step.x, &a.rot_step.y);
+        // one workgroup's step between its units: nwg segments (per-segment kernel), nwg groups of dec segments (grouped)
+        unit_of_fx(e->dphase, (long double)nwg * (long double)a.L * (long double)(grouped ? a.dec : 1), &a.rot_step.x, &a.rot_step.y);
         for (int n2 = 0; n2 < 16; n2++) {
             double c, sn;
             unit_of_fx(e->dphase, (long double)(256 * n2), &c, &sn);
@@ -702,13 +726,18 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
     return 0;
 }
 
-int launch_xlate_raw(Engine* e, const void* d_in, int64_t count, void* d_out, unsigned long long phase0, float gm1, hipStream_t s);
+int launch_xlate_inc(Engine* e, const void* d_in, int64_t count, void* d_out, unsigned long long phase0, unsigned long long dphase, float gm1,
+                     hipStream_t s);
+int launch_xlate_raw(Engine* e, const void* d_in, int64_t count, void* d_out, unsigned long long phase0, float gm1, hipStream_t s) {
+    return launch_xlate_inc(e, d_in, count, d_out, phase0, e->dphase, gm1, s);
+}
 
 int launch_xlate(Engine* e, const void* d_in, int64_t count, void* d_out, hipStream_t s) {
     return launch_xlate_raw(e, d_in, count, d_out, e->phase, e->volk_gain ? e->gm1 : 0.0f, s);
 }
 
-int launch_xlate_raw(Engine* e, const void* d_in, int64_t count, void* d_out, unsigned long long phase0, float gm1, hipStream_t s) {
+int launch_xlate_inc(Engine* e, const void* d_in, int64_t count, void* d_out, unsigned long long phase0, unsigned long long dphase, float gm1,
+                     hipStream_t s) {
     constexpr int NT = 256;
     if (count <= 0) return 0;
     qk::XlateArgs a;
@@ -716,12 +745,12 @@ int launch_xlate_raw(Engine* e, const void* d_in, int64_t count, void* d_out, un
     a.out = static_cast<float2*>(d_out);
     a.count = count;
     a.phase0 = phase0;
-    a.dphase = e->dphase;
+    a.dphase = dphase;
     const long long npairs = (count + 1) / 2;
     long long grid = (npairs + NT - 1) / NT;
     if (grid > 256 * 16) grid = 256 * 16;  // 16 blocks per CU, grid-stride beyond
-    unit_of_fx(e->dphase, 1.0L, &a.rot_one.x, &a.rot_one.y);
-    unit_of_fx(e->dphase, (long double)(2 * grid * NT), &a.rot_stride.x, &a.rot_stride.y);
+    unit_of_fx(dphase, 1.0L, &a.rot_one.x, &a.rot_one.y);
+    unit_of_fx(dphase, (long double)(2 * grid * NT), &a.rot_stride.x, &a.rot_stride.y);
     a.vec = (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0;   // d_in == nullptr (SineSource) counts as aligned
     a.gm1 = gm1;
     hipLaunchKernelGGL((qk::xlate_kernel<NT>), dim3((unsigned)grid), dim3(NT), 0, s, a);

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <cstdlib>
 
 template <int RUN_ELEMS>   // float2 elements per row per wave tile (16 -> 128 B)
 __global__ __launch_bounds__(256) void wr(float2* out, long long stride, int ntiles, int nwaves) {
@@ -81,8 +82,9 @@ __global__ void lin(float4* out, long long n) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) out[i] = make_float4(1, 2, 3, 4);
 }
 
-int main() {
-    const long long stride = 1 << 21;   // 2^21 outputs per row = 16 MiB rows, 1 GiB total
+int main(int argc, char** argv) {
+    // 2^21 outputs per row = 16 MiB rows, 1 GiB total (the channelizer at decimation 64); pass 24 for 128 MiB rows, 8 GiB (decimation 8)
+    const long long stride = 1ll << (argc > 1 ? atoi(argv[1]) : 21);
     float2* d; hipMalloc(&d, 64 * stride * 8);
     for (int i = 0; i < 30; i++) hipLaunchKernelGGL(lin, dim3(4096), dim3(256), 0, 0, (float4*)d, 64 * stride / 2);
     hipDeviceSynchronize();
