@@ -56,6 +56,15 @@ __device__ __forceinline__ float2 rotate(float2 x, double2 p, long long g, float
     return make_float2(fmaf(x.x, pr, -x.y * pi), fmaf(x.x, pi, x.y * pr));
 }
 __device__ __forceinline__ float rotate(float x, double2, long long, float) { return x; }  // CH==1: unused
+// the same with the phasor as an FP32 product p * w (staging batches, stage_tile)
+__device__ __forceinline__ float2 rotate_f(float2 x, float2 p, float2 w, long long g, float gm1) {
+    const float gain = fmaf((float)(int)(g & 511), gm1, 1.0f);
+    const float pr = fmaf(p.x, w.x, -p.y * w.y) * gain, pi = fmaf(p.x, w.y, p.y * w.x) * gain;
+    return make_float2(fmaf(x.x, pr, -x.y * pi), fmaf(x.x, pi, x.y * pr));
+}
+__device__ __forceinline__ float rotate_f(float x, float2, float2, long long, float) { return x; }  // CH==1: unused
+__device__ __forceinline__ float2 rot_apply(float2 x, float pr, float pi) { return make_float2(fmaf(x.x, pr, -x.y * pi), fmaf(x.x, pi, x.y * pr)); }
+__device__ __forceinline__ float rot_apply(float x, float, float) { return x; }  // CH==1: unused
 
 // ---- element-wise two-input blocks (src/dsp/math.h: Add / Substract / Multiply) -------------
 // out = a (+, -, *) b over `n4` float4s (+ a scalar tail); CPLX: * is the complex product of
@@ -107,14 +116,16 @@ __global__ __launch_bounds__(256) void ew_kernel(const EwArgs a) {
 // Eight independent loads are issued before the first is consumed: written as one load per loop trip
 // the compiler leaves them serialised (load, wait, LDS store, next load), and a tile's ~35 loads per
 // lane then cost ~35 memory latencies -- several times the arithmetic of the tile.
-template <int CH, int NT, bool ROT, class PUT>
+template <int CH, int NT, bool ROT, class ARGS, class PUT>
 __device__ __forceinline__ void stage_tile(const typename Smp<CH>::T* __restrict__ in, const typename Smp<CH>::T* __restrict__ hist,
-                                           int H, long long count, long long base, int U, unsigned long long phase0,
-                                           unsigned long long dphase, double2 rot_nt, float gm1, PUT put) {
+                                           int H, long long count, long long base, int U, const ARGS& a, PUT put) {
     using T = typename Smp<CH>::T;
     const int t = threadIdx.x;
+    // NCO: one exact FP64 phasor per lane and batch of 8 staged samples (advanced by an FP64 rotation of 8*NT
+    // samples), times an FP32 table exp(j k NT dphase) inside the batch: an FP64 complex multiply per staged
+    // sample made the fused VFO 30-50 % slower than the plain decimator in these memory-bound kernels.
     double2 ph;
-    if (ROT) ph = phasor_fx(phase0 + (unsigned long long)(base + t) * dphase);
+    if (ROT) ph = phasor_fx(a.phase0 + (unsigned long long)(base + t) * a.dphase);
     constexpr int K = 8;
     for (int u0 = t; u0 < U; u0 += NT * K) {
         T v[K];
@@ -131,14 +142,35 @@ __device__ __forceinline__ void stage_tile(const typename Smp<CH>::T* __restrict
                 v[k] = x;
             }
         }
+        if (ROT) {
+            // VOLK's magnitude sawtooth 1 + (g mod 512)*gm1 takes two values over the batch when NT is a multiple of
+            // 256 (g advances by NT per element): fold them into the batch phasor once
+            const float2 pf = make_float2((float)ph.x, (float)ph.y);
+            ph = cmul(ph, a.rot_8nt);
+            const long long gb = base + u0;
+            const bool whole = gb - t >= 0 && gb - t + NT * K <= count;
+            if (NT % 256 == 0 && whole) {
+                const int m0 = (int)(gb & 511);
+                const float g0 = fmaf((float)m0, a.gm1, 1.0f), g1 = fmaf((float)((m0 + NT) & 511), a.gm1, 1.0f);
+                const float2 p0 = make_float2(pf.x * g0, pf.y * g0), p1 = make_float2(pf.x * g1, pf.y * g1);
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    const float2 pb = (NT % 512 == 0 || (k & 1) == 0) ? p0 : p1;
+                    const float2 w = a.rot_k[k];
+                    const float pr = fmaf(pb.x, w.x, -pb.y * w.y), pi = fmaf(pb.x, w.y, pb.y * w.x);
+                    v[k] = rot_apply(v[k], pr, pi);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    const long long g = gb + k * NT;
+                    if (g >= 0 && g < count) v[k] = rotate_f(v[k], pf, a.rot_k[k], g, a.gm1);   // history is already rotated
+                }
+            }
+        }
 #pragma unroll
         for (int k = 0; k < K; k++) {
             const int u = u0 + k * NT;
-            const long long g = base + u;
-            if (ROT) {
-                if (g >= 0 && g < count) v[k] = rotate(v[k], ph, g, gm1);   // history is already rotated
-                ph = cmul(ph, rot_nt);
-            }
             if (u < U) put(u, v[k]);
         }
     }
@@ -161,6 +193,8 @@ struct CoreArgs {
     unsigned long long phase0;  // NCO phase of in[0]            (ROT only)
     unsigned long long dphase;  // NCO phase increment per sample (ROT only)
     double2 rot_nt;             // exp(j*2pi*NT*dphase)           (ROT only)
+    double2 rot_8nt;            // exp(j*2pi*8*NT*dphase): one staging batch further  (ROT only)
+    float2 rot_k[8];            // exp(j*2pi*k*NT*dphase), k = 0..7, FP32                 (ROT only)
     double2 rot_one;            // exp(j*2pi*dphase)              (ROT only)
     double2 rot_2nt;            // exp(j*2pi*2*NT*dphase)         (ROT only)
     float gm1;                  // |phase_inc| - 1, 0 = ideal NCO  (ROT only)
@@ -249,7 +283,7 @@ __global__ __launch_bounds__(NT) void fir_core_kernel(const CoreArgs a) {
             staged = true;
         }
     }
-    if (!staged) stage_tile<CH, NT, ROT>(in, hist, H, a.count, base, U, a.phase0, a.dphase, a.rot_nt, a.gm1, put);
+    if (!staged) stage_tile<CH, NT, ROT>(in, hist, H, a.count, base, U, a, put);
     __syncthreads();
 
     // ---- sliding-window dot products ------------------------------------------------------
@@ -318,6 +352,8 @@ struct AnyArgs {
     int tap_bytes;         // LT: bytes of LDS the table takes (multiple of 16)
     unsigned long long phase0, dphase;
     double2 rot_nt;        // exp(j*2pi*NT*dphase)   (ROT only)
+    double2 rot_8nt;            // exp(j*2pi*8*NT*dphase): one staging batch further  (ROT only)
+    float2 rot_k[8];            // exp(j*2pi*k*NT*dphase), k = 0..7, FP32                 (ROT only)
     float gm1;
 };
 
@@ -370,7 +406,7 @@ __global__ __launch_bounds__(NT) void resamp_any_kernel(const AnyArgs a) {
         const long long hi = ((n1 - 1) * a.M) / a.L;         // one past the last needed sample
         const int span = (int)(hi - lo);
         __syncthreads();                                     // the previous tile's reads are done (and `tl` is written)
-        stage_tile<CH, NT, ROT>(in, hist, P, a.count, lo, span, a.phase0, a.dphase, a.rot_nt, a.gm1, [&](int u, T v) { lds[u] = v; });
+        stage_tile<CH, NT, ROT>(in, hist, P, a.count, lo, span, a, [&](int u, T v) { lds[u] = v; });
         __syncthreads();
         // (n*M) / L and % L: one 64-bit division for the lane's first output of the tile, then n += NT moves
         // them by (NT*M) / L and % L with a carry
@@ -434,6 +470,8 @@ struct WinArgs {
     int nblocks;
     unsigned long long phase0, dphase;
     double2 rot_nt;        // exp(j*2pi*NT*dphase)   (ROT only)
+    double2 rot_8nt;            // exp(j*2pi*8*NT*dphase): one staging batch further  (ROT only)
+    float2 rot_k[8];            // exp(j*2pi*k*NT*dphase), k = 0..7, FP32                 (ROT only)
     float gm1;
 };
 
@@ -469,8 +507,7 @@ __global__ __launch_bounds__(NT) void decim_win_kernel(const WinArgs a) {
     const long long n0 = (long long)blockIdx.x * TILE;
     const long long base = n0 * M - P;              // stream position of staged element 0
     const int U = TILE * M + a.nchunks * MR;        // staged span: every chunk any lane reads (zero taps beyond P)
-    stage_tile<CH, NT, ROT>(in, hist, P, a.count, base, U, a.phase0, a.dphase, a.rot_nt, a.gm1,
-                            [&](int u, T v) { lds[u + (PAD ? u / MR : 0)] = v; });
+    stage_tile<CH, NT, ROT>(in, hist, P, a.count, base, U, a, [&](int u, T v) { lds[u + (PAD ? u / MR : 0)] = v; });
     __syncthreads();
 
     T acc[R];
@@ -548,6 +585,8 @@ struct LmArgs {
     int nblocks;
     unsigned long long phase0, dphase;
     double2 rot_nt;        // exp(j*2pi*NT*dphase)   (ROT only)
+    double2 rot_8nt;            // exp(j*2pi*8*NT*dphase): one staging batch further  (ROT only)
+    float2 rot_k[8];            // exp(j*2pi*k*NT*dphase), k = 0..7, FP32                 (ROT only)
     float gm1;
 };
 
@@ -583,7 +622,7 @@ __global__ __launch_bounds__(NT) void resamp_lm_kernel(const LmArgs a) {
     const long long base = j0 * M - P;                       // stream position of staged element 0
     const int V = TJ + Q + 1;                                // elements per branch (e_c < M adds at most one)
     const int U = V * M;
-    stage_tile<CH, NT, ROT>(in, hist, P, a.count, base, U, a.phase0, a.dphase, a.rot_nt, a.gm1, [&](int u, T v) {
+    stage_tile<CH, NT, ROT>(in, hist, P, a.count, base, U, a, [&](int u, T v) {
         const int vv = u / M, m = u - vv * M;
         lds[m * a.sb + vv] = v;
     });

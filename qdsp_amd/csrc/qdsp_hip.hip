@@ -317,6 +317,18 @@ void destroy(Engine* e) {
 
 // ---- launches --------------------------------------------------------------------------
 
+// NCO constants of stage_tile (kernels.hip.h) for a kernel staging with NT lanes
+template <class ARGS> void fill_stage_rot(ARGS& a, int NT) {
+    unit_of_fx(a.dphase, (long double)NT, &a.rot_nt.x, &a.rot_nt.y);
+    unit_of_fx(a.dphase, (long double)(8 * NT), &a.rot_8nt.x, &a.rot_8nt.y);
+    for (int k = 0; k < 8; k++) {
+        double c, sn;
+        unit_of_fx(a.dphase, (long double)(k * NT), &c, &sn);
+        a.rot_k[k] = make_float2((float)c, (float)sn);
+    }
+}
+
+
 // host copy of qk::slot (must match kernels.hip.h)
 inline int qk_slot_host(int R, int v) { return (R % 2 == 0) ? v + v / R : v; }
 
@@ -336,7 +348,7 @@ int launch_core_t(Engine* e, qk::CoreArgs& a, hipStream_t s) {
     a.nblocks = (int)((a.nout + TILE - 1) / TILE);
     a.vec = ((uintptr_t)a.in & 15) == 0;
     if (ROT) {
-        unit_of_fx(a.dphase, (long double)NT, &a.rot_nt.x, &a.rot_nt.y);
+        fill_stage_rot(a, NT);
         unit_of_fx(a.dphase, 1.0L, &a.rot_one.x, &a.rot_one.y);
         unit_of_fx(a.dphase, (long double)(2 * NT), &a.rot_2nt.x, &a.rot_2nt.y);
     }
@@ -401,7 +413,7 @@ template <int CH, bool ROT> int launch_win(Engine* e, const void* d_in, int64_t 
         const size_t lds = (size_t)(U + U / MR + 1) * CH * sizeof(float);
         if (lds > (size_t)kMaxDynLds) return QDSP_HIP_EINVAL;
         a.nblocks = (int)((nout + TILE - 1) / TILE);
-        unit_of_fx(a.dphase, (long double)NT, &a.rot_nt.x, &a.rot_nt.y);
+        fill_stage_rot(a, NT);
         hipLaunchKernelGGL((qk::decim_win_kernel<CH, M, R, NT, ROT>), dim3(a.nblocks + 1), dim3(NT), lds, s, a);
         HIPCHK(hipGetLastError());
         e->last.name = "decim_win_kernel";
@@ -458,7 +470,7 @@ template <int CH, bool ROT> int launch_lm(Engine* e, const void* d_in, int64_t c
         if (lds < lds_out) lds = lds_out;
         if (lds > (size_t)kMaxDynLds) return QDSP_HIP_EINVAL;
         a.nblocks = (int)((nout + (long long)TJ * LL - 1) / ((long long)TJ * LL));
-        unit_of_fx(a.dphase, (long double)NT, &a.rot_nt.x, &a.rot_nt.y);
+        fill_stage_rot(a, NT);
         hipLaunchKernelGGL((qk::resamp_lm_kernel<CH, R, NT, ROT, LL>), dim3(a.nblocks + 1), dim3(NT), lds, s, a);
         HIPCHK(hipGetLastError());
         e->last.name = "resamp_lm_kernel";
@@ -502,7 +514,7 @@ template <int CH, bool ROT> int launch_any(Engine* e, qk::AnyArgs& a, hipStream_
     if (nwg < 1) nwg = 1;
     a.nwg = nwg;
     const size_t lds = (size_t)a.tap_bytes + (size_t)span_of(tile) * CH * sizeof(float);
-    unit_of_fx(a.dphase, (long double)NT, &a.rot_nt.x, &a.rot_nt.y);
+    fill_stage_rot(a, NT);
     if (lt) hipLaunchKernelGGL((qk::resamp_any_kernel<CH, NT, ROT, true>), dim3(nwg + 1), dim3(NT), lds, s, a);
     else hipLaunchKernelGGL((qk::resamp_any_kernel<CH, NT, ROT, false>), dim3(nwg + 1), dim3(NT), lds, s, a);
     HIPCHK(hipGetLastError());
