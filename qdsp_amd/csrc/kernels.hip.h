@@ -453,7 +453,11 @@ __global__ __launch_bounds__(NT) void resamp_any_kernel(const AnyArgs a) {
 // it lies in memory (one pad element per M*R so the stride-M*R lane pattern falls on distinct banks),
 // lane t owns R consecutive outputs and walks its M*(R-1)+P samples ONCE: sample i feeds output r with
 // tap i - M r.  Taps come zero-padded by M*(R-1) on both sides so no tap index is ever tested, in
-// chunks of M*R consecutive scalars per output (s_load_dwordx8/x16 into SGPRs).  Accumulation is in tap
+// chunks of M*R consecutive scalars per output (s_load_dwordx8/x16 into SGPRs).  One tile per workgroup:
+// a persistent variant (tiles looped inside, the fused NCO's per-lane FP64 phasor carried from tile to tile
+// instead of one sincos per lane and tile) made the NCO free but the kernel itself 1.5-1.8x slower
+// (0.13 -> 0.23 ms per 2^26 samples at M = 10): block-level overlap of staging and arithmetic is lost.
+// Accumulation is in tap
 // order with one FMA per tap, so results equal the k-ordered fmaf chain bit for bit; the first and last
 // chunks, where some (sample, output) pairs fall outside the window, test the tap index instead of relying
 // on the zero padding, so a NaN/Inf sample stays inside the windows that hold it.
