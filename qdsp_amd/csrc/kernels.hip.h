@@ -116,16 +116,27 @@ __global__ __launch_bounds__(256) void ew_kernel(const EwArgs a) {
 // Eight independent loads are issued before the first is consumed: written as one load per loop trip
 // the compiler leaves them serialised (load, wait, LDS store, next load), and a tile's ~35 loads per
 // lane then cost ~35 memory latencies -- several times the arithmetic of the tile.
+// The fused NCO needs its exact phasor for lane t of tile `tile`: exp(j*(phase0 + (first + tile*S + t)*dphase)),
+// S = samples between tiles.  One FP64 sincos per lane and TILE cost these kernels 30-40 % (a tile is only
+// 8-16 staged samples per lane); instead the host keeps three small tables of exactly rounded FP64 phasors per
+// (dphase, S, NT) -- T0[b] = exp(j b S dphase), T1[a] = exp(j 256 a S dphase), W[t] = exp(j t dphase) -- and a
+// tile's lane phasor is e0 * T1[tile >> 8] * T0[tile & 255] * W[t]: three FP64 complex multiplies.
+template <class ARGS> __device__ __forceinline__ double2 tile_phasor(const ARGS& a, int tile, long long base, int t) {
+    if (!a.nco_tab) return phasor_fx(a.phase0 + (unsigned long long)(base + t) * a.dphase);
+    const double2 blk = cmul(cmul(a.nco_e0, a.nco_tab[256 + (tile >> 8)]), a.nco_tab[tile & 255]);
+    return cmul(blk, a.nco_tab[256 + a.nco_na + t]);
+}
+
 template <int CH, int NT, bool ROT, class ARGS, class PUT>
 __device__ __forceinline__ void stage_tile(const typename Smp<CH>::T* __restrict__ in, const typename Smp<CH>::T* __restrict__ hist,
-                                           int H, long long count, long long base, int U, const ARGS& a, PUT put) {
+                                           int H, long long count, long long base, int U, const ARGS& a, PUT put, int tile = -1) {
     using T = typename Smp<CH>::T;
     const int t = threadIdx.x;
     // NCO: one exact FP64 phasor per lane and batch of 8 staged samples (advanced by an FP64 rotation of 8*NT
     // samples), times an FP32 table exp(j k NT dphase) inside the batch: an FP64 complex multiply per staged
     // sample made the fused VFO 30-50 % slower than the plain decimator in these memory-bound kernels.
     double2 ph;
-    if (ROT) ph = phasor_fx(a.phase0 + (unsigned long long)(base + t) * a.dphase);
+    if (ROT) ph = tile >= 0 ? tile_phasor(a, tile, base, t) : phasor_fx(a.phase0 + (unsigned long long)(base + t) * a.dphase);
     constexpr int K = 8;
     for (int u0 = t; u0 < U; u0 += NT * K) {
         T v[K];
@@ -195,6 +206,9 @@ struct CoreArgs {
     double2 rot_nt;             // exp(j*2pi*NT*dphase)           (ROT only)
     double2 rot_8nt;            // exp(j*2pi*8*NT*dphase): one staging batch further  (ROT only)
     float2 rot_k[8];            // exp(j*2pi*k*NT*dphase), k = 0..7, FP32                 (ROT only)
+    const double2* nco_tab;     // [T0: 256][T1: nco_na][W: NT] unit phasors (see tile_phasor), nullptr: sincos per tile   (ROT only)
+    double2 nco_e0;             // exp(j*(phase0 + first*dphase)), first = stream position staged by lane 0 of tile 0
+    int nco_na;
     double2 rot_one;            // exp(j*2pi*dphase)              (ROT only)
     double2 rot_2nt;            // exp(j*2pi*2*NT*dphase)         (ROT only)
     float gm1;                  // |phase_inc| - 1, 0 = ideal NCO  (ROT only)
@@ -283,7 +297,7 @@ __global__ __launch_bounds__(NT) void fir_core_kernel(const CoreArgs a) {
             staged = true;
         }
     }
-    if (!staged) stage_tile<CH, NT, ROT>(in, hist, H, a.count, base, U, a, put);
+    if (!staged) stage_tile<CH, NT, ROT>(in, hist, H, a.count, base, U, a, put, (int)blockIdx.x);
     __syncthreads();
 
     // ---- sliding-window dot products ------------------------------------------------------
@@ -354,6 +368,9 @@ struct AnyArgs {
     double2 rot_nt;        // exp(j*2pi*NT*dphase)   (ROT only)
     double2 rot_8nt;            // exp(j*2pi*8*NT*dphase): one staging batch further  (ROT only)
     float2 rot_k[8];            // exp(j*2pi*k*NT*dphase), k = 0..7, FP32                 (ROT only)
+    const double2* nco_tab;     // [T0: 256][T1: nco_na][W: NT] unit phasors (see tile_phasor), nullptr: sincos per tile   (ROT only)
+    double2 nco_e0;             // exp(j*(phase0 + first*dphase)), first = stream position staged by lane 0 of tile 0
+    int nco_na;
     float gm1;
 };
 
@@ -476,6 +493,9 @@ struct WinArgs {
     double2 rot_nt;        // exp(j*2pi*NT*dphase)   (ROT only)
     double2 rot_8nt;            // exp(j*2pi*8*NT*dphase): one staging batch further  (ROT only)
     float2 rot_k[8];            // exp(j*2pi*k*NT*dphase), k = 0..7, FP32                 (ROT only)
+    const double2* nco_tab;     // [T0: 256][T1: nco_na][W: NT] unit phasors (see tile_phasor), nullptr: sincos per tile   (ROT only)
+    double2 nco_e0;             // exp(j*(phase0 + first*dphase)), first = stream position staged by lane 0 of tile 0
+    int nco_na;
     float gm1;
 };
 
@@ -511,7 +531,7 @@ __global__ __launch_bounds__(NT) void decim_win_kernel(const WinArgs a) {
     const long long n0 = (long long)blockIdx.x * TILE;
     const long long base = n0 * M - P;              // stream position of staged element 0
     const int U = TILE * M + a.nchunks * MR;        // staged span: every chunk any lane reads (zero taps beyond P)
-    stage_tile<CH, NT, ROT>(in, hist, P, a.count, base, U, a, [&](int u, T v) { lds[u + (PAD ? u / MR : 0)] = v; });
+    stage_tile<CH, NT, ROT>(in, hist, P, a.count, base, U, a, [&](int u, T v) { lds[u + (PAD ? u / MR : 0)] = v; }, (int)blockIdx.x);
     __syncthreads();
 
     T acc[R];
@@ -591,6 +611,9 @@ struct LmArgs {
     double2 rot_nt;        // exp(j*2pi*NT*dphase)   (ROT only)
     double2 rot_8nt;            // exp(j*2pi*8*NT*dphase): one staging batch further  (ROT only)
     float2 rot_k[8];            // exp(j*2pi*k*NT*dphase), k = 0..7, FP32                 (ROT only)
+    const double2* nco_tab;     // [T0: 256][T1: nco_na][W: NT] unit phasors (see tile_phasor), nullptr: sincos per tile   (ROT only)
+    double2 nco_e0;             // exp(j*(phase0 + first*dphase)), first = stream position staged by lane 0 of tile 0
+    int nco_na;
     float gm1;
 };
 
@@ -629,7 +652,7 @@ __global__ __launch_bounds__(NT) void resamp_lm_kernel(const LmArgs a) {
     stage_tile<CH, NT, ROT>(in, hist, P, a.count, base, U, a, [&](int u, T v) {
         const int vv = u / M, m = u - vv * M;
         lds[m * a.sb + vv] = v;
-    });
+    }, (int)blockIdx.x);
     __syncthreads();
 
     T acc[L][R];

@@ -53,6 +53,10 @@ struct Engine {
     float gm1 = 0.0f;          // |phase_inc| - 1
     // device state
     float* d_taps = nullptr;
+    double2* d_nco_tab = nullptr;  // tile_phasor tables of the direct kernels (fused NCO)
+    unsigned long long nco_key_dphase = 0;
+    long long nco_key_S = 0;
+    int nco_key_NT = 0, nco_key_na = 0;
     float* d_hist_raw = nullptr;  // overlap-save VFO: the history de-rotated for the current call
     int hist_raw_cap = 0;
     float* d_taps_lm = nullptr;  // resamp_lm_kernel's per-sub-filter branch-major taps (small interp only)
@@ -301,6 +305,7 @@ void destroy(Engine* e) {
     if (e->d_taps) (void)hipFree(e->d_taps);
     if (e->d_taps_lm) (void)hipFree(e->d_taps_lm);
     if (e->d_hist_raw) (void)hipFree(e->d_hist_raw);
+    if (e->d_nco_tab) (void)hipFree(e->d_nco_tab);
     if (e->d_fft_H) (void)hipFree(e->d_fft_H);
     if (e->d_fft_TA) (void)hipFree(e->d_fft_TA);
     if (e->d_fft_TB) (void)hipFree(e->d_fft_TB);
@@ -317,7 +322,6 @@ void destroy(Engine* e) {
 
 // ---- launches --------------------------------------------------------------------------
 
-// NCO constants of stage_tile (kernels.hip.h) for a kernel staging with NT lanes
 template <class ARGS> void fill_stage_rot(ARGS& a, int NT) {
     unit_of_fx(a.dphase, (long double)NT, &a.rot_nt.x, &a.rot_nt.y);
     unit_of_fx(a.dphase, (long double)(8 * NT), &a.rot_8nt.x, &a.rot_8nt.y);
@@ -327,6 +331,47 @@ template <class ARGS> void fill_stage_rot(ARGS& a, int NT) {
         a.rot_k[k] = make_float2((float)c, (float)sn);
     }
 }
+
+// tile_phasor's tables (kernels.hip.h), cached per handle for (dphase, S, NT, na); rebuilt on a retune or a new geometry
+int nco_tables(Engine* e, long long S, int NT, int na, const double2** tab) {
+    if (e->d_nco_tab && e->nco_key_dphase == e->dphase && e->nco_key_S == S && e->nco_key_NT == NT && e->nco_key_na >= na) {
+        *tab = e->d_nco_tab;
+        return 0;
+    }
+    if (na < 64) na = 64;
+    std::vector<double2> h((size_t)256 + na + NT);
+    for (int b = 0; b < 256; b++) unit_of_fx(e->dphase, (long double)b * (long double)S, &h[b].x, &h[b].y);
+    for (int a2 = 0; a2 < na; a2++) unit_of_fx(e->dphase, 256.0L * (long double)a2 * (long double)S, &h[256 + a2].x, &h[256 + a2].y);
+    for (int t = 0; t < NT; t++) unit_of_fx(e->dphase, (long double)t, &h[256 + na + t].x, &h[256 + na + t].y);
+    HIPCHK(hipDeviceSynchronize());       // (rare: nothing in flight may still read the old tables)
+    if (e->d_nco_tab) HIPCHK(hipFree(e->d_nco_tab));
+    e->d_nco_tab = nullptr;
+    HIPCHK(hipMalloc(&e->d_nco_tab, h.size() * sizeof(double2)));
+    HIPCHK(hipMemcpy(e->d_nco_tab, h.data(), h.size() * sizeof(double2), hipMemcpyHostToDevice));
+    e->nco_key_dphase = e->dphase;
+    e->nco_key_S = S;
+    e->nco_key_NT = NT;
+    e->nco_key_na = na;
+    *tab = e->d_nco_tab;
+    return 0;
+}
+
+// NCO constants of stage_tile (kernels.hip.h) for a kernel staging with NT lanes; with the tile geometry (S samples
+// between tiles, `first` = stream position staged by lane 0 of tile 0, ntiles) also the tile_phasor tables
+template <class ARGS> int fill_stage_rot(Engine* e, ARGS& a, int NT, long long S, long long first, long long ntiles) {
+    fill_stage_rot(a, NT);
+    a.nco_tab = nullptr;
+    if (!e->rotate || env_int("QDSP_HIP_NO_NCO_TABLES", 0)) return 0;
+    const int na = (int)((ntiles + 255) / 256) + 1;
+    if (na > 65536) return 0;
+    int rc = nco_tables(e, S, NT, na, &a.nco_tab);
+    if (rc) return rc;
+    a.nco_na = e->nco_key_na;
+    const unsigned long long ph = a.phase0 + (unsigned long long)first * a.dphase;
+    unit_of_fx(ph, 1.0L, &a.nco_e0.x, &a.nco_e0.y);
+    return 0;
+}
+
 
 
 // host copy of qk::slot (must match kernels.hip.h)
@@ -348,7 +393,7 @@ int launch_core_t(Engine* e, qk::CoreArgs& a, hipStream_t s) {
     a.nblocks = (int)((a.nout + TILE - 1) / TILE);
     a.vec = ((uintptr_t)a.in & 15) == 0;
     if (ROT) {
-        fill_stage_rot(a, NT);
+        { int rcn = fill_stage_rot(e, a, NT, (long long)TILE * a.M, -(long long)a.H, a.nblocks); if (rcn) return rcn; }
         unit_of_fx(a.dphase, 1.0L, &a.rot_one.x, &a.rot_one.y);
         unit_of_fx(a.dphase, (long double)(2 * NT), &a.rot_2nt.x, &a.rot_2nt.y);
     }
@@ -413,7 +458,7 @@ template <int CH, bool ROT> int launch_win(Engine* e, const void* d_in, int64_t 
         const size_t lds = (size_t)(U + U / MR + 1) * CH * sizeof(float);
         if (lds > (size_t)kMaxDynLds) return QDSP_HIP_EINVAL;
         a.nblocks = (int)((nout + TILE - 1) / TILE);
-        fill_stage_rot(a, NT);
+        { int rcn = fill_stage_rot(e, a, NT, (long long)TILE * M, -(long long)a.P, a.nblocks); if (rcn) return rcn; }
         hipLaunchKernelGGL((qk::decim_win_kernel<CH, M, R, NT, ROT>), dim3(a.nblocks + 1), dim3(NT), lds, s, a);
         HIPCHK(hipGetLastError());
         e->last.name = "decim_win_kernel";
@@ -470,7 +515,7 @@ template <int CH, bool ROT> int launch_lm(Engine* e, const void* d_in, int64_t c
         if (lds < lds_out) lds = lds_out;
         if (lds > (size_t)kMaxDynLds) return QDSP_HIP_EINVAL;
         a.nblocks = (int)((nout + (long long)TJ * LL - 1) / ((long long)TJ * LL));
-        fill_stage_rot(a, NT);
+        { int rcn = fill_stage_rot(e, a, NT, (long long)TJ * a.M, -(long long)a.P, a.nblocks); if (rcn) return rcn; }
         hipLaunchKernelGGL((qk::resamp_lm_kernel<CH, R, NT, ROT, LL>), dim3(a.nblocks + 1), dim3(NT), lds, s, a);
         HIPCHK(hipGetLastError());
         e->last.name = "resamp_lm_kernel";
