@@ -795,3 +795,26 @@ def test_any_decimation_strided_store(ops, gold, M):
     o = O.Resampler(taps, 1, M, acc=O.ACC_F64)
     want = np.concatenate([o.process(x[a:b]) for a, b in zip(cuts, cuts[1:])])
     assert y.shape == want.shape and len(y) >= 3 and rel_rms(y, want) < 2e-6
+
+
+@pytest.mark.parametrize("M,ntaps", [(8, 63), (8, 256), (10, 256), (3, 150)])
+def test_vfo_retune_mid_stream(ops, gold, M, ntaps):
+    """FrequencyXlator::setFrequency between blocks (processing.h:45-49: "no need to restart"): the carried phase
+    continues, only the increment changes.  Exercises the per-handle caches that follow the NCO -- the
+    overlap-save spectrum of taps*exp(jk dphase) and the direct kernels' phasor tables."""
+    taps = O.lowpass_taps_f64(ntaps, 0.4 / M).astype(np.float32)
+    blk = 512 * M * 20                      # multiples of lcm(M, 512): polyphase counter and VOLK gain restart together
+    x = O.synth_iq(0, 3 * blk, seed=M + ntaps)
+    freqs = [1234.0, -7000.0, 321.5]
+    v = ops.Vfo(taps, 1, M, ops.phase_delta(48000.0, freqs[0]))
+    xl, rs = O.Xlator(48000.0, freqs[0], exact=True, volk_gain=True), O.Resampler(taps, 1, M, acc=O.ACC_F64)
+    got, want = [], []
+    for i, f in enumerate(freqs):
+        if i:
+            v.set_phase_inc(*ops.phase_delta(48000.0, f))
+            O.lib().oracle_xlator_phase_delta(48000.0, f, O._fp(xl.delta))
+        seg = x[i * blk:(i + 1) * blk]
+        got.append(v.process(dev(seg)).cpu().numpy())
+        want.append(rs.process(xl.process(seg)))
+    got, want = np.concatenate(got), np.concatenate(want)
+    assert got.shape == want.shape and rel_rms(got, want) < 3e-6
