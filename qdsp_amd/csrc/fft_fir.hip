@@ -134,7 +134,21 @@ __global__ __launch_bounds__(kFftNT, (DEC == 1 && !ROT && !REAL) ? 4 : 3) void f
         if constexpr (REAL) {
             const float* __restrict__ inr = reinterpret_cast<const float*>(a.in);
             const float* __restrict__ hr = reinterpret_cast<const float*>(a.hist);
-            if (interior) {
+            if (interior && a.vec) {
+                // 8-byte loads, as the complex path does with 16-byte ones: lanes l and l+32 own the adjacent elements
+                // (te & ~1, +1); each loads both for half the rows (of segment A and of segment B) and trades
+                // halves with v_permlane32_swap
+                const float2* __restrict__ pa = reinterpret_cast<const float2*>(inr + seg0 + (te & ~1)) + half * 8 * 128;
+                const float2* __restrict__ pb = reinterpret_cast<const float2*>(inr + segB + (te & ~1)) + half * 8 * 128;
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const float2 qa = pa[r * 128], qb = pb[r * 128];
+                    const auto sa = __builtin_amdgcn_permlane32_swap(__float_as_uint(qa.x), __float_as_uint(qa.y), false, false);
+                    const auto sb = __builtin_amdgcn_permlane32_swap(__float_as_uint(qb.x), __float_as_uint(qb.y), false, false);
+                    v[r] = make_float2(__uint_as_float(sa[0]), __uint_as_float(sb[0]));
+                    v[8 + r] = make_float2(__uint_as_float(sa[1]), __uint_as_float(sb[1]));
+                }
+            } else if (interior) {
 #pragma unroll
                 for (int n2 = 0; n2 < 16; n2++) v[n2] = make_float2(inr[seg0 + n2 * 256 + te], inr[segB + n2 * 256 + te]);
             } else {
@@ -273,6 +287,21 @@ __global__ __launch_bounds__(kFftNT, (DEC == 1 && !ROT && !REAL) ? 4 : 3) void f
                     seg_split(seg0 + 1, qA, rA);
                     seg_split(segB + 1, qB, rB);
                 }
+                if (!a.strided && interior && a.vec && segB + kFftN <= a.nout) {
+                    // FIR<float>: the mirror image of the loads -- 8-byte stores of both segments
+                    float2* __restrict__ oa = reinterpret_cast<float2*>(outr + seg0 + (te & ~1)) + half * 8 * 128;
+                    float2* __restrict__ ob = reinterpret_cast<float2*>(outr + segB + (te & ~1)) + half * 8 * 128;
+#pragma unroll
+                    for (int r = 0; r < 8; r++) {
+                        const float2 lo_row = v[rev16(r)], hi_row = v[rev16(8 + r)];
+                        const auto sa = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo_row.x), __float_as_uint(hi_row.x), false, false);
+                        const auto sb = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo_row.y), __float_as_uint(hi_row.y), false, false);
+                        if ((half * 8 + r) * 256 + (te & ~1) >= a.ov) {   // ov is even: both elements or neither
+                            oa[r * 128] = make_float2(__uint_as_float(sa[0]), __uint_as_float(sa[1]));
+                            ob[r * 128] = make_float2(__uint_as_float(sb[0]), __uint_as_float(sb[1]));
+                        }
+                    }
+                } else
 #pragma unroll
                 for (int n2 = 0; n2 < 16; n2++) {
                     if (n2 * 256 + te < a.ov) continue;

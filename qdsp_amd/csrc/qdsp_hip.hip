@@ -750,7 +750,8 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
     }
     if (e->ch == 1) {   // real data: one workgroup iteration = a PAIR of real segments
         a.real2 = 1;
-        a.vec = 0;
+        // 8-byte pair accesses: segments start on even samples (L, ov, seg_shift are even) of 8-byte aligned buffers
+        a.vec = ((((uintptr_t)d_in) | ((uintptr_t)d_out)) & 7) == 0 && !env_int("QDSP_HIP_FFT_NOVEC", 0);
         a.nblocks = (a.nblocks + 1) / 2;
     }
     // FIR: 4 workgroups resident per CU (124 VGPRs, 37 KB LDS), 16 queued per CU for balance.
