@@ -15,6 +15,20 @@ __global__ __launch_bounds__(256) void copy16(const float4* __restrict__ in, flo
         for (int u = 0; u < UNROLL; u++) out[base + u * 256] = v[u];
     }
 }
+// one float4 per lane, no loop: as many blocks as it takes
+__global__ __launch_bounds__(256) void copy16_oneshot(const float4* __restrict__ in, float4* __restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+template <int PER> __global__ __launch_bounds__(256) void copy16_few(const float4* __restrict__ in, float4* __restrict__ out, long long n) {
+    const long long base = (long long)blockIdx.x * 256 * PER + threadIdx.x;
+    float4 v[PER];
+#pragma unroll
+    for (int u = 0; u < PER; u++) if (base + u * 256 < n) v[u] = in[base + u * 256];
+#pragma unroll
+    for (int u = 0; u < PER; u++) if (base + u * 256 < n) out[base + u * 256] = v[u];
+}
+
 __global__ __launch_bounds__(256) void read16(const float4* __restrict__ in, float4* __restrict__ out, long long n) {
     const long long stride = (long long)gridDim.x * 256 * 4;
     float4 acc = make_float4(0, 0, 0, 0);
@@ -43,6 +57,18 @@ int main() {
     for (int i = 0; i < 10; i++) hipLaunchKernelGGL(copy16<8>, dim3(8192), dim3(256), 0, 0, a, b, n);
     hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
     printf("copy16 unroll 8 grid   8192: %.3f ms  %.0f GB/s\n", ms / 10, 2.0 * n * 16 / (ms / 10) / 1e6);
+    hipEventRecord(e0);
+    for (int i = 0; i < 10; i++) hipLaunchKernelGGL(copy16_oneshot, dim3((unsigned)(n / 256)), dim3(256), 0, 0, a, b, n);
+    hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+    printf("copy16 one float4 per lane, %lld blocks: %.3f ms  %.0f GB/s\n", n / 256, ms / 10, 2.0 * n * 16 / (ms / 10) / 1e6);
+    hipEventRecord(e0);
+    for (int i = 0; i < 10; i++) hipLaunchKernelGGL(copy16_few<2>, dim3((unsigned)(n / 512)), dim3(256), 0, 0, a, b, n);
+    hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+    printf("copy16 two float4 per lane, %lld blocks: %.3f ms  %.0f GB/s\n", n / 512, ms / 10, 2.0 * n * 16 / (ms / 10) / 1e6);
+    hipEventRecord(e0);
+    for (int i = 0; i < 10; i++) hipLaunchKernelGGL(copy16_few<4>, dim3((unsigned)(n / 1024)), dim3(256), 0, 0, a, b, n);
+    hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+    printf("copy16 four float4 per lane, %lld blocks: %.3f ms  %.0f GB/s\n", n / 1024, ms / 10, 2.0 * n * 16 / (ms / 10) / 1e6);
     hipEventRecord(e0);
     for (int i = 0; i < 10; i++) hipMemcpyAsync(b, a, n * 16, hipMemcpyDeviceToDevice, 0);
     hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
