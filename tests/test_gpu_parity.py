@@ -818,3 +818,47 @@ def test_vfo_retune_mid_stream(ops, gold, M, ntaps):
         want.append(rs.process(xl.process(seg)))
     got, want = np.concatenate(got), np.concatenate(want)
     assert got.shape == want.shape and rel_rms(got, want) < 3e-6
+
+
+def test_bench_size_cross_checks(ops, gold):
+    """The bench's size (2^27 samples per call = 1 GiB in: byte offsets past 2^31): independent kernels must agree.
+    Overlap-save FIR vs direct form; fused overlap-save VFO vs NCO kernel -> decimator; polyphase channelizer vs
+    one fused kernel per channel; spot windows of the FIR against the CPU oracle."""
+    import torch
+
+    n = 1 << 27
+    taps = gold["taps256"]
+    x = ops.synth_iq(n, seed=1234)
+    f = ops.Fir(taps)
+    y = f.process(x)
+    assert f.last_kernel()["name"] == "fir_fft_kernel"
+    for start in (0, (1 << 26) + 12_345, n - 70_000):            # the far windows sit past the 2^31-byte mark
+        lo = max(start - 255, 0)
+        xh = O.synth_iq(lo, 65_536 + (start - lo), seed=1234)
+        want = O.Fir(taps, acc=O.ACC_F64).process(xh)[start - lo:]
+        got = y[start:start + 65_536].cpu().numpy()
+        sl = slice(255 if start else 0, None)
+        assert rel_rms(got[sl], want[sl]) < 2e-6, start
+    d = ops.Fir(taps)
+    d.set_mode(d.DIRECT)
+    yd = d.process(x)
+    assert (y - yd).abs().max().item() < 2e-5 * yd.abs().max().item()
+    del yd, d
+    inc = ops.phase_delta(1.0, 0.1234)
+    v = ops.Vfo(taps, 1, 8, inc)
+    yv = v.process(x)
+    assert v.last_kernel()["name"] == "fir_fft_kernel" and yv.numel() == n // 8
+    xl, rs = ops.Xlator(phase_inc=inc), ops.Resampler(taps, 1, 8)
+    y2 = rs.process(xl.process(x))
+    assert (yv - y2).abs().max().item() < 2e-5 * y2.abs().max().item()
+    del y2, yv
+    incs = [ops.phase_delta(1.0, -(c - 31.5) / 64.0) for c in range(64)]
+    ch = ops.Channelizer(gold["taps256"], 1, 64, incs, max_block=0)
+    yc = ch.process(x)
+    assert ch.last_kernel()["name"] == "chan_uniform_kernel" and tuple(yc.shape) == (64, n // 64)
+    for c in (0, 37, 63):
+        one = ops.Vfo(gold["taps256"], 1, 64, incs[c])
+        one.set_mode(one.DIRECT)
+        yo = one.process(x)
+        assert (yc[c] - yo).abs().max().item() < 4e-5 * yo.abs().max().item(), c
+    torch.cuda.synchronize()
