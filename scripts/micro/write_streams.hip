@@ -107,7 +107,7 @@ int main(int argc, char** argv) {
         float2* din; hipMalloc(&din, 64 * stride * 8 + 8192);
         hipMemset(din, 0, 64 * stride * 8 + 8192);
         const int ntiles = (int)(stride / 16);
-        for (int wpc = 8; wpc <= 32; wpc *= 2) {
+        for (int wpc = 8; wpc <= 512; wpc *= 4) {
             const int nwg = 256 * wpc / 4 * 4 / 4 * 1, nwaves = nwg * 4;
             for (int i = 0; i < 3; i++) hipLaunchKernelGGL(skel<19>, dim3(nwg), dim3(256), 0, 0, din, d, stride, ntiles, nwaves);
             hipEventRecord(e0);
