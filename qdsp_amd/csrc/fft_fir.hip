@@ -19,6 +19,9 @@
 //     more VGPRs than the halved issue count buys -- 372 B/lane of scratch at 128 VGPRs
 //     (0.86 ms), still 84 B at 168 VGPRs and 3 waves/SIMD (0.55 ms) vs 0.41 ms scalar; the
 //     grouped decimators 0.36 / 0.43 ms vs 0.33 / 0.36 ms;
+//   * the next segment's loads issued during passes B .. A' of fir_fft_kernel<1> (as the grouped decimator
+//     kernel does), at 3 waves/SIMD to make room for the 32 registers: 0.464 vs 0.440 ms on the same box --
+//     the fourth wave per SIMD hides more than the prefetch does;
 //   * 16-byte loads by lane pairs (as fir_fft_kernel does) in the grouped decimator kernel, with
 //     segments moved to even starts: 248 VGPRs, decim-8 0.36 ms vs 0.33 ms with 8-byte loads;
 //   * non-temporal loads/stores for the sample stream: +-1 %;
