@@ -18,7 +18,7 @@ BIN = os.path.join(HOST, "build", "graph_check")
 
 @pytest.fixture(scope="module")
 def harness():
-    if not os.path.exists(BIN):
+    if not os.path.exists(BIN) or not os.path.exists(os.path.join(os.path.dirname(BIN), "patch_b_fir")):
         subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL, timeout=300)
     return BIN
 
@@ -204,6 +204,21 @@ def test_graph_splitter_to_vfos(harness, data):
         v = O.Vfo(float(off), 2.4e6, 240e3, 200e3, exact_nco=True, volk_gain=True)
         want = np.concatenate([v.process(x[j:j + b]) for j in range(0, len(x), b)])
         assert len(y) == len(want) and rel_rms(y, want) < 3e-6, i
+
+
+@gpu
+def test_integration_patch_b_fir(harness, data):
+    """INTEGRATION.md section B compiled: a block that keeps its own stream / window types and only swaps the
+    VOLK loop for qdsp_hip_fir_cf32_process (examples/patch_b_fir.cpp)."""
+    d, x = data
+    exe = os.path.join(os.path.dirname(harness), "patch_b_fir")
+    assert os.path.exists(exe)
+    taps = O.lowpass_taps_f64(256, 0.0625).astype(np.float32)
+    taps.tofile(d / "t256b.f32")
+    run([exe, str(d / "x.cf32"), str(d / "yb.cf32"), "65536", str(d / "t256b.f32")])
+    y = np.fromfile(d / "yb.cf32", dtype=np.complex64)
+    want = blocks(O.Fir(taps, acc=O.ACC_F64), x, 65536)
+    assert len(y) == len(want) and rel_rms(y, want) < 2e-6
 
 
 @gpu
