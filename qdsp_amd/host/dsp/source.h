@@ -44,16 +44,10 @@ public:
     }
     int getBlockSize() { return _blockSize; }
 
-    void setSampleRate(float sampleRate) {
-        _sampleRate = sampleRate;
-        push();
-    }
+    // (both retune the running NCO between two run() calls; the phase carries on)
+    void setSampleRate(float sampleRate) { retune(sampleRate, _freq); }
+    void setFrequency(float freq) { retune(_sampleRate, freq); }
     float getSampleRate() { return _sampleRate; }
-
-    void setFrequency(float freq) {
-        _freq = freq;
-        push();
-    }
     float getFrequency() { return _freq; }
 
     int run() override {
@@ -75,7 +69,9 @@ private:
         dRe = std::cos(theta);
         dIm = std::sin(theta);
     }
-    void push() {
+    void retune(float sampleRate, float freq) {
+        _sampleRate = sampleRate;
+        _freq = freq;
         float dRe, dIm;
         delta(dRe, dIm);
         if (handle) { qdsp_hip_sine_cf32_set_phase_inc(handle, dRe, dIm); }
@@ -91,20 +87,21 @@ class HandlerSource : public generic_block<HandlerSource<T>> {
     using base = generic_block<HandlerSource<T>>;
 
 public:
-    HandlerSource() {}
-    HandlerSource(int (*handler)(T* data, void* ctx), void* ctx) { init(handler, ctx); }
+    // fills `data` (room for STREAM_BUFFER_SIZE samples) and returns how many it wrote, < 0 to end the stream
+    using fill_fn = int (*)(T* data, void* ctx);
 
-    void init(int (*handler)(T* data, void* ctx), void* ctx) {
-        _handler = handler;
-        _ctx = ctx;
+    HandlerSource() {}
+    HandlerSource(fill_fn handler, void* ctx) { init(handler, ctx); }
+
+    void init(fill_fn handler, void* ctx) {
+        bind(handler, ctx);
         base::registerOutput(&out);
     }
 
-    void setHandler(int (*handler)(T* data, void* ctx), void* ctx) {
+    void setHandler(fill_fn handler, void* ctx) {
         std::lock_guard<std::mutex> lck(base::ctrlMtx);
         base::tempStop();
-        _handler = handler;
-        _ctx = ctx;
+        bind(handler, ctx);
         base::tempStart();
     }
 
@@ -121,7 +118,12 @@ public:
     stream<T> out;
 
 private:
-    int (*_handler)(T* data, void* ctx) = nullptr;
+    void bind(fill_fn handler, void* ctx) {
+        _handler = handler;
+        _ctx = ctx;
+    }
+
+    fill_fn _handler = nullptr;
     void* _ctx = nullptr;
 };
 

@@ -50,72 +50,76 @@ inline float blackmanRawTaps(float* taps, int tapCount, float cutoff, float samp
 }
 }  // namespace detail
 
-class BlackmanWindow : public generic_window {
+// cutoff / transition width / sample rate (+ band centre): the state both Blackman designers keep, with the
+// reference's setter names
+class blackman_params : public generic_window {
 public:
-    BlackmanWindow() {}
-    BlackmanWindow(float cutoff, float transWidth, float sampleRate) { init(cutoff, transWidth, sampleRate); }
-
-    void init(float cutoff, float transWidth, float sampleRate) {
-        _cutoff = cutoff;
-        _transWidth = transWidth;
-        _sampleRate = sampleRate;
-    }
-
     void setSampleRate(float sampleRate) { _sampleRate = sampleRate; }
     void setCutoff(float cutoff) { _cutoff = cutoff; }
     void setTransWidth(float transWidth) { _transWidth = transWidth; }
 
     int getTapCount() override { return detail::blackmanTapCount(_transWidth, _sampleRate); }
 
-    void createTaps(float* taps, int tapCount, float factor = 1.0f) override {
-        const float sum = detail::blackmanRawTaps(taps, tapCount, _cutoff, _sampleRate);
+protected:
+    void keep(float cutoff, float transWidth, float sampleRate) {
+        _cutoff = cutoff;
+        _transWidth = transWidth;
+        _sampleRate = sampleRate;
+    }
+    // taps[i] = raw[i] * shift(i) * factor / sum(raw), each step rounded to float in this order
+    template <class SHIFT> void design(float* taps, int tapCount, float factor, SHIFT shift) {
+        const float total = detail::blackmanRawTaps(taps, tapCount, _cutoff, _sampleRate);
         for (int i = 0; i < tapCount; i++) {
+            shift(taps[i], i);
             taps[i] *= factor;
-            taps[i] /= sum;
+            taps[i] /= total;
         }
     }
 
-private:
     float _cutoff = 0.0f, _transWidth = 1.0f, _sampleRate = 1.0f;
 };
 
-class BlackmanBandpassWindow : public generic_window {
+class BlackmanWindow : public blackman_params {
+public:
+    BlackmanWindow() {}
+    BlackmanWindow(float cutoff, float transWidth, float sampleRate) { init(cutoff, transWidth, sampleRate); }
+    void init(float cutoff, float transWidth, float sampleRate) { keep(cutoff, transWidth, sampleRate); }
+
+    void createTaps(float* taps, int tapCount, float factor = 1.0f) override {
+        design(taps, tapCount, factor, [](float&, int) {});
+    }
+};
+
+class BlackmanBandpassWindow : public blackman_params {
 public:
     BlackmanBandpassWindow() {}
     BlackmanBandpassWindow(float cutoff, float transWidth, float offset, float sampleRate) { init(cutoff, transWidth, offset, sampleRate); }
-
     void init(float cutoff, float transWidth, float offset, float sampleRate) {
-        _cutoff = cutoff;
-        _transWidth = transWidth;
+        keep(cutoff, transWidth, sampleRate);
         _offset = offset;
-        _sampleRate = sampleRate;
     }
-
-    void setSampleRate(float sampleRate) { _sampleRate = sampleRate; }
-    void setCutoff(float cutoff) { _cutoff = cutoff; }
-    void setTransWidth(float transWidth) { _transWidth = transWidth; }
     void setOffset(float offset) { _offset = offset; }
 
-    int getTapCount() override { return detail::blackmanTapCount(_transWidth, _sampleRate); }
-
     void createTaps(float* taps, int tapCount, float factor = 1.0f) override {
-        const float sum = detail::blackmanRawTaps(taps, tapCount, _cutoff, _sampleRate);
-        for (int i = 0; i < tapCount; i++) {
-            taps[i] *= cosf(2.0f * (_offset / _sampleRate) * FL_M_PI * (float)i);  // shift to the band centre
-            taps[i] *= factor;
-            taps[i] /= sum;
-        }
+        // the low-pass prototype moved to the band centre by a cosine at offset/sampleRate cycles per sample
+        design(taps, tapCount, factor, [this](float& tap, int i) { tap *= cosf(2.0f * (_offset / _sampleRate) * FL_M_PI * (float)i); });
     }
 
 private:
-    float _cutoff = 0.0f, _transWidth = 1.0f, _sampleRate = 1.0f, _offset = 0.0f;
+    float _offset = 0.0f;
 };
 
 }  // namespace filter_window
 
-// Root-raised-cosine taps (the reference credits GNU Radio's firdes::root_raised_cosine).
-// Arithmetic is double with the float FL_M_PI and a float samples-per-symbol ratio, exactly
-// as in the reference (src/dsp/window.h:181-225).
+// Root-raised-cosine taps (the reference credits GNU Radio's firdes::root_raised_cosine for the closed form).
+// The arithmetic is double throughout, fed by the FLOAT constant FL_M_PI and a float samples-per-symbol
+// ratio, and every expression keeps the reference's operand order (src/dsp/window.h:181-225), because the
+// taps must come out bit for bit.  Three cases per tap, by t = offset from the centre tap and
+// q = (4 alpha t / sps)^2 - 1:
+//   regular (|q| >= 1e-6): 4 alpha (cos((1+alpha) pi t/sps) + S) / (q pi), S = sin((1-alpha) pi t/sps) / (4 alpha t/sps),
+//                          or its limit (1-alpha) pi / (4 alpha) at the centre tap;
+//   singular, alpha == 1:  the tap is -1;
+//   singular otherwise:    the l'Hopital form below.
 class RRCTaps : public filter_window::generic_window {
 public:
     RRCTaps() {}
@@ -129,49 +133,42 @@ public:
     }
 
     int getTapCount() override { return _tapCount; }
+    void setTapCount(int count) { _tapCount = count; }
     void setSampleRate(float sampleRate) { _sampleRate = sampleRate; }
     void setBaudRate(float baudRate) { _baudRate = baudRate; }
-    void setTapCount(int count) { _tapCount = count; }
     void setAlpha(float alpha) { _alpha = alpha; }
 
     void createTaps(float* taps, int tapCount, float factor = 1.0f) override {
-        (void)factor;  // the reference ignores it too
-        tapCount |= 1;
-        const double spb = _sampleRate / _baudRate;  // samples per symbol
-        const int mid = tapCount / 2;
-        double scale = 0;
+        (void)factor;                       // ignored, as in the reference
+        tapCount |= 1;                      // (sic) an even request writes one tap more
+        const int centre = tapCount / 2;
+        const double sps = _sampleRate / _baudRate;
+        double total = 0;
         for (int i = 0; i < tapCount; i++) {
-            const double xi = i - mid;
-            double x1 = FL_M_PI * xi / spb;
-            double x2 = 4 * _alpha * xi / spb;
-            double x3 = x2 * x2 - 1;
-            double num, den;
-            if (fabs(x3) >= 0.000001) {
-                if (i != mid) {
-                    num = cos((1 + _alpha) * x1) + sin((1 - _alpha) * x1) / (4 * _alpha * xi / spb);
-                } else {
-                    num = cos((1 + _alpha) * x1) + (1 - _alpha) * FL_M_PI / (4 * _alpha);
-                }
-                den = x3 * FL_M_PI;
-            } else {
-                if (_alpha == 1) {
-                    taps[i] = -1;
-                    scale += taps[i];
-                    continue;
-                }
-                x3 = (1 - _alpha) * x1;
-                x2 = (1 + _alpha) * x1;
-                num = (sin(x2) * (1 + _alpha) * FL_M_PI - cos(x3) * ((1 - _alpha) * FL_M_PI * spb) / (4 * _alpha * xi) +
-                       sin(x3) * spb * spb / (4 * _alpha * xi * xi));
-                den = -32 * FL_M_PI * _alpha * _alpha * xi / spb;
-            }
-            taps[i] = 4 * _alpha * num / den;
-            scale += taps[i];
+            taps[i] = (float)tapAt(i, centre, sps);
+            total += taps[i];
         }
-        for (int i = 0; i < tapCount; i++) { taps[i] = taps[i] / scale; }
+        for (int i = 0; i < tapCount; i++) { taps[i] = taps[i] / total; }
     }
 
 private:
+    double tapAt(int i, int centre, double sps) const {
+        const double t = i - centre;
+        const double arg = FL_M_PI * t / sps;
+        const double edge = 4 * _alpha * t / sps;
+        const double q = edge * edge - 1;
+        if (fabs(q) >= 0.000001) {
+            const double tail = (i != centre) ? sin((1 - _alpha) * arg) / (4 * _alpha * t / sps) : (1 - _alpha) * FL_M_PI / (4 * _alpha);
+            const double num = cos((1 + _alpha) * arg) + tail;
+            return 4 * _alpha * num / (q * FL_M_PI);
+        }
+        if (_alpha == 1) { return -1; }
+        const double lo = (1 - _alpha) * arg, hi = (1 + _alpha) * arg;
+        const double num = (sin(hi) * (1 + _alpha) * FL_M_PI - cos(lo) * ((1 - _alpha) * FL_M_PI * sps) / (4 * _alpha * t) +
+                            sin(lo) * sps * sps / (4 * _alpha * t * t));
+        return 4 * _alpha * num / (-32 * FL_M_PI * _alpha * _alpha * t / sps);
+    }
+
     int _tapCount = 0;
     float _sampleRate = 1.0f, _baudRate = 1.0f, _alpha = 0.35f;
 };

@@ -1,47 +1,49 @@
-// wavreader.h -- WavReader (API and behaviour of the reference's src/wavreader.h:14-84):
-// validates "RIFF"/"WAVE", exposes the header fields, and readSamples() WRAPS AROUND to the
-// start of the data at end of file (wavreader.h:41-50) so a short capture loops forever.
+// wavreader.h -- WavReader (public surface and behaviour of the reference's src/wavreader.h:14-84):
+// checks the "RIFF"/"WAVE" tags, exposes bit depth / channel count / sample rate, and
+// readSamples() WRAPS AROUND to the first frame when the file runs out (wavreader.h:41-50), so a
+// short capture loops forever.  The header is parsed byte-wise by wav_detail::Header (wav.h).
 #pragma once
 #include "wav.h"
 
 class WavReader {
 public:
-    WavReader(std::string path) {
-        file = std::ifstream(path.c_str(), std::ios::binary);
-        std::memset(&hdr, 0, sizeof(hdr));
-        file.read(reinterpret_cast<char*>(&hdr), sizeof(WavHeader_t));
-        valid = file.gcount() == (std::streamsize)sizeof(WavHeader_t) && std::memcmp(hdr.signature, "RIFF", 4) == 0 &&
-                std::memcmp(hdr.fileType, "WAVE", 4) == 0;
+    WavReader(std::string path) : src(path.c_str(), std::ios::binary) {
+        unsigned char raw[wav_detail::kHeaderBytes] = {};
+        src.read(reinterpret_cast<char*>(raw), (std::streamsize)sizeof(raw));
+        if (src.gcount() == (std::streamsize)sizeof(raw)) { hdr.get(raw); }
     }
 
-    uint16_t getBitDepth() { return hdr.bitDepth; }
-    uint16_t getChannelCount() { return hdr.channelCount; }
+    bool isValid() { return hdr.tagsOk; }
     uint32_t getSampleRate() { return hdr.sampleRate; }
-    bool isValid() { return valid; }
+    uint16_t getChannelCount() { return hdr.channelCount; }
+    uint16_t getBitDepth() { return hdr.bitDepth; }
 
+    // fills `data` completely; at end of file continues from the first frame
     void readSamples(void* data, size_t size) {
         char* dst = static_cast<char*>(data);
-        file.read(dst, (std::streamsize)size);
-        const size_t got = (size_t)file.gcount();
-        if (got < size) {
-            file.clear();
-            file.seekg(sizeof(WavHeader_t));
-            file.read(dst + got, (std::streamsize)(size - got));
+        size_t have = pull(dst, size);
+        if (have < size) {
+            rewind();
+            have += pull(dst + have, size - have);
         }
-        bytesRead += size;
+        consumed += size;
     }
 
     void rewind() {
-        file.clear();
-        file.seekg(sizeof(WavHeader_t));
+        src.clear();
+        src.seekg((std::streamoff)wav_detail::kHeaderBytes);
     }
 
-    void close() { file.close(); }
+    void close() { src.close(); }
 
-    WavHeader_t hdr;
+    wav_detail::Header hdr;      // parsed fields (dataSize = payload bytes the header announces)
 
 private:
-    bool valid = false;
-    std::ifstream file;
-    size_t bytesRead = 0;
+    size_t pull(char* dst, size_t want) {
+        src.read(dst, (std::streamsize)want);
+        return (size_t)src.gcount();
+    }
+
+    std::ifstream src;
+    size_t consumed = 0;
 };
