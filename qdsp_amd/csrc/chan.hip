@@ -63,8 +63,9 @@ template <int CTRL> __device__ __forceinline__ v2f dpp_quad(v2f v) {
 // phase exp(+-j 2pi c j/64) at j = M n' - P + k leaves a root of unity exp(+-j 2pi c M n'/64) per
 // output time that the DFT does not cover: its tile part rides in A_c, its in-tile part depends on
 // (c0, n') only and is applied with the wave twiddle.
+// (M = 8: its 40-value window takes 80 VGPRs; 2 waves/SIMD without spills measured 10 % faster than 3 with a few)
 template <bool INV, int M>
-__global__ __launch_bounds__(256, 3) void chan_uniform_kernel(const ChanArgs a) {
+__global__ __launch_bounds__(256, (M == 8) ? 2 : 3) void chan_uniform_kernel(const ChanArgs a) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int t = threadIdx.x;
     const int P = a.P, Q = a.Q;
