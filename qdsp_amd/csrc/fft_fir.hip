@@ -22,6 +22,9 @@
 //   * the next segment's loads issued during passes B .. A' of fir_fft_kernel<1> (as the grouped decimator
 //     kernel does), at 3 waves/SIMD to make room for the 32 registers: 0.464 vs 0.440 ms on the same box --
 //     the fourth wave per SIMD hides more than the prefetch does;
+//   * decimate-by-2 through the grouped kernel (pairs of segments, 8-point pruned pass C'): 0.41 ms per 2^26 samples
+//     against 0.27 ms for fir_fft_kernel<2>'s per-segment pruned inverse -- with half of the inverse still to do per
+//     segment, the grouped kernel's 2 workgroups per CU (70 KB of LDS) cost more than the shared inverse saves;
 //   * 16-byte loads by lane pairs (as fir_fft_kernel does) in the grouped decimator kernel, with
 //     segments moved to even starts: 248 VGPRs, decim-8 0.36 ms vs 0.33 ms with 8-byte loads;
 //   * non-temporal loads/stores for the sample stream: +-1 %;
