@@ -25,6 +25,9 @@
 //   * decimate-by-2 through the grouped kernel (pairs of segments, 8-point pruned pass C'): 0.41 ms per 2^26 samples
 //     against 0.27 ms for fir_fft_kernel<2>'s per-segment pruned inverse -- with half of the inverse still to do per
 //     segment, the grouped kernel's 2 workgroups per CU (70 KB of LDS) cost more than the shared inverse saves;
+//   * groups of DEC/2 segments in the grouped kernel (inverse on 128 lanes, 54 KB of LDS, 3 workgroups per CU, no
+//     prefetch of the next segment): the 168-VGPR budget spills 170-220 B per lane; decim-8 0.44 ms vs 0.30 ms and the
+//     translating decimator 0.46 vs 0.32 ms per 2^27 samples;
 //   * 16-byte loads by lane pairs (as fir_fft_kernel does) in the grouped decimator kernel, with
 //     segments moved to even starts: 248 VGPRs, decim-8 0.36 ms vs 0.33 ms with 8-byte loads;
 //   * non-temporal loads/stores for the sample stream: +-1 %;
