@@ -56,6 +56,15 @@ template <int CTRL> __device__ __forceinline__ v2f dpp_quad(v2f v) {
 #endif
 }
 
+// Both lanes of a packed pair fetched from the lane whose byte index is `src` (two ds_bpermute_b32 through a 64-bit
+// integer: taken from .x and .y of the vector directly, hipcc permutes .x only and copies it into both halves).
+__device__ __forceinline__ v2f bperm_pair(int src, v2f v) {
+    const unsigned long long bits = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)bits);
+    const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)(bits >> 32));
+    return __builtin_bit_cast(v2f, ((unsigned long long)hi << 32) | lo);
+}
+
 // INV: channel c sits at +c/64 turn per sample relative to channel 0, else -c/64.
 // M: decimation, 64 (critically sampled) or 8 / 16 / 32 (oversampled by 64/M): the tap window then
 // advances M < 64 samples per output, so (a) the 4 rows an output needs are loaded per output (they
@@ -153,6 +162,25 @@ __global__ __launch_bounds__(256, (M == 8) ? 2 : 3) void chan_uniform_kernel(con
         const v2f v = *(ok ? src : in_or_hist);
         return ok ? v : mk2(0.0f, 0.0f);
     };
+    // Oversampled plans: the tile's windows overlap (40 rows of 64 at M = 8 cover only 376 distinct samples), and
+    // loading every row from memory made the L1 tag pipeline the bottleneck (PMC: 16 cache accesses per 512-byte
+    // load, TCP busy for the whole kernel).  The distinct span is loaded once (kStRows coalesced rows, one tile
+    // ahead so the latency hides behind the previous tile's DFT), parked in the T region and the sliding windows
+    // are read from LDS.
+    constexpr bool kStaged = M != 64;
+    constexpr int kStRows = (kSpan + 63) / 64;
+    v2f pre[kStaged ? kStRows : 1];
+    auto load_rows = [&](int wt) {
+        const long long jb = (long long)wt * kChT * M - P + l;
+        if (jb - l >= 0 && jb - l + 64 * kStRows <= a.count) {
+#pragma unroll
+            for (int k = 0; k < kStRows; k++) pre[k] = in[jb + 64 * k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < kStRows; k++) pre[k] = sample(jb, 64 * k);
+        }
+    };
+    if (kStaged && gw < a.ntiles) load_rows(gw);
     for (int wt = gw; wt < a.ntiles; wt += nwaves) {
         const long long n0 = (long long)wt * kChT;            // first output time of the tile
         const long long jb = n0 * M - P + l;                   // stream position of this lane's column in row 0
@@ -170,7 +198,19 @@ __global__ __launch_bounds__(256, (M == 8) ? 2 : 3) void chan_uniform_kernel(con
             constexpr int RQ = 64 / M;
             constexpr int NX = kChT + 3 * RQ;
             v2f x[NX];
-            if (interior) {
+            if constexpr (kStaged) {
+#pragma unroll
+                for (int k = 0; k < kStRows; k++) T[64 * k + l] = pre[k];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int r = 0; r < NX; r++) x[r] = T[l + M * r];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (wt + nwaves < a.ntiles) load_rows(wt + nwaves);
+            } else if (interior) {
 #pragma unroll
                 for (int r = 0; r < NX; r++) x[r] = in[jb + M * r];
             } else {
@@ -198,8 +238,14 @@ __global__ __launch_bounds__(256, (M == 8) ? 2 : 3) void chan_uniform_kernel(con
         const long long j = nn * M - P + a.kcentre;                  // window-centre position of this output
         const float jm = (float)(int)(j & 511);
         const float fl = (float)nq;
-        v2f* __restrict__ o = reinterpret_cast<v2f*>(a.out) + nn;
-        const bool live = nn < a.nout;
+        // Stores: in the DFT layout the four lanes of a quad hold four different channels (rows 16 apart in memory),
+        // so one store instruction touched 64 separate 32-byte pieces and the L1 tag pipeline, not HBM, set the pace
+        // (PMC: TCP busy for the whole kernel, 64 cache accesses per store).  One ds_bpermute pair transposes the wave
+        // to lane = 16 b + n': 16 neighbouring lanes then write one whole 128-byte line of channel c0 + 16 c1(b).
+        const int tsrc = (((l & 15) << 2) | (l >> 4)) << 2;          // byte index of the source lane 4 n' + b
+        const int c1s = (((l >> 4) & 1) << 1) | (l >> 5);              // c1 of the source lane's sub = b
+        v2f* __restrict__ o = reinterpret_cast<v2f*>(a.out) + n0 + (l & 15) + (size_t)(16 * c1s) * a.out_stride;
+        const bool live = n0 + (l & 15) < a.nout;
         // (two copies of the loop: in the full-tile one nothing depends on `live`, so the compiler keeps
         // it one basic block and overlaps the table reads / DPP hazards of neighbouring groups)
         auto finish = [&](auto guarded) {
@@ -219,7 +265,6 @@ __global__ __launch_bounds__(256, (M == 8) ? 2 : 3) void chan_uniform_kernel(con
                 ta = pk_cmul(ta, Mq, Mqj);
                 const v2f y = pk_fma(ta, sB, dpp_quad<0xB1>(ta));
                 // A_c(tile), B_c(n') and VOLK's magnitude sawtooth
-                const int c = c0 + 16 * c1;
                 const float4 A = tab[4 * c0 + c1];
                 const float2 tg = cst[4 * c0 + c1];
                 const v2f v = pk_cmul(y, mk2(A.x, A.y), mk2(A.z, A.w));
@@ -227,7 +272,8 @@ __global__ __launch_bounds__(256, (M == 8) ? 2 : 3) void chan_uniform_kernel(con
                 const float gain = fmaf(jm, tg.y, 1.0f);
                 const float brg = fmaf(ang * ang, -0.5f, 1.0f) * gain;
                 const v2f r = pk_fma(v.yx, mk2(-ang * gain, ang * gain), v * mk2(brg, brg));
-                if (!decltype(guarded)::value || live) o[(size_t)c * a.out_stride] = r;
+                const v2f rt = bperm_pair(tsrc, r);
+                if (!decltype(guarded)::value || live) o[(size_t)c0 * a.out_stride] = rt;
             }
         };
         if (n0 + kChT <= a.nout) finish(std::false_type{});
