@@ -23,9 +23,10 @@
 //            VGPRs) -> wave-private LDS tile T[n'][mu]
 //   lane (n' = l>>2, sub = l&3): U[sub + 4i] from T -> radix-16 DFT over i in registers
 //            -> * exp(+-j 2pi c0 sub / 64) -> radix-4 across the quad with DPP (no LDS)
-//            -> channels c0 + 16 c1 at time n': rot_c(n') and stores; each store instruction writes 4
-//            runs of 16 consecutive n' (128-byte lines).  (The first version scattered 64 8-byte pieces
-//            per store and was bound by L2 write requests: 134 M per GiB of output.)
+//            -> channels c0 + 16 c1 at time n': rot_c(n'), wave transpose (ds_bpermute) and stores; each
+//            store instruction writes 4 runs of 16 consecutive n' (128-byte lines), each run by 16
+//            neighbouring lanes.  (The first version scattered 64 8-byte pieces per store and was bound
+//            by L2 write requests: 134 M per GiB of output.)
 // rot_c(n') = A_c(tile) * W(n' - n0) * B_c(n' - n0): A_c is FP64 state of lane c advanced by one
 // complex multiply per tile, W = exp(j 64 m dphi_0) a per-lane constant, B_c = exp(j 64 m delta_c) a
 // 2-term FP32 series (<= 2.4e-3 rad over 16 outputs).  History is raw input.
