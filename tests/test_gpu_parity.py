@@ -546,6 +546,38 @@ def test_channelizer_64_channels(ops, gold, dec):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("dec", [8, 32, 64])
+def test_channelizer_small_and_ragged_blocks(ops, gold, dec):
+    """Blocks shorter than one wave tile (16 output times x dec samples + 256 of window), an empty block, and
+    block lengths that end inside a tile: every call takes the boundary (history / zero-fill) path of the polyphase
+    kernel and hands its history on.  Checked against the per-channel kernels fed the same calls."""
+    taps = gold["taps256"]
+    nch = 64
+    incs = [ops.phase_delta(1.0, -(c - 31.5) / nch) for c in range(nch)]
+    sizes = [dec, 3 * dec, 0, 16 * dec + dec, 7 * dec, 64 * dec, 129 * dec, dec, 1000 * dec]
+    x = O.synth_iq(0, sum(sizes), seed=900 + dec)
+    fast = ops.Channelizer(taps, 1, dec, incs, max_block=max(sizes))
+    slow = ops.Channelizer(taps, 1, dec, incs, max_block=max(sizes))
+    slow.set_mode(slow.DIRECT)
+    pos = 0
+    outs_f, outs_s = [], []
+    for m in sizes:
+        blk = x[pos : pos + m]
+        pos += m
+        yf = np.array(fast.process(blk))
+        ys = np.array(slow.process(blk))
+        assert yf.shape == ys.shape == (nch, m // dec)
+        if m:
+            assert fast.last_kernel()["name"] == "chan_uniform_kernel"
+            assert slow.last_kernel()["name"] != "chan_uniform_kernel"
+        outs_f.append(yf)
+        outs_s.append(ys)
+    yf = np.concatenate(outs_f, axis=1)
+    ys = np.concatenate(outs_s, axis=1)
+    for c in range(nch):
+        assert rel_rms(yf[c], ys[c]) < 8e-6, c
+
+
 def test_channelizer_non_uniform_plan_falls_back(ops, gold):
     """Arbitrary offsets (or another decimation) are served by one fused kernel per channel."""
     taps = gold["taps256"]
