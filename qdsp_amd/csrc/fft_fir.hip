@@ -286,7 +286,8 @@ __global__ __launch_bounds__(kFftNT, (DEC == 1 && !ROT && !REAL) ? 4 : 3) void f
                 const unsigned x = (unsigned)(r0 + i);
                 const unsigned q = a.decm_inv ? (unsigned)(((unsigned long long)x * a.decm_inv) >> 32) : x / (unsigned)a.decm;
                 n = q0 + q;
-                return x - q * (unsigned)a.decm == 0;
+                // (n >= 0: at decm == 1 the first segment's element at stream position -2 would be "output -1")
+                return x - q * (unsigned)a.decm == 0 && n >= 0;
             };
             if constexpr (REAL) {
                 float* __restrict__ outr = reinterpret_cast<float*>(a.out);

@@ -852,6 +852,54 @@ def test_vfo_retune_mid_stream(ops, gold, M, ntaps):
     assert got.shape == want.shape and rel_rms(got, want) < 3e-6
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_random_plans_every_dispatch_path(ops, seed):
+    """Seeded sweep over (interp, decim, tap count, data type, NCO, block sizes, kernel mode): whichever kernel the
+    dispatcher picks (strided window, de-interleaved core, small-interp, general, overlap-save full / pruned /
+    grouped / strided store, real pairs), a three-block stream must match the FP64-accumulating oracle fed the same
+    blocks (the reference restarts its polyphase counter per block, H4).  Plans near the dispatch thresholds are the
+    point: tap counts around 8 / 24 / 96 / 112 / 128 / 256, decimations around 7 / 8 / 16 / 17."""
+    rng = np.random.default_rng(7000 + seed)
+    Ls = [1, 1, 1, 1, 2, 3, 4, 5, 7, 10, 12]
+    Ms = [1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 16, 17, 25, 50, 147]
+    Ns = [1, 2, 7, 8, 9, 23, 24, 25, 31, 63, 64, 95, 96, 97, 111, 112, 113, 127, 128, 129, 200, 255, 256]
+    seen = set()
+    for case in range(10):
+        L, M = int(rng.choice(Ls)), int(rng.choice(Ms))
+        g = int(np.gcd(L, M))
+        L, M = L // g, M // g
+        ntaps = int(rng.choice(Ns))
+        kind = ("cplx", "real", "vfo")[int(rng.integers(0, 3))]
+        mode = int(rng.choice([0, 0, 2]))
+        taps = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+        sizes = [int(rng.integers(1, 40_000)), int(rng.integers(0, 3000)), int(rng.integers(20_000, 90_000))]
+        x = O.synth_iq(0, sum(sizes), seed=seed * 100 + case)
+        cuts = np.cumsum([0] + sizes)
+        blocks = [x[a:b] for a, b in zip(cuts, cuts[1:])]
+        if kind == "real":
+            blocks = [np.ascontiguousarray(b.real) for b in blocks]
+            op = ops.Resampler(taps, L, M, complex_data=False)
+            orc = O.Resampler(taps, L, M, complex_data=False, acc=O.ACC_F64)
+            want = np.concatenate([orc.process(b) for b in blocks])
+        elif kind == "cplx":
+            op = ops.Resampler(taps, L, M)
+            orc = O.Resampler(taps, L, M, acc=O.ACC_F64)
+            want = np.concatenate([orc.process(b) for b in blocks])
+        else:
+            f = float(rng.uniform(-0.45, 0.45))
+            op = ops.Vfo(taps, L, M, ops.phase_delta(1.0, f))
+            xl, orc = O.Xlator(1.0, f, exact=True, volk_gain=True), O.Resampler(taps, L, M, acc=O.ACC_F64)
+            want = np.concatenate([orc.process(xl.process(b)) for b in blocks])
+        op.set_mode(mode)
+        print("plan", seed, case, L, M, ntaps, kind, mode, sizes, flush=True)
+        got = np.concatenate([np.array(op.process(b)) for b in blocks])
+        seen.add(op.last_kernel()["name"])
+        assert got.shape == want.shape, (L, M, ntaps, kind, mode, sizes)
+        if len(want):
+            assert rel_rms(got, want) < 4e-6, (L, M, ntaps, kind, mode, sizes, op.last_kernel()["name"])
+    assert len(seen) >= 2, seen
+
+
 def test_bench_size_cross_checks(ops, gold):
     """The bench's size (2^27 samples per call = 1 GiB in: byte offsets past 2^31): independent kernels must agree.
     Overlap-save FIR vs direct form; fused overlap-save VFO vs NCO kernel -> decimator; polyphase channelizer vs
