@@ -578,6 +578,39 @@ def test_channelizer_small_and_ragged_blocks(ops, gold, dec):
         assert rel_rms(yf[c], ys[c]) < 8e-6, c
 
 
+@pytest.mark.parametrize("dec", [8, 16, 32, 64])
+def test_channelizer_guard_bands_and_odd_strides(ops, gold, dec):
+    """Channel rows wider than the output (odd strides: the wave-transposed 128-byte store runs are then not line
+    aligned), input pointer at an odd sample offset, output counts that end inside a wave tile: nothing but
+    [0, out_size) of each row may be written, values equal the contiguous-layout result bit for bit."""
+    import torch
+
+    taps = gold["taps256"]
+    nch = 64
+    incs = [ops.phase_delta(1.0, -(c - 31.5) / nch) for c in range(nch)]
+    rng = np.random.default_rng(dec)
+    sentinel = -777.0
+    for trial in range(4):
+        n = dec * int(rng.integers(1, 3000))
+        x = O.synth_iq(0, n, seed=40 + trial)
+        off = int(rng.integers(0, 4))
+        xin = torch.empty(n + off, dtype=torch.complex64, device="cuda")
+        xin[off:] = dev(x)
+        a = ops.Channelizer(taps, 1, dec, incs, max_block=0)
+        want = a.process(dev(x)).cpu().numpy()
+        no = n // dec
+        stride = no + int(rng.integers(1, 40))
+        big = torch.full((nch, stride), sentinel, dtype=torch.complex64, device="cuda")
+        b = ops.Channelizer(taps, 1, dec, incs, max_block=0)
+        got = b.process(xin[off:], out=big)
+        torch.cuda.synchronize()
+        assert b.last_kernel()["name"] == "chan_uniform_kernel"
+        host = big.cpu().numpy()
+        assert got.shape == (nch, no)
+        assert (host[:, no:] == sentinel).all(), (dec, n, stride, off)
+        assert np.array_equal(host[:, :no], want), (dec, n, stride, off)
+
+
 def test_channelizer_non_uniform_plan_falls_back(ops, gold):
     """Arbitrary offsets (or another decimation) are served by one fused kernel per channel."""
     taps = gold["taps256"]
@@ -898,6 +931,66 @@ def test_random_plans_every_dispatch_path(ops, seed):
         if len(want):
             assert rel_rms(got, want) < 4e-6, (L, M, ntaps, kind, mode, sizes, op.last_kernel()["name"])
     assert len(seen) >= 2, seen
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_device_pointers_and_guard_bands(ops, seed):
+    """Device path with input and output pointers at random sample offsets (8-byte / 4-byte aligned only: the
+    16-byte load/store variants must step aside) and the output inside a buffer of sentinels: nothing outside
+    [0, out_size) may be written (an out-of-bounds store at index -1 was found this way), and the values must match
+    the oracle.  Covers FIR, resampler, fused VFO and the plain NCO mixer, complex and real, all kernel modes."""
+    import torch
+
+    rng = np.random.default_rng(9100 + seed)
+    Ns = [1, 2, 7, 8, 24, 63, 64, 96, 112, 128, 129, 255, 256]
+    for case in range(8):
+        kind = ("fir", "fir_real", "rs", "rs_real", "vfo", "xlate")[int(rng.integers(0, 6))]
+        L = int(rng.choice([1, 1, 1, 2, 3, 5]))
+        M = int(rng.choice([1, 2, 3, 4, 5, 8, 10, 16, 17, 50]))
+        g = int(np.gcd(L, M))
+        L, M = L // g, M // g
+        ntaps = int(rng.choice(Ns))
+        mode = int(rng.choice([0, 1, 2]))
+        taps = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+        sizes = [int(rng.integers(1, 5000)), int(rng.integers(70_000, 200_000)), int(rng.integers(1, 70_000))]
+        x = O.synth_iq(0, sum(sizes), seed=seed * 1000 + case)
+        real = kind.endswith("_real")
+        xs = np.ascontiguousarray(x.real) if real else x
+        f = float(rng.uniform(-0.45, 0.45))
+        if kind.startswith("fir"):
+            op, orc = ops.Fir(taps, complex_data=not real), O.Fir(taps, complex_data=not real, acc=O.ACC_F64)
+            ref = lambda b: orc.process(b)
+        elif kind.startswith("rs"):
+            op, orc = ops.Resampler(taps, L, M, complex_data=not real), O.Resampler(taps, L, M, complex_data=not real, acc=O.ACC_F64)
+            ref = lambda b: orc.process(b)
+        elif kind == "vfo":
+            op = ops.Vfo(taps, L, M, ops.phase_delta(1.0, f))
+            xl, orc = O.Xlator(1.0, f, exact=True, volk_gain=True), O.Resampler(taps, L, M, acc=O.ACC_F64)
+            ref = lambda b: orc.process(xl.process(b))
+        else:
+            op = ops.Xlator(1.0, f)
+            xl = O.Xlator(1.0, f, exact=True, volk_gain=True)
+            ref = lambda b: xl.process(b)
+        if kind != "xlate":
+            op.set_mode(mode)
+        pos = 0
+        for m in sizes:
+            blk = xs[pos : pos + m]
+            pos += m
+            want = ref(blk)
+            oi, oo, pad = int(rng.integers(0, 4)), int(rng.integers(0, 4)), 64
+            xin = torch.empty(m + oi, dtype=torch.from_numpy(xs[:1]).dtype, device="cuda")
+            xin[oi:] = dev(blk)
+            sentinel = -12345.0
+            big = torch.full((pad + oo + len(want) + pad,), sentinel, dtype=xin.dtype, device="cuda")
+            y = op.process(xin[oi:], out=big[pad + oo : pad + oo + max(len(want), 1)])
+            torch.cuda.synchronize()
+            assert y.numel() == len(want), (kind, L, M, ntaps, mode, m)
+            host = big.cpu().numpy()
+            lo, hi = host[: pad + oo], host[pad + oo + len(want) :]
+            assert (lo == sentinel).all() and (hi == sentinel).all(), (kind, L, M, ntaps, mode, m, oi, oo, op.last_kernel()["name"])
+            if len(want):
+                assert rel_rms(host[pad + oo : pad + oo + len(want)], want) < 4e-6, (kind, L, M, ntaps, mode, m, oi, oo, op.last_kernel()["name"])
 
 
 def test_bench_size_cross_checks(ops, gold):
