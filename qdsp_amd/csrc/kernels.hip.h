@@ -362,6 +362,7 @@ struct AnyArgs {
     int nblocks;           // tiles
     int nwg;               // persistent workgroups (grid = nwg + 1: the last hands over history)
     int step_d, step_p;    // (NT*M) / L and (NT*M) % L
+    unsigned pad_inv;      // PAD: ceil(2^32 / M), u / M == (u * pad_inv) >> 32 for every staged index u
     int Pp;                // LT: row pitch of the phase table in LDS (floats; Pp/4 odd)
     int tap_bytes;         // LT: bytes of LDS the table takes (multiple of 16)
     unsigned long long phase0, dphase;
@@ -381,7 +382,11 @@ struct AnyArgs {
 // number of 16-byte units: every lane reads ITS phase's row, and the rows of neighbouring outputs are
 // M % L apart), read four taps at a time -- fetching one tap per MAC per lane from memory kept this
 // kernel at 0.49 ms per 2^26 samples for 147/160 (44.1 <-> 48 kHz).
-template <int CH, int NT, bool ROT, bool LT>
+// PAD (interp 1, decimation a multiple of 4): neighbouring lanes' windows start M samples apart, which puts them
+// on the same few LDS banks (M = 32: all 64 lanes on one, 0.48 ms per 2^26 samples against 0.13 at M = 25).  The
+// tile is then staged with one pad element per M samples (index u -> u + u / M): the lane pitch M + 1 is odd,
+// and window element k sits at k + k / M from the lane's start (a wave-uniform offset: rows of M).
+template <int CH, int NT, bool ROT, bool LT, bool PAD>
 __global__ __launch_bounds__(NT) void resamp_any_kernel(const AnyArgs a) {
     using T = typename Smp<CH>::T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -423,7 +428,9 @@ __global__ __launch_bounds__(NT) void resamp_any_kernel(const AnyArgs a) {
         const long long hi = ((n1 - 1) * a.M) / a.L;         // one past the last needed sample
         const int span = (int)(hi - lo);
         __syncthreads();                                     // the previous tile's reads are done (and `tl` is written)
-        stage_tile<CH, NT, ROT>(in, hist, P, a.count, lo, span, a, [&](int u, T v) { lds[u] = v; });
+        stage_tile<CH, NT, ROT>(in, hist, P, a.count, lo, span, a, [&](int u, T v) {
+            lds[PAD ? u + (int)(((unsigned long long)(unsigned)u * a.pad_inv) >> 32) : u] = v;
+        });
         __syncthreads();
         // (n*M) / L and % L: one 64-bit division for the lane's first output of the tile, then n += NT moves
         // them by (NT*M) / L and % L with a carry
@@ -435,13 +442,33 @@ __global__ __launch_bounds__(NT) void resamp_any_kernel(const AnyArgs a) {
             phase = (int)(i - d * a.L);
         }
         for (long long n = n0 + t; n < n1; n += NT) {
-            const T* w = lds + (int)(d - P - lo);
+            const T* w = lds + (int)(d - P - lo) + (PAD ? (int)(n - n0) : 0);   // PAD: the start is (n - n0) * M, exactly
             const int phase_n = phase;
             d += a.step_d;
             phase += a.step_p;
             if (phase >= a.L) { phase -= a.L; d += 1; }
             T acc = Smp<CH>::zero();
-            if (LT) {
+            if (PAD) {
+                // interp 1: one phase.  Rows of M window elements (M a multiple of 4, so the 16-byte tap reads stay
+                // aligned) lie M + 1 apart; inside a row the loop is the unpadded one.
+                const float* hp = LT ? tl : a.phases;
+                const T* wr = w;
+                for (int k0 = 0; k0 < P; k0 += a.M, wr += a.M + 1) {
+                    const int len = (P - k0 < a.M) ? P - k0 : a.M;
+                    const float* hr = hp + k0;
+                    int k = 0;
+                    for (; k + 4 <= len; k += 4) {
+                        float4 h4;
+                        if (LT) h4 = *reinterpret_cast<const float4*>(hr + k);
+                        else h4 = make_float4(hr[k], hr[k + 1], hr[k + 2], hr[k + 3]);
+                        mac(acc, h4.x, wr[k]);
+                        mac(acc, h4.y, wr[k + 1]);
+                        mac(acc, h4.z, wr[k + 2]);
+                        mac(acc, h4.w, wr[k + 3]);
+                    }
+                    for (; k < len; k++) mac(acc, hr[k], wr[k]);
+                }
+            } else if (LT) {
                 const float* hp = tl + phase_n * a.Pp;
                 int k = 0;
                 for (; k + 4 <= P; k += 4) {

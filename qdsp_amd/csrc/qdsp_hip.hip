@@ -123,7 +123,10 @@ int64_t out_size(const Engine* e, int64_t count) {
     return (count * e->L) / e->M;  // calcOutSize, resampling.h:95-97 (L = M = 1 for FIR)
 }
 
-bool use_core(const Engine* e) { return e->L == 1 && e->M <= 16 && !env_int("QDSP_HIP_FORCE_ANY", 0); }
+// fir_core_kernel (de-interleaved tile): FIR and decimations up to 8.  From 9 on the general kernel with its
+// staged-as-it-lies tile is 2-3x faster (scripts/tune_large_decim.py: M = 9..16, 31-255 taps: 0.12-0.38 ms per
+// 2^26 samples against 0.26-0.54).
+bool use_core(const Engine* e) { return e->L == 1 && e->M <= env_int("QDSP_HIP_CORE_MAX_DECIM", 8) && !env_int("QDSP_HIP_FORCE_ANY", 0); }
 
 // decimators served by decim_win_kernel (kernels.hip.h): interp 1, short filters.  Outputs per lane and the
 // tap limit from scripts/tune_win.py / tune_small.py (2^26 samples): chunks of M*R <= 10 samples are the sweet
@@ -535,21 +538,43 @@ template <int CH, bool ROT> int launch_lm(Engine* e, const void* d_in, int64_t c
     }
 }
 
+// Tile plan of resamp_any_kernel: phase-table pitch and bytes in LDS (0: table stays in memory), padded layout,
+// outputs per tile (0: the taps of one phase do not fit) and the LDS elements a tile stages.
+struct AnyPlan { int Pp, tap_bytes; bool pad; long long tile, span; };
+AnyPlan any_plan(int L, int M, int P, int ch) {
+    constexpr int NT = 256;
+    AnyPlan p;
+    // the phase table rides in LDS when it leaves at least half of the budget to the samples
+    p.Pp = (P + 3) & ~3;
+    if (((p.Pp >> 2) & 1) == 0) p.Pp += 4;
+    const long long tap_bytes = (long long)L * p.Pp * (long long)sizeof(float);
+    const bool lt = tap_bytes <= kMaxDynLds / 2 && env_int("QDSP_HIP_ANY_NO_LDS_TAPS", 0) == 0;
+    p.tap_bytes = lt ? (int)tap_bytes : 0;
+    // Tile = as many outputs as keep the staged input span inside what is left of the LDS budget.
+    const long long max_elems = (kMaxDynLds - p.tap_bytes) / (ch * (int)sizeof(float));
+    long long tile = (long long)env_int("QDSP_HIP_ANY_TILE", 8) * NT;
+    // interp 1 with a decimation that is a multiple of 4: lane windows M samples apart share LDS banks (4-way and
+    // worse) -> one pad element per M samples
+    p.pad = L == 1 && (M & 3) == 0 && M <= 65536 && env_int("QDSP_HIP_ANY_NO_PAD", 0) == 0;
+    auto span_of = [&](long long t) {
+        const long long sp = ((t - 1) * M) / L + P + 2;
+        return p.pad ? sp + sp / M + 1 : sp;
+    };
+    while (tile > 1 && span_of(tile) > max_elems) tile /= 2;
+    p.tile = span_of(tile) > max_elems ? 0 : tile;
+    p.span = span_of(tile);
+    return p;
+}
+
 template <int CH, bool ROT> int launch_any(Engine* e, qk::AnyArgs& a, hipStream_t s) {
     constexpr int NT = 256;
-    // the phase table rides in LDS when it leaves at least half of the budget to the samples
-    int Pp = (a.P + 3) & ~3;
-    if (((Pp >> 2) & 1) == 0) Pp += 4;
-    const long long tap_bytes = (long long)a.L * Pp * (long long)sizeof(float);
-    const bool lt = tap_bytes <= kMaxDynLds / 2 && env_int("QDSP_HIP_ANY_NO_LDS_TAPS", 0) == 0;
-    a.Pp = Pp;
-    a.tap_bytes = lt ? (int)tap_bytes : 0;
-    // Tile = as many outputs as keep the staged input span inside what is left of the LDS budget.
-    const long long max_elems = (kMaxDynLds - a.tap_bytes) / (CH * (int)sizeof(float));
-    long long tile = (long long)env_int("QDSP_HIP_ANY_TILE", 8) * NT;
-    auto span_of = [&](long long t) { return ((t - 1) * a.M) / a.L + a.P + 2; };
-    while (tile > 1 && span_of(tile) > max_elems) tile /= 2;
-    if (span_of(tile) > max_elems) return QDSP_HIP_EINVAL;  // taps per phase beyond LDS
+    const AnyPlan pl = any_plan(a.L, a.M, a.P, CH);
+    if (pl.tile == 0) return QDSP_HIP_EINVAL;  // taps per phase beyond LDS
+    const bool lt = pl.tap_bytes != 0, pad = pl.pad;
+    const long long tile = pl.tile;
+    a.Pp = pl.Pp;
+    a.tap_bytes = pl.tap_bytes;
+    a.pad_inv = pad ? (unsigned)((1ULL << 32) / (unsigned)a.M) + 1u : 0u;
     a.tile = (int)tile;
     a.nblocks = (int)((a.nout + tile - 1) / tile);
     a.step_d = (int)(((long long)NT * a.M) / a.L);
@@ -558,10 +583,15 @@ template <int CH, bool ROT> int launch_any(Engine* e, qk::AnyArgs& a, hipStream_
     if (nwg > a.nblocks) nwg = a.nblocks;
     if (nwg < 1) nwg = 1;
     a.nwg = nwg;
-    const size_t lds = (size_t)a.tap_bytes + (size_t)span_of(tile) * CH * sizeof(float);
+    const size_t lds = (size_t)a.tap_bytes + (size_t)pl.span * CH * sizeof(float);
     fill_stage_rot(a, NT);
-    if (lt) hipLaunchKernelGGL((qk::resamp_any_kernel<CH, NT, ROT, true>), dim3(nwg + 1), dim3(NT), lds, s, a);
-    else hipLaunchKernelGGL((qk::resamp_any_kernel<CH, NT, ROT, false>), dim3(nwg + 1), dim3(NT), lds, s, a);
+    if (pad) {
+        if (lt) hipLaunchKernelGGL((qk::resamp_any_kernel<CH, NT, ROT, true, true>), dim3(nwg + 1), dim3(NT), lds, s, a);
+        else hipLaunchKernelGGL((qk::resamp_any_kernel<CH, NT, ROT, false, true>), dim3(nwg + 1), dim3(NT), lds, s, a);
+    } else {
+        if (lt) hipLaunchKernelGGL((qk::resamp_any_kernel<CH, NT, ROT, true, false>), dim3(nwg + 1), dim3(NT), lds, s, a);
+        else hipLaunchKernelGGL((qk::resamp_any_kernel<CH, NT, ROT, false, false>), dim3(nwg + 1), dim3(NT), lds, s, a);
+    }
     HIPCHK(hipGetLastError());
     e->last.name = "resamp_any_kernel";
     e->last.grid = nwg + 1;
@@ -593,6 +623,21 @@ int fft_dec(const Engine* e) {
 
 int mode_of(const Engine* e) { return e->fir_mode ? e->fir_mode : env_int("QDSP_HIP_FIR_MODE", 0); }
 
+// Large decimations (the VFO's usual job: 2.4 Msps -> 48 kHz is M = 50) with the few taps per output such
+// filters have: the general direct kernel streams the input once and does P/M MACs per input sample, while the
+// overlap-save form pays a full 4096-point transform pair whatever M (0.20-0.22 ms per 2^26 samples, 0.25-0.28
+// with the fused NCO).  Measured (scripts/tune_large_decim.py, M = 9..250, 31..1001 taps): the direct form takes
+// 0.12-0.17 ms up to ~9 taps per input-sample-of-decimation and ~320 taps (tiles shrink with M: LDS holds
+// tile * M samples), and the NCO costs it 0.015 ms instead of 0.055; 2-way bank conflicts (M = 2 mod 4) move
+// the crossover down.
+bool any_direct_wins(const Engine* e) {
+    if (e->L != 1 || e->ch != 2 || env_int("QDSP_HIP_NO_ANY_POLICY", 0)) return false;
+    if (any_plan(1, e->M, e->P, e->ch).tile == 0) return false;
+    const int per_m = (e->M & 3) == 2 ? (e->rotate ? 10 : 7) : (e->rotate ? 15 : 9);
+    const int max_taps = e->rotate ? 512 : 320;
+    return e->P <= per_m * e->M && e->P <= max_taps;
+}
+
 bool fft_eligible(const Engine* e, int64_t count) {
     if (!fft_dec(e)) return false;
     int mode = e->fir_mode ? e->fir_mode : env_int("QDSP_HIP_FIR_MODE", 0);
@@ -617,6 +662,7 @@ bool fft_eligible(const Engine* e, int64_t count) {
         // direct form from 8 taps on (2^26 samples: 0.222 vs 0.256 ms at 7 taps, 0.225 vs 0.394 at 127)
         min_taps = env_int("QDSP_HIP_FFT_MIN_TAPS", 8);
     } else {
+        if (e->M >= 9 && !use_win(e) && any_direct_wins(e)) return false;
         // decimators (scripts/tune_small.py, profiles/r01_tune_small.txt): the direct form slows down with the
         // decimation (LDS-capacity-bound de-interleaved tiles): M = 2 / 4 / 5 it wins to ~110 taps
         // (0.20 / 0.16 / 0.18 ms vs 0.24 / 0.18 / 0.22), from M = 7 the overlap-save form wins at any length
