@@ -127,6 +127,9 @@ template <class ARGS> __device__ __forceinline__ double2 tile_phasor(const ARGS&
     return cmul(blk, a.nco_tab[256 + a.nco_na + t]);
 }
 
+__device__ __forceinline__ float smp_add(float a, float b) { return a + b; }
+__device__ __forceinline__ float2 smp_add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+
 template <int CH, int NT, bool ROT, class ARGS, class PUT>
 __device__ __forceinline__ void stage_tile(const typename Smp<CH>::T* __restrict__ in, const typename Smp<CH>::T* __restrict__ hist,
                                            int H, long long count, long long base, int U, const ARGS& a, PUT put, int tile = -1) {
@@ -363,6 +366,10 @@ struct AnyArgs {
     int nwg;               // persistent workgroups (grid = nwg + 1: the last hands over history)
     int step_d, step_p;    // (NT*M) / L and (NT*M) % L
     unsigned pad_inv;      // PAD: ceil(2^32 / M), u / M == (u * pad_inv) >> 32 for every staged index u
+    int ks_lanes;          // 0, or lanes per output S = NT / tile (interp 1, tile < NT): each takes ks_chunk taps
+    int ks_shift;          // log2(tile)
+    int ks_chunk;          // taps per lane, a multiple of 4
+    int ks_red;            // element offset of the NT partial sums behind the staged samples
     int Pp;                // LT: row pitch of the phase table in LDS (floats; Pp/4 odd)
     int tap_bytes;         // LT: bytes of LDS the table takes (multiple of 16)
     unsigned long long phase0, dphase;
@@ -386,6 +393,11 @@ struct AnyArgs {
 // on the same few LDS banks (M = 32: all 64 lanes on one, 0.48 ms per 2^26 samples against 0.13 at M = 25).  The
 // tile is then staged with one pad element per M samples (index u -> u + u / M): the lane pitch M + 1 is odd,
 // and window element k sits at k + k / M from the lane's start (a wave-uniform offset: rows of M).
+// Tap split (interp 1, large decimations): LDS holds tile * M samples, so from M ~ 32 on a tile has fewer outputs
+// than the workgroup has lanes (M = 100: 64) and most lanes idled through the P-tap loop.  S = NT / tile lanes
+// then share an output: lane t works on output t % tile, taps [j, j + 1) * ks_chunk with j = t / tile (whole
+// waves or half-waves per j: the window pattern across lanes is unchanged), partial sums meet in LDS and are
+// added in the order j = 0 .. S-1.
 template <int CH, int NT, bool ROT, bool LT, bool PAD>
 __global__ __launch_bounds__(NT) void resamp_any_kernel(const AnyArgs a) {
     using T = typename Smp<CH>::T;
@@ -440,6 +452,58 @@ __global__ __launch_bounds__(NT) void resamp_any_kernel(const AnyArgs a) {
             const long long i = (n0 + t) * a.M;
             d = i / a.L;
             phase = (int)(i - d * a.L);
+        }
+        if (a.ks_lanes) {
+            const int o = t & (a.tile - 1), j = t >> a.ks_shift;
+            const int kb = j * a.ks_chunk;
+            const int ke = (kb + a.ks_chunk < P) ? kb + a.ks_chunk : P;
+            const float* hp = LT ? tl : a.phases;
+            T acc = Smp<CH>::zero();
+            if (n0 + o < n1 && kb < ke) {
+                const T* w = lds + o * a.M + (PAD ? o : 0);
+                int k = kb;
+                if (PAD) {
+                    // element k sits at k + k / M; kb and M are multiples of 4: a group of four stays inside a row
+                    int row = (int)(((unsigned long long)(unsigned)kb * a.pad_inv) >> 32);
+                    int r = kb - row * a.M;
+                    for (; k + 4 <= ke; k += 4) {
+                        float4 h4;
+                        if (LT) h4 = *reinterpret_cast<const float4*>(hp + k);
+                        else h4 = make_float4(hp[k], hp[k + 1], hp[k + 2], hp[k + 3]);
+                        const T* wk = w + k + row;
+                        mac(acc, h4.x, wk[0]);
+                        mac(acc, h4.y, wk[1]);
+                        mac(acc, h4.z, wk[2]);
+                        mac(acc, h4.w, wk[3]);
+                        r += 4;
+                        if (r == a.M) { r = 0; row++; }
+                    }
+                    for (; k < ke; k++) {
+                        mac(acc, hp[k], w[k + row]);
+                        if (++r == a.M) { r = 0; row++; }
+                    }
+                } else {
+                    for (; k + 4 <= ke; k += 4) {
+                        float4 h4;
+                        if (LT) h4 = *reinterpret_cast<const float4*>(hp + k);
+                        else h4 = make_float4(hp[k], hp[k + 1], hp[k + 2], hp[k + 3]);
+                        mac(acc, h4.x, w[k]);
+                        mac(acc, h4.y, w[k + 1]);
+                        mac(acc, h4.z, w[k + 2]);
+                        mac(acc, h4.w, w[k + 3]);
+                    }
+                    for (; k < ke; k++) mac(acc, hp[k], w[k]);
+                }
+            }
+            T* red = lds + a.ks_red;
+            red[t] = acc;
+            __syncthreads();
+            if (t < a.tile && n0 + t < n1) {
+                T y = red[t];
+                for (int jj = 1; jj < a.ks_lanes; jj++) y = smp_add(y, red[jj * a.tile + t]);
+                out[n0 + t] = y;
+            }
+            continue;   // (the barrier at the top of the tile loop also guards `red`)
         }
         for (long long n = n0 + t; n < n1; n += NT) {
             const T* w = lds + (int)(d - P - lo) + (PAD ? (int)(n - n0) : 0);   // PAD: the start is (n - n0) * M, exactly

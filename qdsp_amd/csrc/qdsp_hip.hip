@@ -540,7 +540,7 @@ template <int CH, bool ROT> int launch_lm(Engine* e, const void* d_in, int64_t c
 
 // Tile plan of resamp_any_kernel: phase-table pitch and bytes in LDS (0: table stays in memory), padded layout,
 // outputs per tile (0: the taps of one phase do not fit) and the LDS elements a tile stages.
-struct AnyPlan { int Pp, tap_bytes; bool pad; long long tile, span; };
+struct AnyPlan { int Pp, tap_bytes; bool pad; long long tile, span; int ks_lanes, ks_shift, ks_chunk; };
 AnyPlan any_plan(int L, int M, int P, int ch) {
     constexpr int NT = 256;
     AnyPlan p;
@@ -560,9 +560,24 @@ AnyPlan any_plan(int L, int M, int P, int ch) {
         const long long sp = ((t - 1) * M) / L + P + 2;
         return p.pad ? sp + sp / M + 1 : sp;
     };
-    while (tile > 1 && span_of(tile) > max_elems) tile /= 2;
-    p.tile = span_of(tile) > max_elems ? 0 : tile;
+    // interp 1 with a tile of at most a quarter of the workgroup: NT / tile lanes share an output's taps (NT partial
+    // sums behind the samples).  Two lanes per output (tile 128) measured no better than one: the extra barrier
+    // and LDS round trip cost what the halved tap loop saves (M = 50, 201 taps: 0.162 vs 0.145 ms).
+    constexpr int kSplitTile = NT / 4;
+    const bool ks_ok = L == 1 && P >= 64 && env_int("QDSP_HIP_ANY_NO_SPLIT", 0) == 0;
+    auto need = [&](long long t) { return span_of(t) + ((ks_ok && t <= kSplitTile) ? NT : 0); };
+    while (tile > 1 && need(tile) > max_elems) tile /= 2;
+    // a half-workgroup tile with a long tap loop: the quarter tile with four lanes per output is faster (M = 50,
+    // 401 taps: 0.24 -> 0.17 ms) unless it stages too little per lane (M = 32: 9 samples in batches of 8)
+    if (ks_ok && tile == 2 * kSplitTile && P >= env_int("QDSP_HIP_ANY_SPLIT_MIN_TAPS", 192) && M >= 40) tile = kSplitTile;
+    p.tile = need(tile) > max_elems ? 0 : tile;
     p.span = span_of(tile);
+    p.ks_lanes = p.ks_shift = p.ks_chunk = 0;
+    if (ks_ok && p.tile >= 16 && p.tile <= kSplitTile && (p.tile & (p.tile - 1)) == 0) {
+        p.ks_lanes = (int)(NT / p.tile);
+        while ((1 << p.ks_shift) < p.tile) p.ks_shift++;
+        p.ks_chunk = (((P + p.ks_lanes - 1) / p.ks_lanes) + 3) & ~3;
+    }
     return p;
 }
 
@@ -576,6 +591,10 @@ template <int CH, bool ROT> int launch_any(Engine* e, qk::AnyArgs& a, hipStream_
     a.tap_bytes = pl.tap_bytes;
     a.pad_inv = pad ? (unsigned)((1ULL << 32) / (unsigned)a.M) + 1u : 0u;
     a.tile = (int)tile;
+    a.ks_lanes = pl.ks_lanes;
+    a.ks_shift = pl.ks_shift;
+    a.ks_chunk = pl.ks_chunk;
+    a.ks_red = (int)pl.span;
     a.nblocks = (int)((a.nout + tile - 1) / tile);
     a.step_d = (int)(((long long)NT * a.M) / a.L);
     a.step_p = (int)(((long long)NT * a.M) % a.L);
@@ -583,7 +602,7 @@ template <int CH, bool ROT> int launch_any(Engine* e, qk::AnyArgs& a, hipStream_
     if (nwg > a.nblocks) nwg = a.nblocks;
     if (nwg < 1) nwg = 1;
     a.nwg = nwg;
-    const size_t lds = (size_t)a.tap_bytes + (size_t)pl.span * CH * sizeof(float);
+    const size_t lds = (size_t)a.tap_bytes + (size_t)(pl.span + (pl.ks_lanes ? NT : 0)) * CH * sizeof(float);
     fill_stage_rot(a, NT);
     if (pad) {
         if (lt) hipLaunchKernelGGL((qk::resamp_any_kernel<CH, NT, ROT, true, true>), dim3(nwg + 1), dim3(NT), lds, s, a);
@@ -632,7 +651,11 @@ int mode_of(const Engine* e) { return e->fir_mode ? e->fir_mode : env_int("QDSP_
 // the crossover down.
 bool any_direct_wins(const Engine* e) {
     if (e->L != 1 || e->ch != 2 || env_int("QDSP_HIP_NO_ANY_POLICY", 0)) return false;
-    if (any_plan(1, e->M, e->P, e->ch).tile == 0) return false;
+    const AnyPlan pl = any_plan(1, e->M, e->P, e->ch);
+    if (pl.tile == 0) return false;
+    // tiles of 64 outputs and fewer (M >= 64 or so) split every output's taps over 4-16 lanes: 0.12-0.26 ms up to
+    // 2001 taps at ~8 taps per unit of decimation (the reference VFO's own design rule) against 0.22-0.41
+    if (pl.ks_lanes) return e->P <= (e->rotate ? 12 : 10) * e->M;
     const int per_m = (e->M & 3) == 2 ? (e->rotate ? 10 : 7) : (e->rotate ? 15 : 9);
     const int max_taps = e->rotate ? 512 : 320;
     return e->P <= per_m * e->M && e->P <= max_taps;

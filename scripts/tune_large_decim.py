@@ -14,7 +14,7 @@ def timeit(op, x, out, iters=10):
 
 n = 1 << 26
 x = ops.synth_iq(n, seed=1)
-for M, ntaps in ((9, 63), (9, 127), (11, 63), (13, 127), (14, 63), (14, 127), (15, 127), (17, 69), (20, 127), (20, 255), (24, 97), (25, 101), (32, 129), (32, 255), (40, 161), (50, 201), (50, 63), (64, 257), (100, 201), (100, 401), (125, 501), (128, 255), (250, 1001)):
+for M, ntaps in ((9, 63), (14, 127), (17, 69), (20, 255), (25, 201), (32, 255), (40, 321), (50, 201), (50, 401), (64, 513), (100, 401), (100, 801), (125, 501), (128, 1025), (192, 1537), (250, 1001), (250, 2001)):
     taps = bench.lowpass_taps(ntaps, 0.4 / M)
     for vfo in (False, True):
         row = []
