@@ -885,6 +885,38 @@ def test_vfo_retune_mid_stream(ops, gold, M, ntaps):
     assert got.shape == want.shape and rel_rms(got, want) < 3e-6
 
 
+@pytest.mark.parametrize("M,ntaps", [(9, 63), (20, 127), (32, 255), (40, 321), (50, 401), (64, 513), (100, 801), (128, 255),
+                                      (147, 1177), (192, 1537), (250, 2001)])
+def test_large_decimation_direct_kernel(ops, M, ntaps):
+    """The VFO's usual job (2.4 Msps -> 48 kHz is M = 50) with the reference's ~8 taps per unit of decimation: AUTO
+    takes the general direct kernel (padded LDS layout when M is a multiple of 4; 4-16 lanes per output from tiles of
+    64 outputs down), as decimator and as fused VFO, over blocks that end inside tiles.  The tap split adds partial
+    sums in a different order than the k-ordered chain, so the bar is the FP64 oracle, not bit equality."""
+    taps = O.lowpass_taps_f64(ntaps, 0.4 / M).astype(np.float32)
+    sizes = [M * 4096 + 17, 5, M * 1500]
+    x = O.synth_iq(0, sum(sizes), seed=M)
+    cuts = np.cumsum([0] + sizes)
+    blocks = [x[a:b] for a, b in zip(cuts, cuts[1:])]
+    for vfo in (False, True):
+        if vfo:
+            op = ops.Vfo(taps, 1, M, ops.phase_delta(1.0, 0.2345), max_block=0)
+            xl, rs = O.Xlator(1.0, 0.2345, exact=True, volk_gain=True), O.Resampler(taps, 1, M, acc=O.ACC_F64)
+            want = np.concatenate([rs.process(xl.process(b)) for b in blocks])
+        else:
+            op = ops.Resampler(taps, 1, M, max_block=0)
+            rs = O.Resampler(taps, 1, M, acc=O.ACC_F64)
+            want = np.concatenate([rs.process(b) for b in blocks])
+        got = np.concatenate([op.process(dev(b)).cpu().numpy() for b in blocks])
+        assert op.last_kernel()["name"] == "resamp_any_kernel", (M, ntaps, vfo, op.last_kernel())
+        assert got.shape == want.shape and rel_rms(got, want) < 2e-6, (M, ntaps, vfo)
+        # the overlap-save form of the same plan agrees
+        ref = ops.Vfo(taps, 1, M, ops.phase_delta(1.0, 0.2345), max_block=0) if vfo else ops.Resampler(taps, 1, M, max_block=0)
+        ref.set_mode(ref.FFT)
+        alt = np.concatenate([ref.process(dev(b)).cpu().numpy() for b in blocks])
+        assert ref.last_kernel()["name"] == "fir_fft_kernel"
+        assert rel_rms(got, alt) < 3e-6, (M, ntaps, vfo)
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_random_plans_every_dispatch_path(ops, seed):
     """Seeded sweep over (interp, decim, tap count, data type, NCO, block sizes, kernel mode): whichever kernel the
