@@ -54,6 +54,8 @@ WORKLOADS = {
     # short filters (the strided-window direct kernel)
     "decim8_t63": dict(ntaps=63, decim=8, rot=False, bytes=9.0, flops=31.5),
     "xlate_fir_decim8_t63": dict(ntaps=63, decim=8, rot=True, bytes=9.0, flops=37.5),
+    # the reference VFO's usual shape (vfo.h: 2.4 Msps -> 48 kHz, ~8 taps per unit of decimation): 8 + 8/50 B
+    "vfo50": dict(ntaps=401, decim=50, rot=True, bytes=8.16, flops=38.1, fc=0.4 / 50),
     # BASELINE configs[4]: 64 channels at (c - 31.5) fs/64, 256 taps, decimate 64: 8 B in + 64*8/64 B out
     "chan64": dict(ntaps=256, decim=64, rot=True, bytes=16.0, flops=1408.0, nchan=64),
     # its oversampled variant (SURVEY 8d config 5 "and M = 8"): 8 B in + 64*8/8 B out per input sample
@@ -81,7 +83,7 @@ def make_op(ops, name: str, device: int):
     if name in ("chan64", "chan64m8"):
         incs = [ops.phase_delta(1.0, -(c - 31.5) / 64.0) for c in range(64)]
         return ops.Channelizer(lowpass_taps(256, 1.0 / 128.0), 1, w["decim"], incs, device=device, max_block=0)
-    taps = lowpass_taps(w["ntaps"], 1.0 / 16.0) if name != "fir63" else None
+    taps = lowpass_taps(w["ntaps"], w.get("fc", 1.0 / 16.0)) if name != "fir63" else None
     if taps is None:
         import numpy as np
 
@@ -105,7 +107,7 @@ def cpu_baseline(name: str, seconds: float):
     import oracle as O
 
     w = WORKLOADS[name]
-    taps = lowpass_taps(w["ntaps"] or 256, 1.0 / 16.0)
+    taps = lowpass_taps(w["ntaps"] or 256, w.get("fc", 1.0 / 16.0))
 
     def make():
         if name == "xlate":
@@ -437,6 +439,7 @@ def main():
                     "xlate": "NCO frequency translator alone",
                     "decim8_t63": "63-tap polyphase decimate-by-8",
                     "xlate_fir_decim8_t63": "fused NCO + 63-tap FIR + decimate-by-8",
+                    "vfo50": "fused NCO + 401-tap FIR + decimate-by-50 (the reference VFO's 2.4 Msps -> 48 kHz shape)",
                     "chan64": "64-channel polyphase channelizer, 256 taps, decimate 64 (BASELINE configs[4])",
                     "chan64m8": "64-channel polyphase channelizer oversampled by 8: 256 taps, decimate 8 (BASELINE configs[4], M = 8 variant)",
                 }[args.workload],

@@ -598,11 +598,13 @@ template <int CH, bool ROT> int launch_any(Engine* e, qk::AnyArgs& a, hipStream_
     a.nblocks = (int)((a.nout + tile - 1) / tile);
     a.step_d = (int)(((long long)NT * a.M) / a.L);
     a.step_p = (int)(((long long)NT * a.M) % a.L);
-    int nwg = 256 * 8;
+    const size_t lds = (size_t)a.tap_bytes + (size_t)(pl.span + (pl.ks_lanes ? NT : 0)) * CH * sizeof(float);
+    // persistent workgroups, 8 per CU (measured on the M = 50, 401-tap VFO, 32 KB of LDS each: 5 per CU -- what is
+    // resident at once -- 0.41 ms per 2^27 samples, 8 .. 64 per CU 0.345-0.358)
+    int nwg = 256 * env_int("QDSP_HIP_ANY_WG_PER_CU", 8);
     if (nwg > a.nblocks) nwg = a.nblocks;
     if (nwg < 1) nwg = 1;
     a.nwg = nwg;
-    const size_t lds = (size_t)a.tap_bytes + (size_t)(pl.span + (pl.ks_lanes ? NT : 0)) * CH * sizeof(float);
     fill_stage_rot(a, NT);
     if (pad) {
         if (lt) hipLaunchKernelGGL((qk::resamp_any_kernel<CH, NT, ROT, true, true>), dim3(nwg + 1), dim3(NT), lds, s, a);
