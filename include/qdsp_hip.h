@@ -155,10 +155,12 @@ int64_t qdsp_hip_decim_cf32_out_size(void* h, int64_t count); /* calcOutSize, :9
 /* QDSP_HIP_FIR_AUTO / _DIRECT / _FFT as for the FIR.  The overlap-save path serves interp == 1
  * with any decimation >= 2 (decim in {2, 4, 8, 16}: pruned inverse transform; others: full
  * inverse, every decim-th output stored).  AUTO (measured crossovers): short and medium filters
- * (decim 2..8, 10, 12, 16; up to 150..256 taps) run a strided-window direct kernel; longer ones, and other decimations, the
- * overlap-save path on calls of >= 65536 samples; the rest the de-interleaved direct form.
- * QDSP_HIP_FIR_DIRECT always means that last, k-ordered form.  interp > 1 is direct form whatever
- * the mode. */
+ * (decim 2..8, 10, 12, 16; up to 150..256 taps) run a strided-window direct kernel; decimations from 9 on with
+ * up to ~9 taps per unit of decimation (the VFO's usual shape) the general direct kernel, which streams the
+ * input once (4-16 lanes share an output's taps once a tile holds fewer outputs than a workgroup has lanes:
+ * partial sums are then added in chunk order, not tap order); longer filters the overlap-save path on calls of
+ * >= 65536 samples; the rest a direct form.  QDSP_HIP_FIR_DIRECT always means a direct form (decim <= 8: the
+ * de-interleaved, k-ordered kernel; above: the general kernel).  interp > 1 is direct form whatever the mode. */
 int qdsp_hip_decim_cf32_set_mode(void* h, int mode);
 int qdsp_hip_decim_cf32_reset(void* h);
 int qdsp_hip_decim_cf32_history_len(void* h); /* = taps per phase */
