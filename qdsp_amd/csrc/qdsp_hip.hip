@@ -573,7 +573,7 @@ AnyPlan any_plan(int L, int M, int P, int ch) {
     p.tile = need(tile) > max_elems ? 0 : tile;
     p.span = span_of(tile);
     p.ks_lanes = p.ks_shift = p.ks_chunk = 0;
-    if (ks_ok && p.tile >= 16 && p.tile <= kSplitTile && (p.tile & (p.tile - 1)) == 0) {
+    if (ks_ok && p.tile >= 1 && p.tile <= kSplitTile && (p.tile & (p.tile - 1)) == 0) {
         p.ks_lanes = (int)(NT / p.tile);
         while ((1 << p.ks_shift) < p.tile) p.ks_shift++;
         p.ks_chunk = (((P + p.ks_lanes - 1) / p.ks_lanes) + 3) & ~3;

@@ -886,14 +886,14 @@ def test_vfo_retune_mid_stream(ops, gold, M, ntaps):
 
 
 @pytest.mark.parametrize("M,ntaps", [(9, 63), (20, 127), (32, 255), (40, 321), (50, 401), (64, 513), (100, 801), (128, 255),
-                                      (147, 1177), (192, 1537), (250, 2001)])
+                                      (147, 1177), (192, 1537), (250, 2001), (1000, 2049), (2500, 1999)])
 def test_large_decimation_direct_kernel(ops, M, ntaps):
     """The VFO's usual job (2.4 Msps -> 48 kHz is M = 50) with the reference's ~8 taps per unit of decimation: AUTO
     takes the general direct kernel (padded LDS layout when M is a multiple of 4; 4-16 lanes per output from tiles of
     64 outputs down), as decimator and as fused VFO, over blocks that end inside tiles.  The tap split adds partial
     sums in a different order than the k-ordered chain, so the bar is the FP64 oracle, not bit equality."""
     taps = O.lowpass_taps_f64(ntaps, 0.4 / M).astype(np.float32)
-    sizes = [M * 4096 + 17, 5, M * 1500]
+    sizes = [M * 4096 + 17, 5, M * 1500] if M < 1000 else [M * 300 + 17, 5, M * 100]
     x = O.synth_iq(0, sum(sizes), seed=M)
     cuts = np.cumsum([0] + sizes)
     blocks = [x[a:b] for a, b in zip(cuts, cuts[1:])]
@@ -906,6 +906,8 @@ def test_large_decimation_direct_kernel(ops, M, ntaps):
             op = ops.Resampler(taps, 1, M, max_block=0)
             rs = O.Resampler(taps, 1, M, acc=O.ACC_F64)
             want = np.concatenate([rs.process(b) for b in blocks])
+        if M >= 1000:
+            op.set_mode(op.DIRECT)      # (AUTO: overlap-save; here the tap split at 1-8 outputs per tile is under test)
         got = np.concatenate([op.process(dev(b)).cpu().numpy() for b in blocks])
         assert op.last_kernel()["name"] == "resamp_any_kernel", (M, ntaps, vfo, op.last_kernel())
         assert got.shape == want.shape and rel_rms(got, want) < 2e-6, (M, ntaps, vfo)
