@@ -399,7 +399,9 @@ struct AnyArgs {
 // waves or half-waves per j: the window pattern across lanes is unchanged), partial sums meet in LDS and are
 // added in the order j = 0 .. S-1.  (Taps of a wave-uniform chunk through scalar loads instead of LDS broadcast
 // reads -- a third of the kernel's LDS traffic -- measured SLOWER, 0.44 vs 0.35 ms per 2^27 samples at M = 50,
-// 401 taps: SMEM and LDS share lgkmcnt, so every group of four MACs waits for both.)
+// 401 taps: SMEM and LDS share lgkmcnt, so every group of four MACs waits for both.  The padded layout for
+// M = 2 mod 4 in this form -- pairs instead of groups of four inside a row -- also lost: 0.41 vs 0.35 ms at M = 50;
+// its 2-way conflicts cost less than the row bookkeeping.)
 template <int CH, int NT, bool ROT, bool LT, bool PAD>
 __global__ __launch_bounds__(NT) void resamp_any_kernel(const AnyArgs a) {
     using T = typename Smp<CH>::T;
