@@ -614,9 +614,13 @@ int launch_fir_fft(const FftArgs& a, int grid, hipStream_t stream) {
             if (r) hipLaunchKernelGGL((fir_fft_kernel<2, true>), dim3(grid), dim3(kFftNT), 0, stream, a);
             else hipLaunchKernelGGL((fir_fft_kernel<2, false>), dim3(grid), dim3(kFftNT), 0, stream, a);
             break;
-        case 4: if (r) QK_FFT(4, true); else QK_FFT(4, false); break;
-        case 8: if (r) QK_FFT(8, true); else QK_FFT(8, false); break;
-        case 16: if (r) QK_FFT(16, true); else QK_FFT(16, false); break;
+        // grouped: the chip-filling form; per segment (small calls: a 1e6-sample block is 33 groups of 8 segments, worked
+        // through serially by 33 workgroups in 27 us -- as 260 independent segments it takes 9 us)
+#define QK_SEG(dec, rot) hipLaunchKernelGGL((fir_fft_kernel<dec, rot>), dim3(grid), dim3(kFftNT), 0, stream, a)
+        case 4: if (a.grouped) { if (r) QK_FFT(4, true); else QK_FFT(4, false); } else { if (r) QK_SEG(4, true); else QK_SEG(4, false); } break;
+        case 8: if (a.grouped) { if (r) QK_FFT(8, true); else QK_FFT(8, false); } else { if (r) QK_SEG(8, true); else QK_SEG(8, false); } break;
+        case 16: if (a.grouped) { if (r) QK_FFT(16, true); else QK_FFT(16, false); } else { if (r) QK_SEG(16, true); else QK_SEG(16, false); } break;
+#undef QK_SEG
         default: return -1;
     }
 #undef QK_FFT

@@ -47,6 +47,7 @@ struct FftArgs {
     int nblocks;
     int nwg;                  // persistent workgroups (grid = nwg + 1; the last one hands over history)
     int vec;                  // 1: in/out 16-byte aligned and segments start on even samples -> float4 path
+    int grouped;              // dec >= 4: 1 = fir_fft_dec_kernel (groups of dec segments), 0 = one segment per workgroup
     int real2;                // 1: real samples (4-byte in/out/hist); block b = real segments 2b (re) and 2b+1 (im)
     // NCO (rot only).  x[j] exp(j phi(j)) filtered by h == exp(j phi(p - (N-1))) * (x filtered by
     // h[k] exp(j k dphase)) at output position p: the input is never rotated, only the KEPT outputs are.

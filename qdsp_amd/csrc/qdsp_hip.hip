@@ -827,7 +827,10 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
     }
     // FIR: 4 workgroups resident per CU (124 VGPRs, 37 KB LDS), 16 queued per CU for balance.
     // Decimators work in groups of `dec` segments, 2 resident per CU (70 KB LDS).
-    const bool grouped = a.dec >= 4;
+    // (grouped only when the groups fill the chip -- measured crossover ~1000 groups, 2^25 samples at decimation 8 --
+    // below that the segments run one per workgroup: a 1e6-sample block 10 us instead of 28)
+    const bool grouped = a.dec >= 4 && (a.nblocks + a.dec - 1) / a.dec >= env_int("QDSP_HIP_FFT_GROUP_MIN_UNITS", 1024);
+    a.grouped = grouped ? 1 : 0;
     const int per_cu = env_int("QDSP_HIP_FFT_WG_PER_CU", grouped ? 4 : 16);
     const int units = grouped ? (a.nblocks + a.dec - 1) / a.dec : a.nblocks;
     int nwg = 256 * per_cu;
