@@ -686,6 +686,9 @@ bool fft_eligible(const Engine* e, int64_t count) {
         // FIR: the overlap-save kernel (a copy-speed 4.8 TB/s whatever the taps) beats the tile-per-block
         // direct form from 8 taps on (2^26 samples: 0.222 vs 0.256 ms at 7 taps, 0.225 vs 0.394 at 127)
         min_taps = env_int("QDSP_HIP_FFT_MIN_TAPS", 8);
+        // reference-sized calls (<= 1e6 samples, stream.h:7) are latency-bound: one 4096-point segment takes ~9 us
+        // whatever the taps, the direct form 4.7 / 5.7 us at 31 / 63 taps (8.3 at 1e6 samples) and 11-16 us at 256
+        if (count < (1 << 21) && min_taps < 96) min_taps = env_int("QDSP_HIP_FFT_MIN_TAPS_SMALL", 96);
     } else {
         if (e->M >= 9 && !use_win(e) && any_direct_wins(e)) return false;
         // decimators (scripts/tune_small.py, profiles/r01_tune_small.txt): the direct form slows down with the
