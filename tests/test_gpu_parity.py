@@ -1027,6 +1027,52 @@ def test_random_device_pointers_and_guard_bands(ops, seed):
                 assert rel_rms(host[pad + oo : pad + oo + len(want)], want) < 4e-6, (kind, L, M, ntaps, mode, m, oi, oo, op.last_kernel()["name"])
 
 
+def test_calls_beyond_2_31_samples(ops, gold):
+    """One call of 2^31 + 65553 samples (16 GiB in: sample indices past 2^31, byte offsets past 2^34) through the mixer,
+    the overlap-save FIR, the grouped decimator and the large-decimation direct kernel.  Windows right after the 2^31
+    boundary and at the very end are recomputed by a fresh instance on a short slice (started on a multiple of
+    lcm(512, decim) so that the polyphase counter, the NCO -- advanced to the slice start -- and VOLK's gain
+    sawtooth line up) and must agree."""
+    import torch
+
+    free, _ = torch.cuda.mem_get_info()
+    n = (1 << 31) + 65553
+    if free < 40 * (1 << 30):
+        pytest.skip("needs 40 GiB of device memory")
+    x = ops.synth_iq(n, seed=77)
+    t401 = O.lowpass_taps_f64(401, 0.4 / 50).astype(np.float32)
+    inc = ops.phase_delta(1.0, 0.1234)
+    plans = [
+        ("xlate", 1, 0, lambda: ops.Xlator(phase_inc=inc, max_block=0), "xlate_kernel"),
+        ("fir256", 1, 256, lambda: ops.Fir(gold["taps256"], max_block=0), "fir_fft_kernel"),
+        ("vfo8", 8, 256, lambda: ops.Vfo(gold["taps256"], 1, 8, inc, max_block=0), "fir_fft_kernel"),
+        ("vfo50", 50, 401, lambda: ops.Vfo(t401, 1, 50, inc, max_block=0), "resamp_any_kernel"),
+    ]
+    for name, M, ntaps, mk, kernel in plans:
+        op = mk()
+        nout = n // M
+        y = torch.empty(nout + 8, dtype=torch.complex64, device="cuda")
+        got = op.process(x, out=y)
+        torch.cuda.synchronize()
+        assert got.numel() == nout and op.last_kernel()["name"] == kernel, (name, op.last_kernel())
+        step = 512 * M // int(np.gcd(512, M))
+        for target in ((1 << 31) + 4096, n - 70_000):
+            s0 = (target // step) * step
+            seg = x[s0 : min(n, s0 + 66_000 // M * M)]
+            ref = mk()
+            if name != "fir256":
+                ref.advance(s0)
+            want = ref.process(seg)
+            torch.cuda.synchronize()
+            skip = (ntaps + M - 1) // M + 2          # the slice starts from zero history
+            a = got[s0 // M + skip : s0 // M + want.numel()].cpu().numpy()
+            b = want[skip:].cpu().numpy()
+            assert a.shape == b.shape and len(a) > 500
+            assert rel_rms(a, b) < 3e-6, (name, target)
+        del y, got, op
+        torch.cuda.empty_cache()
+
+
 def test_bench_size_cross_checks(ops, gold):
     """The bench's size (2^27 samples per call = 1 GiB in: byte offsets past 2^31): independent kernels must agree.
     Overlap-save FIR vs direct form; fused overlap-save VFO vs NCO kernel -> decimator; polyphase channelizer vs
