@@ -96,11 +96,14 @@ __global__ __launch_bounds__(kFftNT, (DEC == 1 && !ROT && !REAL) ? 4 : 3) void f
             float2 v;
             if (g < 0) {
                 v = a.hist_keep[g + H];
+                if (ROT && a.hist_raw_next) a.hist_raw_next[i] = a.hist[g + H];
             } else {
                 v = a.in[g];
                 if (ROT) {
                     const double2 p = fx_phasor(a.phase_in0 + (unsigned long long)g * a.dphase);
                     const float gain = fmaf((float)(int)(g & 511), a.gm1, 1.0f);
+                    // the un-rotated form (gain kept) for the next overlap-save call: saves its de-rotation launch
+                    if (a.hist_raw_next) a.hist_raw_next[i] = make_float2(v.x * gain, v.y * gain);
                     v = cmulc<false>(v, make_float2((float)p.x * gain, (float)p.y * gain));
                 }
             }
@@ -426,11 +429,14 @@ __global__ __launch_bounds__(kFftNT, 2) void fir_fft_dec_kernel(const FftArgs a)
             float2 v;
             if (g < 0) {
                 v = a.hist_keep[g + H];
+                if (ROT && a.hist_raw_next) a.hist_raw_next[i] = a.hist[g + H];
             } else {
                 v = a.in[g];
                 if (ROT) {
                     const double2 p = fx_phasor(a.phase_in0 + (unsigned long long)g * a.dphase);
                     const float gain = fmaf((float)(int)(g & 511), a.gm1, 1.0f);
+                    // the un-rotated form (gain kept) for the next overlap-save call: saves its de-rotation launch
+                    if (a.hist_raw_next) a.hist_raw_next[i] = make_float2(v.x * gain, v.y * gain);
                     v = cmulc<false>(v, make_float2((float)p.x * gain, (float)p.y * gain));
                 }
             }

@@ -28,6 +28,7 @@ struct FftArgs {
     const float2* in;
     float2* out;
     const float2* hist;       // H raw samples preceding in[0] (fused VFO: de-rotated by the caller from the rotated form the handle keeps)
+    float2* hist_raw_next;    // fused VFO: where the hand-over also leaves the next call's history un-rotated (or nullptr)
     const float2* hist_keep;  // the same H samples in the form the handle keeps them (rotated for the fused VFO): source of the hand-over
     float2* hist_next;
     const float2* Hf;         // [256][16]: Hf[(k0*16+k1)*16 + k2] = FFT(taps reversed)[k0 + 16 k1 + 256 k2] / F

@@ -57,8 +57,12 @@ struct Engine {
     unsigned long long nco_key_dphase = 0;
     long long nco_key_S = 0;
     int nco_key_NT = 0, nco_key_na = 0;
-    float* d_hist_raw = nullptr;  // overlap-save VFO: the history de-rotated for the current call
+    // overlap-save VFO: the history un-rotated (the kernels filter raw samples), double-buffered like d_hist.
+    // raw_valid: d_hist_raw[cur] matches d_hist[cur] (left there by the previous overlap-save call's hand-over);
+    // anything else that touches the history or the NCO clears it and the next call de-rotates d_hist[cur] once.
+    float* d_hist_raw[2] = {nullptr, nullptr};
     int hist_raw_cap = 0;
+    bool raw_valid = false;
     float* d_taps_lm = nullptr;  // resamp_lm_kernel's per-sub-filter branch-major taps (small interp only)
     size_t taps_lm_t_off = 0;    // offset (floats) of the transposed copy used when decim == 1    // core layout (branch-major) or phases [L][P]
     float* d_hist[2] = {nullptr, nullptr};
@@ -244,12 +248,14 @@ int configure(Engine* e, const float* taps, int ntaps, int interp, int decim) {
     e->d_hist[0] = nh[0];
     e->d_hist[1] = nh[1];
     e->cur = 0;
+    e->raw_valid = false;
     e->H = newH;
     e->hist_cap = newH;
     return 0;
 }
 
 void set_inc(Engine* e, float re, float im) {
+    e->raw_valid = false;   // (a retune: the rotated history stays the truth, see launch_fft)
     e->inc_re = re;
     e->inc_im = im;
     e->dturns = turns_of(re, im);
@@ -307,7 +313,8 @@ void destroy(Engine* e) {
     (void)hipDeviceSynchronize();
     if (e->d_taps) (void)hipFree(e->d_taps);
     if (e->d_taps_lm) (void)hipFree(e->d_taps_lm);
-    if (e->d_hist_raw) (void)hipFree(e->d_hist_raw);
+    for (int i = 0; i < 2; i++)
+        if (e->d_hist_raw[i]) (void)hipFree(e->d_hist_raw[i]);
     if (e->d_nco_tab) (void)hipFree(e->d_nco_tab);
     if (e->d_fft_H) (void)hipFree(e->d_fft_H);
     if (e->d_fft_TA) (void)hipFree(e->d_fft_TA);
@@ -775,18 +782,24 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
         // form with its size), the overlap-save kernels filter RAW samples: de-rotate the H samples once per call
         // into a side buffer -- exp(-j phi(g)), g = -H .. -1 -- instead of carrying an FP64 sincos in the first
         // segment's load path of the big kernel (its registers cost the grouped kernel 20 spilled VGPRs).
-        if (!e->d_hist_raw || e->hist_raw_cap < e->H) {
-            if (e->d_hist_raw) HIPCHK(hipFree(e->d_hist_raw));
-            e->d_hist_raw = nullptr;
-            HIPCHK(hipMalloc(&e->d_hist_raw, (size_t)e->H * sizeof(float2)));
+        if (!e->d_hist_raw[0] || e->hist_raw_cap < e->H) {
+            for (int i = 0; i < 2; i++) {
+                if (e->d_hist_raw[i]) HIPCHK(hipFree(e->d_hist_raw[i]));
+                e->d_hist_raw[i] = nullptr;
+                HIPCHK(hipMalloc(&e->d_hist_raw[i], (size_t)e->H * sizeof(float2)));
+            }
             e->hist_raw_cap = e->H;
+            e->raw_valid = false;
         }
-        const unsigned long long ph_first = e->phase - (unsigned long long)e->H * e->dphase;   // phase of history sample 0
-        const Launch keep = e->last;
-        rc = launch_xlate_inc(e, e->d_hist[e->cur], e->H, e->d_hist_raw, 0ULL - ph_first, 0ULL - e->dphase, 0.0f, s);
-        e->last = keep;
-        if (rc) return rc;
-        a.hist = reinterpret_cast<const float2*>(e->d_hist_raw);
+        if (!e->raw_valid || env_int("QDSP_HIP_NO_RAW_CARRY", 0)) {
+            const unsigned long long ph_first = e->phase - (unsigned long long)e->H * e->dphase;   // phase of history sample 0
+            const Launch keep = e->last;
+            rc = launch_xlate_inc(e, e->d_hist[e->cur], e->H, e->d_hist_raw[e->cur], 0ULL - ph_first, 0ULL - e->dphase, 0.0f, s);
+            e->last = keep;
+            if (rc) return rc;
+        }
+        a.hist = reinterpret_cast<const float2*>(e->d_hist_raw[e->cur]);
+        a.hist_raw_next = reinterpret_cast<float2*>(e->d_hist_raw[e->cur ^ 1]);
     }
     a.Hf = e->d_fft_H;
     a.TA = e->d_fft_TA;
@@ -854,6 +867,7 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
     }
     rc = qk::launch_fir_fft(a, nwg + 1, s);
     if (rc) return rc;
+    e->raw_valid = e->rotate && e->H > 0;   // (the caller flips cur: the raw hand-over then sits at d_hist_raw[cur])
     e->last.name = "fir_fft_kernel";
     e->last.grid = nwg + 1;
     e->last.block = qk::kFftNT;
@@ -906,11 +920,13 @@ int64_t process_dev(Engine* e, const void* d_in, int64_t count, void* d_out, voi
     hipStream_t s = static_cast<hipStream_t>(stream);  // NULL == HIP's default stream
     const int64_t nout = out_size(e, count);
     int rc = 0;
+    bool took_fft = false;
     if (!e->has_filter) {
         rc = launch_xlate(e, d_in, count, d_out, s);
     } else if (fft_eligible(e, count) && !(mode_of(e) == 0 && use_win(e) && e->d_taps_lm)) {
         rc = launch_fft(e, d_in, count, nout, d_out, s);
         if (rc == 0) e->cur ^= 1;
+        took_fft = true;
     } else if (use_win(e) && e->d_taps_lm && mode_of(e) == 0) {
         // AUTO only: QDSP_HIP_FIR_DIRECT keeps meaning fir_core_kernel (the form the bit-exactness tests pin),
         // QDSP_HIP_FIR_FFT the overlap-save kernels
@@ -960,6 +976,7 @@ int64_t process_dev(Engine* e, const void* d_in, int64_t count, void* d_out, voi
         else rc = launch_any<1, false>(e, a, s);
         if (rc == 0) e->cur ^= 1;
     }
+    if (!took_fft) e->raw_valid = false;   // (the direct kernels hand over the rotated history only)
     if (rc) return rc;
     if (e->rotate) e->phase += (unsigned long long)count * e->dphase;  // exact mod 2^64
     return nout;
@@ -1012,6 +1029,7 @@ int reset(Engine* e) {
     for (int i = 0; i < 2; i++)
         if (e->d_hist[i] && e->H > 0) HIPCHK(hipMemset(e->d_hist[i], 0, (size_t)e->H * e->ch * sizeof(float)));
     e->phase = 0;
+    e->raw_valid = false;
     return 0;
 }
 
@@ -1025,6 +1043,7 @@ int get_history(Engine* e, float* hist) {
 }
 int set_history(Engine* e, const float* hist) {
     if (!hist) return QDSP_HIP_EINVAL;
+    e->raw_valid = false;
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipDeviceSynchronize());
     if (e->H > 0)
@@ -1037,6 +1056,7 @@ int set_history(Engine* e, const float* hist) {
 // those samples are rotated here with the phases they would have had: phase - H*dphase onward.
 int set_history_dev(Engine* e, const void* d_hist, void* stream) {
     if (!d_hist) return QDSP_HIP_EINVAL;
+    e->raw_valid = false;
     HIPCHK(hipSetDevice(e->device));
     if (e->H <= 0) return 0;
     if (e->rotate && e->has_filter)
@@ -1057,6 +1077,7 @@ int get_phase(Engine* e, float* re, float* im) {
 }
 int set_phase(Engine* e, float re, float im) {
     if (re == 0.0f && im == 0.0f) return QDSP_HIP_EINVAL;
+    e->raw_valid = false;
     e->phase = fx_of_turns(turns_of(re, im));
     return 0;
 }
@@ -1371,6 +1392,7 @@ int qdsp_hip_device_sync(int device) { HIPCHK(hipSetDevice(device)); HIPCHK(hipD
         Engine* e = as_engine(h, KIND);                                                           \
         if (!e || !d) return QDSP_HIP_EINVAL;                                                     \
         *d = e->d_hist[e->cur];                                                                   \
+        e->raw_valid = false; /* (the caller may write through the pointer) */                    \
         return 0;                                                                                 \
     }                                                                                             \
     int prefix##_set_history_dev(void* h, const void* d, void* s) {                               \
@@ -1516,6 +1538,7 @@ int qdsp_hip_xlate_cf32_advance(void* h, int64_t n) {
     Engine* e = as_engine(h, KIND_XLATE);
     if (!e) return QDSP_HIP_EINVAL;
     e->phase += (unsigned long long)n * e->dphase;
+    e->raw_valid = false;
     return 0;
 }
 int qdsp_hip_xlate_cf32_set_volk_gain(void* h, int on) {
@@ -1627,6 +1650,7 @@ int qdsp_hip_xlate_fir_decim_cf32_advance(void* h, int64_t n) {
     Engine* e = as_engine(h, KIND_VFO);
     if (!e) return QDSP_HIP_EINVAL;
     e->phase += (unsigned long long)n * e->dphase;
+    e->raw_valid = false;
     return 0;
 }
 int qdsp_hip_xlate_fir_decim_cf32_set_volk_gain(void* h, int on) {
@@ -1754,7 +1778,7 @@ int qdsp_hip_chan_cf32_set_history_dev(void* h, const void* d_hist, void* s) {
 int qdsp_hip_chan_cf32_advance(void* h, int64_t n) {
     Chan* c = as_chan(h);
     if (!c) return QDSP_HIP_EINVAL;
-    for (Engine* e : c->vfo) e->phase += (unsigned long long)n * e->dphase;
+    for (Engine* e : c->vfo) { e->phase += (unsigned long long)n * e->dphase; e->raw_valid = false; }
     return 0;
 }
 int qdsp_hip_chan_cf32_channels(void* h) {

@@ -1027,6 +1027,31 @@ def test_random_device_pointers_and_guard_bands(ops, seed):
                 assert rel_rms(host[pad + oo : pad + oo + len(want)], want) < 4e-6, (kind, L, M, ntaps, mode, m, oi, oo, op.last_kernel()["name"])
 
 
+def test_vfo_history_forms_across_kernel_switches(ops, gold):
+    """The fused VFO keeps its history rotated (what the direct kernels and the reference's resampler buffer hold);
+    the overlap-save kernels filter raw samples and hand the un-rotated history from call to call.  A stream
+    whose calls alternate between the two forms, with a retune and a phase jump in between, must still match
+    the oracle: every switch has to pick up the right copy."""
+    taps = gold["taps256"]
+    sizes = [70_000, 90_000, 3_000, 80_000, 66_000, 1_000, 72_000, 72_000, 88_000]
+    sizes = [n // 8 * 8 for n in sizes]
+    x = O.synth_iq(0, sum(sizes), seed=4242)
+    v = ops.Vfo(taps, 1, 8, ops.phase_delta(48000.0, 1234.0), max_block=0)
+    xl, rs = O.Xlator(48000.0, 1234.0, exact=True, volk_gain=True), O.Resampler(taps, 1, 8, acc=O.ACC_F64)
+    pos, names = 0, []
+    for i, m in enumerate(sizes):
+        if i == 6:       # retune between two overlap-save calls
+            v.set_phase_inc(*ops.phase_delta(48000.0, -7000.0))
+            O.lib().oracle_xlator_phase_delta(48000.0, -7000.0, O._fp(xl.delta))
+        seg = x[pos : pos + m]
+        pos += m
+        got = v.process(dev(seg)).cpu().numpy()
+        names.append(v.last_kernel()["name"])
+        want = rs.process(xl.process(seg))
+        assert got.shape == want.shape and rel_rms(got, want) < 3e-6, (i, m, names)
+    assert names.count("fir_fft_kernel") >= 6 and len(set(names)) >= 2, names
+
+
 def test_calls_beyond_2_31_samples(ops, gold):
     """One call of 2^31 + 65553 samples (16 GiB in: sample indices past 2^31, byte offsets past 2^34) through the mixer,
     the overlap-save FIR, the grouped decimator and the large-decimation direct kernel.  Windows right after the 2^31
