@@ -1040,6 +1040,11 @@ def test_vfo_history_forms_across_kernel_switches(ops, gold):
     xl, rs = O.Xlator(48000.0, 1234.0, exact=True, volk_gain=True), O.Resampler(taps, 1, 8, acc=O.ACC_F64)
     pos, names = 0, []
     for i, m in enumerate(sizes):
+        if i == 4:       # phase jump (FrequencyXlator has no such setter; the ABI's *_set_phase does) before an overlap-save call
+            import math
+            re, im = np.float32(math.cos(1.0)), np.float32(math.sin(1.0))
+            v.set_phase(float(re), float(im))
+            xl.turns.value = math.atan2(float(im), float(re)) / (2 * math.pi)
         if i == 6:       # retune between two overlap-save calls
             v.set_phase_inc(*ops.phase_delta(48000.0, -7000.0))
             O.lib().oracle_xlator_phase_delta(48000.0, -7000.0, O._fp(xl.delta))
