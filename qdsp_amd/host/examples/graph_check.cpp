@@ -18,6 +18,10 @@
 //                      blocks in a row, the two links between them device-resident
 //   graph_check math   <in.cf32> <out.cf32> <block> add|sub|mul <sampleRate> <freq>
 //                      source -> Splitter -> { FrequencyXlator, identity } -> Add | Substract | Multiply -> sink
+//   graph_check bench  vfo|chain <blockSize> <nblocks> <inSR> <outSR>
+//                      throughput of a live graph: SineSource -> VFO -> sink, or SineSource -> FrequencyXlator ->
+//                      PolyphaseResampler -> sink (the same two blocks unfused, device-resident link between them);
+//                      prints input Msamples/s and microseconds per block
 //   graph_check split  <in.cf32> <out_prefix> <block> <n> <inSR> <outSR> <bw>
 //                      source -> Splitter -> n x VFO(offset_i = (i - (n-1)/2) * inSR/n) -> sinks
 #include <atomic>
@@ -241,6 +245,64 @@ int main(int argc, char** argv) {
         delete fir;
         delete taps;
         printf("sine ok: %d blocks of %d\n", nb, bs);
+        return 0;
+    }
+    if (mode == "bench" && argc >= 7) {
+        const std::string kind = argv[2];
+        const int bs = atoi(argv[3]), nb = atoi(argv[4]);
+        const float inSR = (float)atof(argv[5]), outSR = (float)atof(argv[6]);
+        if (bs <= 0 || bs > STREAM_BUFFER_SIZE || nb <= 0) { fprintf(stderr, "bad block size / count\n"); return 2; }
+        struct Count {
+            std::atomic<long> blocks{0}, samples{0};
+            static void push(complex_t*, int count, void* ctx) {
+                Count* c = static_cast<Count*>(ctx);
+                c->samples += count;
+                c->blocks++;
+            }
+        } cnt;
+        SineSource src(bs, inSR, inSR * 0.01f);
+        VFO* vfo = nullptr;
+        FrequencyXlator<complex_t>* xl = nullptr;
+        PolyphaseResampler<complex_t>* rs = nullptr;
+        filter_window::BlackmanWindow win(outSR / 2.0f, outSR / 2.0f, inSR);
+        stream<complex_t>* tail = nullptr;
+        if (kind == "vfo") {
+            vfo = new VFO(&src.out, inSR * 0.1f, inSR, outSR, outSR);
+            tail = vfo->out;
+        } else if (kind == "chain") {
+            xl = new FrequencyXlator<complex_t>(&src.out, inSR, -inSR * 0.1f);
+            rs = new PolyphaseResampler<complex_t>(&xl->out, &win, inSR, outSR);
+            tail = &rs->out;
+        } else { fprintf(stderr, "bench kind: vfo | chain\n"); return 2; }
+        HandlerSink<complex_t> sink(tail, Count::push, &cnt);
+        sink.start();
+        if (vfo) { vfo->start(); }
+        if (rs) { rs->start(); xl->start(); }
+        src.start();
+        const int warm = nb / 10 + 2;
+        auto wait_for = [&](long n) {
+            const auto t0 = std::chrono::steady_clock::now();
+            while (cnt.blocks.load() < n) {
+                std::this_thread::sleep_for(std::chrono::microseconds(200));
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) { return false; }
+            }
+            return true;
+        };
+        if (!wait_for(warm)) { fprintf(stderr, "bench graph timed out\n"); return 3; }
+        const long b0 = cnt.blocks.load();
+        const auto t0 = std::chrono::steady_clock::now();
+        if (!wait_for(b0 + nb)) { fprintf(stderr, "bench graph timed out\n"); return 3; }
+        const long b1 = cnt.blocks.load();
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        src.stop();
+        if (vfo) { vfo->stop(); }
+        if (rs) { xl->stop(); rs->stop(); }
+        sink.stop();
+        printf("bench %s: %ld blocks of %d in %.4f s = %.1f Msamples/s in, %.1f us per block\n", kind.c_str(), b1 - b0, bs, sec,
+               (double)(b1 - b0) * bs / sec / 1e6, sec / (double)(b1 - b0) * 1e6);
+        delete vfo;
+        delete rs;
+        delete xl;
         return 0;
     }
     if (argc < 5) { fprintf(stderr, "missing arguments\n"); return 2; }

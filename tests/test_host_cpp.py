@@ -237,6 +237,20 @@ def test_graph_math_blocks(harness, data, op):
 
 
 @gpu
+def test_graph_live_bench_modes(harness):
+    """graph_check bench: a free-running SineSource -> VFO -> sink graph (and the same two blocks unfused with a
+    device-resident link) through the block API; the harness prints the rate DESIGN.md quotes."""
+    import re
+    import subprocess
+
+    for kind in ("vfo", "chain"):
+        out = subprocess.run([harness, "bench", kind, "65536", "40", "2400000", "48000"], check=True, capture_output=True,
+                             text=True, timeout=120).stdout
+        m = re.search(r"= ([0-9.]+) Msamples/s in, ([0-9.]+) us per block", out)
+        assert m and float(m.group(1)) > 10.0, out
+
+
+@gpu
 def test_graph_sine_source(harness, tmp_path):
     """SineSource (device NCO) alone, and feeding a FIR through a device-resident link."""
     bs, nb, fs, f = 4096, 8, 48000.0, 1234.0
