@@ -58,6 +58,16 @@ int qdsp_hip_device_count(int* count);
 int qdsp_hip_device_info(int device, char* name, int name_len, char* arch, int arch_len,
                          int* compute_units);
 
+/* Link codes of the *_process_ex / sine generate `*_on_device` arguments (the device-resident companion of
+ * dsp::stream<T>, src/dsp/stream.h:21-125): 0 = host buffer; 1 = device buffer, complete on entry / on return;
+ * QDSP_HIP_LINK_PIPELINED = device buffer on a pipelined link: the call runs on the library's one in-order stream
+ * per device and does not wait for a block it hands to such a link -- the consumer's call runs on the same stream,
+ * behind it.  Valid when both ends launch before they swap / flush the stream<T> (the blocks of
+ * qdsp_amd/host/dsp do).  A host input is always waited for (its buffer is released on return). */
+#define QDSP_HIP_LINK_HOST 0
+#define QDSP_HIP_LINK_DEVICE 1
+#define QDSP_HIP_LINK_PIPELINED 2
+
 /* ---- memory helpers (for hosts that do not link the HIP runtime themselves) ----------- */
 /* Pinned host memory: replaces volk_malloc for stream buffers (src/dsp/stream.h:25-26) so
  * readBuf/writeBuf are DMA-able without staging. */

@@ -11,6 +11,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -67,6 +69,7 @@ struct Engine {
     size_t taps_lm_t_off = 0;    // offset (floats) of the transposed copy used when decim == 1    // core layout (branch-major) or phases [L][P]
     float* d_hist[2] = {nullptr, nullptr};
     int cur = 0;
+    hipStream_t last_stream = nullptr;   // process_ex / generate: the stream of the previous call (its own or the shared one)
     size_t hist_cap = 0;        // samples
     // host-pointer path
     hipStream_t stream = nullptr;
@@ -97,6 +100,55 @@ Engine* as_engine(void* h, Kind k) {
 int env_int(const char* name, int dflt) {
     const char* s = getenv(name);
     return (s && *s) ? atoi(s) : dflt;
+}
+
+// End-of-call wait of the host-pointer paths.  hipStreamSynchronize sleeps on an interrupt (~20 us to wake up),
+// longer than the kernels of a reference-sized block take: poll the stream for a bounded time first
+// (QDSP_HIP_SYNC_SPIN_US, default 200; 0 = always block).
+hipError_t wait_stream(hipStream_t s) {
+    static const int spin_us = env_int("QDSP_HIP_SYNC_SPIN_US", 200);
+    if (spin_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        do {
+            const hipError_t q = hipStreamQuery(s);
+            if (q == hipSuccess) return hipSuccess;
+            if (q != hipErrorNotReady) return q;
+        } while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(spin_us));
+    }
+    return hipStreamSynchronize(s);
+}
+
+// The same for the library's shared stream: wait for THIS call's work only (an event recorded behind it), not for
+// whatever the upstream blocks have queued for later blocks in the meantime.
+hipError_t wait_event(hipEvent_t ev, hipStream_t s) {
+    hipError_t rc = hipEventRecord(ev, s);
+    if (rc != hipSuccess) return rc;
+    static const int spin_us = env_int("QDSP_HIP_SYNC_SPIN_US", 200);
+    if (spin_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        do {
+            const hipError_t q = hipEventQuery(ev);
+            if (q == hipSuccess) return hipSuccess;
+            if (q != hipErrorNotReady) return q;
+        } while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(spin_us));
+    }
+    return hipEventSynchronize(ev);
+}
+
+// One in-order stream per device for "pipelined" device-resident links (QDSP_HIP_LINK_PIPELINED): a producer
+// launches into it and hands its block over without waiting; the consumer launches into the same stream, so
+// the GPU runs the two in launch order -- which is the order the stream<T> protocol imposes on the host threads
+// (the consumer reads a block only after the producer swapped it in, the producer reuses a buffer only after
+// the consumer flushed it, and both launch before they swap / flush).
+hipStream_t shared_stream(int device) {
+    static std::mutex m;
+    static hipStream_t tab[64] = {};
+    std::lock_guard<std::mutex> lk(m);
+    if (device < 0 || device >= 64) return nullptr;
+    if (!tab[device]) {
+        if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&tab[device], hipStreamNonBlocking) != hipSuccess) tab[device] = nullptr;
+    }
+    return tab[device];
 }
 
 long double turns_of(float re, float im) {
@@ -996,8 +1048,18 @@ int64_t process_host(Engine* e, const float* in, int count, float* out) {
     if (nout < 0) return nout;
     if (nout)
         HIPCHK(hipMemcpyAsync(out, e->d_out, (size_t)nout * e->ch * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(wait_stream(e->stream));
     return nout;
+}
+
+// The device address of a pinned host buffer the kernels may store into, or nullptr (pageable memory).  Asked on
+// every call (~1 us): a remembered answer could outlive the buffer it was about.
+void* mapped_host_ptr(void* p) {
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof(at));
+    if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) return at.devicePointer;
+    (void)hipGetLastError();   // (pageable memory: an error the runtime keeps otherwise)
+    return nullptr;
 }
 
 // run() with each side on the host (pinned stream buffer) or already on the device (the
@@ -1009,17 +1071,37 @@ int64_t process_ex(Engine* e, const void* in, int in_dev, int count, void* out, 
         if (rc) return rc;
     }
     HIPCHK(hipSetDevice(e->device));
+    // in_dev / out_dev: 0 host, 1 device (complete / to be complete on return), 2 device through a pipelined link
+    hipStream_t st = e->stream;
+    if (in_dev == QDSP_HIP_LINK_PIPELINED || out_dev == QDSP_HIP_LINK_PIPELINED) {
+        st = shared_stream(e->device);
+        if (!st) return QDSP_HIP_ENOMEM;
+    }
+    if (e->last_stream && e->last_stream != st) HIPCHK(hipStreamSynchronize(e->last_stream));   // (links re-plumbed)
+    e->last_stream = st;
     const void* src = in;
     if (!in_dev) {
-        if (count) HIPCHK(hipMemcpyAsync(e->d_in, in, (size_t)count * e->ch * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        if (count) HIPCHK(hipMemcpyAsync(e->d_in, in, (size_t)count * e->ch * sizeof(float), hipMemcpyHostToDevice, st));
         src = e->d_in;
     }
+    // A small result headed for pinned, device-mapped host memory (a decimator's output in a stream<T> buffer) is
+    // stored there by the kernel itself: posted writes over the link instead of a separate copy operation, which
+    // costs ~10 us of latency per call whatever its size.
     void* dst = out_dev ? out : e->d_out;
-    const int64_t nout = process_dev(e, src, count, dst, e->stream);
+    bool direct_out = false;
+    if (!out_dev && count > 0) {
+        const size_t out_bytes = (size_t)out_size(e, count) * e->ch * sizeof(float);
+        if (out_bytes > 0 && out_bytes <= (size_t)env_int("QDSP_HIP_DIRECT_OUT_MAX_BYTES", 1 << 20)) {
+            void* mapped = mapped_host_ptr(out);
+            if (mapped) { dst = mapped; direct_out = true; }
+        }
+    }
+    const int64_t nout = process_dev(e, src, count, dst, st);
     if (nout < 0) return nout;
-    if (!out_dev && nout)
-        HIPCHK(hipMemcpyAsync(out, e->d_out, (size_t)nout * e->ch * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    if (!out_dev && !direct_out && nout)
+        HIPCHK(hipMemcpyAsync(out, e->d_out, (size_t)nout * e->ch * sizeof(float), hipMemcpyDeviceToHost, st));
+    // a block handed to a pipelined link need not be complete; a host input must have left its buffer, though
+    if (!(out_dev == QDSP_HIP_LINK_PIPELINED && in_dev)) HIPCHK(st == e->stream ? wait_stream(st) : wait_event(e->ev0, st));
     return nout;
 }
 
@@ -1568,12 +1650,19 @@ int qdsp_hip_sine_cf32_generate(void* h, int count, void* out, int out_on_device
         if (rc) return rc;
     }
     HIPCHK(hipSetDevice(e->device));
+    hipStream_t st = e->stream;
+    if (out_on_device == QDSP_HIP_LINK_PIPELINED) {
+        st = shared_stream(e->device);
+        if (!st) return QDSP_HIP_ENOMEM;
+    }
+    if (e->last_stream && e->last_stream != st) HIPCHK(hipStreamSynchronize(e->last_stream));
+    e->last_stream = st;
     void* dst = out_on_device ? out : e->d_out;
-    const int64_t r = process_dev(e, nullptr, count, dst, e->stream);
+    const int64_t r = process_dev(e, nullptr, count, dst, st);
     if (r < 0) return (int)r;
     if (!out_on_device && count)
-        HIPCHK(hipMemcpyAsync(out, e->d_out, (size_t)count * 8, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(hipMemcpyAsync(out, e->d_out, (size_t)count * 8, hipMemcpyDeviceToHost, st));
+    if (out_on_device != QDSP_HIP_LINK_PIPELINED) HIPCHK(wait_stream(st));
     return 0;
 }
 int qdsp_hip_sine_cf32_generate_dev(void* h, int64_t count, void* d_out, void* stream) {
@@ -1721,7 +1810,7 @@ int qdsp_hip_chan_cf32_process(void* h, const float* in, int count, float* out, 
     if (nout)
         HIPCHK(hipMemcpy2DAsync(out, (size_t)out_stride * 8, c->d_out, c->out_cap * 8, (size_t)nout * 8, c->nchan,
                                 hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(wait_stream(c->stream));
     return (int)nout;
 }
 int qdsp_hip_chan_cf32_set_phase_inc(void* h, int chan, float re, float im) {
@@ -1828,7 +1917,7 @@ int qdsp_hip_math_process_ex(void* h, const void* a, int a_dev, const void* b, i
     int rc = math_launch(m, sa, sb, count, dst, m->stream);
     if (rc) return rc;
     if (!out_dev) HIPCHK(hipMemcpyAsync(out, m->d_out, bytes, hipMemcpyDeviceToHost, m->stream));
-    HIPCHK(hipStreamSynchronize(m->stream));
+    HIPCHK(wait_stream(m->stream));
     return 0;
 }
 int qdsp_hip_math_process(void* h, const void* a, const void* b, int count, void* out) {

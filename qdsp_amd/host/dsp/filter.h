@@ -54,6 +54,7 @@ public:
         base::registerInput(_in);
         base::registerOutput(&out);
         _in->consumerTakesDevice = handle != nullptr;
+        _in->consumerPipelined = handle != nullptr;
     }
 
     void setInput(stream<T>* in) {
@@ -61,8 +62,10 @@ public:
         base::tempStop();
         base::unregisterInput(_in);
         _in->consumerTakesDevice = false;
+        _in->consumerPipelined = false;
         _in = in;
         _in->consumerTakesDevice = handle != nullptr;
+        _in->consumerPipelined = handle != nullptr;
         base::registerInput(_in);
         base::tempStart();
     }
@@ -85,11 +88,12 @@ public:
         const bool outDev = out.consumerTakesDevice && out.ensureDevice(detail::hipDeviceForBlocks());
         const void* src = inDev ? static_cast<const void*>(_in->devReadBuf) : static_cast<const void*>(_in->readBuf);
         void* dst = outDev ? static_cast<void*>(out.devWriteBuf) : static_cast<void*>(out.writeBuf);
-        const int rc = kComplex ? qdsp_hip_fir_cf32_process_ex(handle, src, inDev, count, dst, outDev)
-                                : qdsp_hip_fir_f32_process_ex(handle, src, inDev, count, dst, outDev);
+        const int inLink = _in->linkIn(), outLink = out.linkOut(outDev);
+        const int rc = kComplex ? qdsp_hip_fir_cf32_process_ex(handle, src, inLink, count, dst, outLink)
+                                : qdsp_hip_fir_f32_process_ex(handle, src, inLink, count, dst, outLink);
         _in->flush();
         if (rc != 0) { return detail::hipBlockFail("FIR::run", rc); }
-        out.writeOnDevice = outDev;
+        out.markWritten(outLink);
         if (!out.swap(count)) { return -1; }
         return count;
     }

@@ -40,6 +40,7 @@ public:
         base::registerInput(_in);
         base::registerOutput(&out);
         _in->consumerTakesDevice = handle != nullptr;
+        _in->consumerPipelined = handle != nullptr;
     }
 
     // (sic) the reference names its input setter setInputSize (processing.h:26)
@@ -48,8 +49,10 @@ public:
         base::tempStop();
         base::unregisterInput(_in);
         _in->consumerTakesDevice = false;
+        _in->consumerPipelined = false;
         _in = in;
         _in->consumerTakesDevice = handle != nullptr;
+        _in->consumerPipelined = handle != nullptr;
         base::registerInput(_in);
         base::tempStart();
     }
@@ -74,10 +77,11 @@ public:
         const bool outDev = out.consumerTakesDevice && out.ensureDevice(detail::hipDeviceForBlocks());
         const void* src = inDev ? static_cast<const void*>(_in->devReadBuf) : static_cast<const void*>(_in->readBuf);
         void* dst = outDev ? static_cast<void*>(out.devWriteBuf) : static_cast<void*>(out.writeBuf);
-        const int rc = qdsp_hip_xlate_cf32_process_ex(handle, src, inDev, count, dst, outDev);
+        const int outLink = out.linkOut(outDev);
+        const int rc = qdsp_hip_xlate_cf32_process_ex(handle, src, _in->linkIn(), count, dst, outLink);
         _in->flush();
         if (rc != 0) { return detail::hipBlockFail("FrequencyXlator::run", rc); }
-        out.writeOnDevice = outDev;
+        out.markWritten(outLink);
         if (!out.swap(count)) { return -1; }
         return count;
     }

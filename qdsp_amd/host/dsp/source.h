@@ -54,9 +54,10 @@ public:
         if (!handle) { return -1; }
         const bool outDev = out.consumerTakesDevice && out.ensureDevice(detail::hipDeviceForBlocks());
         void* dst = outDev ? static_cast<void*>(out.devWriteBuf) : static_cast<void*>(out.writeBuf);
-        const int rc = qdsp_hip_sine_cf32_generate(handle, _blockSize, dst, outDev);
+        const int outLink = out.linkOut(outDev);
+        const int rc = qdsp_hip_sine_cf32_generate(handle, _blockSize, dst, outLink);
         if (rc != 0) { return detail::hipBlockFail("SineSource::run", rc); }
-        out.writeOnDevice = outDev;
+        out.markWritten(outLink);
         if (!out.swap(_blockSize)) { return -1; }
         return _blockSize;
     }

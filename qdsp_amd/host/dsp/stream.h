@@ -18,7 +18,10 @@
 // stream) leaves its block in devWriteBuf and marks it `writeOnDevice`; after swap() the
 // consumer sees `readOnDevice` and reads devReadBuf: no PCIe round trip between adjacent GPU
 // blocks.  Host blocks never look at these members, so the reference protocol is unchanged.
+// Between two blocks that both launch before they swap / flush (FIR, PolyphaseResampler, FrequencyXlator, VFO,
+// SineSource) the link is "pipelined": see the members at the end of the class.
 #pragma once
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <mutex>
@@ -91,13 +94,15 @@ public:
 
     bool swap(int size) override {
         std::unique_lock<std::mutex> lk(mtx);
-        cv.wait(lk, [this] { return slotFree || writerStopped; });
+        waitFor(lk, [this] { return slotFree || writerStopped; });
         if (writerStopped) { return false; }
         T* t = writeBuf; writeBuf = readBuf; readBuf = t;
         bool p = pinnedW; pinnedW = pinnedR; pinnedR = p;
         t = devWriteBuf; devWriteBuf = devReadBuf; devReadBuf = t;
         readOnDevice = writeOnDevice;
         writeOnDevice = false;
+        readPipelined = writePipelined;
+        writePipelined = false;
         pending = size;
         slotFree = false;
         hasData = true;
@@ -108,7 +113,7 @@ public:
 
     int read() override {
         std::unique_lock<std::mutex> lk(mtx);
-        cv.wait(lk, [this] { return hasData || readerStopped; });
+        waitFor(lk, [this] { return hasData || readerStopped; });
         return readerStopped ? -1 : pending;
     }
 
@@ -135,8 +140,38 @@ public:
     bool writeOnDevice = false;        // producer: the block being swapped in lives in devWriteBuf
     bool readOnDevice = false;         // consumer: the block just read lives in devReadBuf
     bool consumerTakesDevice = false;  // set by a HIP-backed consumer on its input stream
+    // Pipelined link (QDSP_HIP_LINK_PIPELINED, qdsp_hip.h): producer and consumer both launch into the library's
+    // in-order stream before they swap / flush, so the producer does not wait for its kernel and the GPU runs the
+    // two back to back; the host threads only exchange buffers.
+    bool writePipelined = false;       // producer: the block being swapped in may still be in flight on that stream
+    bool readPipelined = false;        // consumer: ... so read it on the same stream
+    bool consumerPipelined = false;    // set by a consumer that launches into that stream before it flushes
+    int linkIn() const { return readOnDevice ? (readPipelined ? QDSP_HIP_LINK_PIPELINED : QDSP_HIP_LINK_DEVICE) : QDSP_HIP_LINK_HOST; }
+    int linkOut(bool outDev) const { return outDev ? (consumerPipelined ? QDSP_HIP_LINK_PIPELINED : QDSP_HIP_LINK_DEVICE) : QDSP_HIP_LINK_HOST; }
+    void markWritten(int link) { writeOnDevice = link != QDSP_HIP_LINK_HOST; writePipelined = link == QDSP_HIP_LINK_PIPELINED; }
 
 private:
+    // A GPU-backed neighbour answers within tens of microseconds, less than a futex sleep and wake-up costs:
+    // poll for a bounded time (QDSP_STREAM_SPIN_US, default 60) before blocking on the condition variable.  Same protocol, same
+    // wake-up conditions as the reference's cv.wait; an idle graph still sleeps.
+    static int spinMicros() {
+        static const int v = [] { const char* e = getenv("QDSP_STREAM_SPIN_US"); return e ? atoi(e) : 60; }();
+        return v;
+    }
+    template <class PRED> void waitFor(std::unique_lock<std::mutex>& lk, PRED pred) {
+        if (pred()) { return; }
+        const int kSpinMicros = spinMicros();
+        if (kSpinMicros <= 0) { cv.wait(lk, pred); return; }
+        const auto t0 = std::chrono::steady_clock::now();
+        do {
+            lk.unlock();
+            for (int i = 0; i < 64; i++) { __asm__ __volatile__("" ::: "memory"); }
+            lk.lock();
+            if (pred()) { return; }
+        } while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(kSpinMicros));
+        cv.wait(lk, pred);
+    }
+
     void setFlag(bool& f, bool v) {
         {
             std::lock_guard<std::mutex> lk(mtx);

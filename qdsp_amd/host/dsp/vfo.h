@@ -42,6 +42,7 @@ public:
         base::registerInput(_in);
         base::registerOutput(&out);
         _in->consumerTakesDevice = handle != nullptr;
+        _in->consumerPipelined = handle != nullptr;
     }
 
     void configure(const std::vector<float>& taps, int interp, int decim) {
@@ -66,10 +67,11 @@ public:
         const bool outDev = out.consumerTakesDevice && out.ensureDevice(hipDeviceForBlocks());
         const void* src = inDev ? static_cast<const void*>(_in->devReadBuf) : static_cast<const void*>(_in->readBuf);
         void* dst = outDev ? static_cast<void*>(out.devWriteBuf) : static_cast<void*>(out.writeBuf);
-        const int outCount = qdsp_hip_xlate_fir_decim_cf32_process_ex(handle, src, inDev, count, dst, outDev);
+        const int outLink = out.linkOut(outDev);
+        const int outCount = qdsp_hip_xlate_fir_decim_cf32_process_ex(handle, src, _in->linkIn(), count, dst, outLink);
         _in->flush();
         if (outCount < 0) { return hipBlockFail("VFO::run", outCount); }
-        out.writeOnDevice = outDev;
+        out.markWritten(outLink);
         if (!out.swap(outCount)) { return -1; }
         return count;
     }
