@@ -81,6 +81,10 @@ int qdsp_hip_dev_free(int device, void* p);
 int qdsp_hip_memcpy_h2d(int device, void* d_dst, const void* h_src, size_t bytes);
 int qdsp_hip_memcpy_d2h(int device, void* h_dst, const void* d_src, size_t bytes);
 int qdsp_hip_memcpy_d2d(int device, void* d_dst, const void* d_src, size_t bytes);
+/* the same for a block that forwards data between links (Splitter, src/dsp/routing.h:47-57): ordered behind a
+ * QDSP_HIP_LINK_PIPELINED source, not waited for when the destination link is pipelined as well */
+int qdsp_hip_memcpy_d2d_link(int device, void* d_dst, const void* d_src, size_t bytes, int in_link, int out_link);
+int qdsp_hip_memcpy_d2h_link(int device, void* h_dst, const void* d_src, size_t bytes, int in_link);
 int qdsp_hip_device_sync(int device);
 
 /* ---- FIR<complex_t> : src/dsp/filter.h:51-74 ------------------------------------------ */

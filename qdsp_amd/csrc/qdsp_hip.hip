@@ -1462,6 +1462,32 @@ int qdsp_hip_memcpy_d2d(int device, void* d_dst, const void* d_src, size_t bytes
     HIPCHK(hipMemcpy(d_dst, d_src, bytes, hipMemcpyDeviceToDevice));
     return 0;
 }
+// Copies for blocks that forward data between links (Splitter): ordered behind a pipelined input, not waited for
+// when the destination link is pipelined too.
+int qdsp_hip_memcpy_d2d_link(int device, void* d_dst, const void* d_src, size_t bytes, int in_link, int out_link) {
+    HIPCHK(hipSetDevice(device));
+    if (in_link != QDSP_HIP_LINK_PIPELINED && out_link != QDSP_HIP_LINK_PIPELINED) {
+        HIPCHK(hipMemcpy(d_dst, d_src, bytes, hipMemcpyDeviceToDevice));
+        return 0;
+    }
+    hipStream_t st = shared_stream(device);
+    if (!st) return QDSP_HIP_ENOMEM;
+    HIPCHK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, st));
+    if (out_link != QDSP_HIP_LINK_PIPELINED) HIPCHK(hipStreamSynchronize(st));
+    return 0;
+}
+int qdsp_hip_memcpy_d2h_link(int device, void* h_dst, const void* d_src, size_t bytes, int in_link) {
+    HIPCHK(hipSetDevice(device));
+    if (in_link != QDSP_HIP_LINK_PIPELINED) {
+        HIPCHK(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+        return 0;
+    }
+    hipStream_t st = shared_stream(device);
+    if (!st) return QDSP_HIP_ENOMEM;
+    HIPCHK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
+}
 int qdsp_hip_device_sync(int device) { HIPCHK(hipSetDevice(device)); HIPCHK(hipDeviceSynchronize()); return 0; }
 
 // ---- filter-bearing operators: FIR, resampler, fused VFO ---------------------------------

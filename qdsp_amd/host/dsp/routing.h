@@ -28,6 +28,7 @@ public:
         _in = in;
         base::registerInput(_in);
         _in->consumerTakesDevice = true;   // it can forward a device-resident block as is
+        _in->consumerPipelined = true;     // ... with copies queued behind the producer's kernel (stream.h)
     }
 
     void setInput(stream<T>* in) {
@@ -35,8 +36,10 @@ public:
         base::tempStop();
         base::unregisterInput(_in);
         _in->consumerTakesDevice = false;
+        _in->consumerPipelined = false;
         _in = in;
         _in->consumerTakesDevice = true;
+        _in->consumerPipelined = true;
         base::registerInput(_in);
         base::tempStart();
     }
@@ -64,21 +67,27 @@ private:
         const int dev = detail::hipDeviceForBlocks();
         const size_t bytes = (size_t)count * sizeof(T);
         bool hostCopyValid = !_in->readOnDevice;
+        const int inLink = _in->linkIn();
         for (stream<T>* s : out) {
             const bool toDev = s->consumerTakesDevice && s->ensureDevice(dev);
-            int rc = 0;
-            if (toDev) {
-                rc = _in->readOnDevice ? qdsp_hip_memcpy_d2d(dev, s->devWriteBuf, _in->devReadBuf, bytes)
-                                       : qdsp_hip_memcpy_h2d(dev, s->devWriteBuf, _in->readBuf, bytes);
+            int rc = 0, outLink = QDSP_HIP_LINK_HOST;
+            if (toDev && _in->readOnDevice) {
+                // device to device; towards a pipelined consumer the copy is only queued (behind the producer's kernel,
+                // ahead of the consumer's), all of them before this block flushes its input
+                outLink = s->linkOut(true);
+                rc = qdsp_hip_memcpy_d2d_link(dev, s->devWriteBuf, _in->devReadBuf, bytes, inLink, outLink);
+            } else if (toDev) {
+                outLink = QDSP_HIP_LINK_DEVICE;
+                rc = qdsp_hip_memcpy_h2d(dev, s->devWriteBuf, _in->readBuf, bytes);
             } else {
                 if (!hostCopyValid) {  // a host consumer behind a device-resident input: one download, reused
-                    rc = qdsp_hip_memcpy_d2h(dev, _in->readBuf, _in->devReadBuf, bytes);
+                    rc = qdsp_hip_memcpy_d2h_link(dev, _in->readBuf, _in->devReadBuf, bytes, inLink);
                     hostCopyValid = rc == 0;
                 }
                 if (rc == 0) { memcpy(s->writeBuf, _in->readBuf, bytes); }
             }
             if (rc != 0) { _in->flush(); return detail::hipBlockFail("Splitter::run", rc); }
-            s->writeOnDevice = toDev;
+            s->markWritten(outLink);
             if (!s->swap(count)) { return -1; }
         }
         _in->flush();

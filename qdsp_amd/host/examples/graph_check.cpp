@@ -18,7 +18,7 @@
 //                      blocks in a row, the two links between them device-resident
 //   graph_check math   <in.cf32> <out.cf32> <block> add|sub|mul <sampleRate> <freq>
 //                      source -> Splitter -> { FrequencyXlator, identity } -> Add | Substract | Multiply -> sink
-//   graph_check bench  vfo|chain <blockSize> <nblocks> <inSR> <outSR>
+//   graph_check bench  vfo|chain|split<n> <blockSize> <nblocks> <inSR> <outSR>
 //                      throughput of a live graph: SineSource -> VFO -> sink, or SineSource -> FrequencyXlator ->
 //                      PolyphaseResampler -> sink (the same two blocks unfused, device-resident link between them);
 //                      prints input Msamples/s and microseconds per block
@@ -273,7 +273,49 @@ int main(int argc, char** argv) {
             xl = new FrequencyXlator<complex_t>(&src.out, inSR, -inSR * 0.1f);
             rs = new PolyphaseResampler<complex_t>(&xl->out, &win, inSR, outSR);
             tail = &rs->out;
-        } else { fprintf(stderr, "bench kind: vfo | chain\n"); return 2; }
+        } else if (kind.rfind("split", 0) == 0) {
+            // SineSource -> Splitter -> n x VFO -> n sinks (the reference's channelizer shape); blocks counted on VFO 0
+            const int n = atoi(kind.c_str() + 5) > 0 ? atoi(kind.c_str() + 5) : 4;
+            Splitter<complex_t> split(&src.out);
+            std::vector<stream<complex_t>*> legs;
+            std::vector<VFO*> vfos;
+            std::vector<HandlerSink<complex_t>*> sinks;
+            Count others;
+            for (int i = 0; i < n; i++) {
+                legs.push_back(new stream<complex_t>());
+                split.bindStream(legs.back());
+                vfos.push_back(new VFO(legs.back(), ((float)i - (float)(n - 1) / 2.0f) * inSR / (float)n * 0.5f, inSR, outSR, outSR));
+                sinks.push_back(new HandlerSink<complex_t>(vfos.back()->out, Count::push, i == 0 ? &cnt : &others));
+            }
+            for (auto* k : sinks) { k->start(); }
+            for (auto* v : vfos) { v->start(); }
+            split.start();
+            src.start();
+            auto wait_blocks = [&](long want) {
+                const auto t0 = std::chrono::steady_clock::now();
+                while (cnt.blocks.load() < want) {
+                    std::this_thread::sleep_for(std::chrono::microseconds(200));
+                    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) { return false; }
+                }
+                return true;
+            };
+            if (!wait_blocks(nb / 10 + 2)) { fprintf(stderr, "bench graph timed out\n"); return 3; }
+            const long b0 = cnt.blocks.load();
+            const auto t0 = std::chrono::steady_clock::now();
+            if (!wait_blocks(b0 + nb)) { fprintf(stderr, "bench graph timed out\n"); return 3; }
+            const long b1 = cnt.blocks.load();
+            const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            src.stop();
+            split.stop();
+            for (auto* v : vfos) { v->stop(); }
+            for (auto* k : sinks) { k->stop(); }
+            printf("bench %s: %ld blocks of %d in %.4f s = %.1f Msamples/s in (x %d channels out), %.1f us per block\n", kind.c_str(), b1 - b0, bs,
+                   sec, (double)(b1 - b0) * bs / sec / 1e6, n, sec / (double)(b1 - b0) * 1e6);
+            for (auto* k : sinks) { delete k; }
+            for (auto* v : vfos) { delete v; }
+            for (auto* l : legs) { delete l; }
+            return 0;
+        } else { fprintf(stderr, "bench kind: vfo | chain | split<n>\n"); return 2; }
         HandlerSink<complex_t> sink(tail, Count::push, &cnt);
         sink.start();
         if (vfo) { vfo->start(); }
