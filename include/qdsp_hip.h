@@ -67,6 +67,14 @@ int qdsp_hip_device_info(int device, char* name, int name_len, char* arch, int a
 #define QDSP_HIP_LINK_HOST 0
 #define QDSP_HIP_LINK_DEVICE 1
 #define QDSP_HIP_LINK_PIPELINED 2
+/* host buffer (pinned), completion deferred to the consumer: the call records the handle's done event
+ * (qdsp_hip_set_done_event) behind its work and returns; whoever reads the buffer waits for that event first
+ * (dsp::stream<T>::read does, the event travels with the buffer through swap()).  Output side only. */
+#define QDSP_HIP_LINK_HOST_DEFERRED 3
+int qdsp_hip_event_create(int device, void** ev);
+int qdsp_hip_event_destroy(void* ev);
+int qdsp_hip_event_wait(void* ev);
+int qdsp_hip_set_done_event(void* handle, void* ev);   /* any FIR / resampler / mixer / VFO / sine handle */
 
 /* ---- memory helpers (for hosts that do not link the HIP runtime themselves) ----------- */
 /* Pinned host memory: replaces volk_malloc for stream buffers (src/dsp/stream.h:25-26) so

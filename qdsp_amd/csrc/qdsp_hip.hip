@@ -70,6 +70,7 @@ struct Engine {
     float* d_hist[2] = {nullptr, nullptr};
     int cur = 0;
     hipStream_t last_stream = nullptr;   // process_ex / generate: the stream of the previous call (its own or the shared one)
+    hipEvent_t done_ev = nullptr;        // QDSP_HIP_LINK_HOST_DEFERRED: recorded behind the call's work instead of waiting for it
     size_t hist_cap = 0;        // samples
     // host-pointer path
     hipStream_t stream = nullptr;
@@ -1087,6 +1088,11 @@ int64_t process_ex(Engine* e, const void* in, int in_dev, int count, void* out, 
     // A small result headed for pinned, device-mapped host memory (a decimator's output in a stream<T> buffer) is
     // stored there by the kernel itself: posted writes over the link instead of a separate copy operation, which
     // costs ~10 us of latency per call whatever its size.
+    const bool deferred = out_dev == QDSP_HIP_LINK_HOST_DEFERRED;
+    if (deferred) {
+        if (!e->done_ev) return QDSP_HIP_EINVAL;
+        out_dev = QDSP_HIP_LINK_HOST;
+    }
     void* dst = out_dev ? out : e->d_out;
     bool direct_out = false;
     if (!out_dev && count > 0) {
@@ -1101,6 +1107,14 @@ int64_t process_ex(Engine* e, const void* in, int in_dev, int count, void* out, 
     if (!out_dev && !direct_out && nout)
         HIPCHK(hipMemcpyAsync(out, e->d_out, (size_t)nout * e->ch * sizeof(float), hipMemcpyDeviceToHost, st));
     // a block handed to a pipelined link need not be complete; a host input must have left its buffer, though
+    if (deferred) {
+        // the consumer waits (stream<T>::read does, on the event that travels with the buffer); only a host INPUT
+        // and a pageable output (whose "async" copy is not) still need this call to wait
+        HIPCHK(hipEventRecord(e->done_ev, st));
+        if (in_dev && (direct_out || nout == 0 || mapped_host_ptr(out))) return nout;
+        HIPCHK(hipEventSynchronize(e->done_ev));
+        return nout;
+    }
     if (!(out_dev == QDSP_HIP_LINK_PIPELINED && in_dev)) HIPCHK(st == e->stream ? wait_stream(st) : wait_event(e->ev0, st));
     return nout;
 }
@@ -1683,11 +1697,22 @@ int qdsp_hip_sine_cf32_generate(void* h, int count, void* out, int out_on_device
     }
     if (e->last_stream && e->last_stream != st) HIPCHK(hipStreamSynchronize(e->last_stream));
     e->last_stream = st;
+    const bool deferred = out_on_device == QDSP_HIP_LINK_HOST_DEFERRED;
+    if (deferred) {
+        if (!e->done_ev) return QDSP_HIP_EINVAL;
+        out_on_device = QDSP_HIP_LINK_HOST;
+    }
     void* dst = out_on_device ? out : e->d_out;
     const int64_t r = process_dev(e, nullptr, count, dst, st);
     if (r < 0) return (int)r;
     if (!out_on_device && count)
         HIPCHK(hipMemcpyAsync(out, e->d_out, (size_t)count * 8, hipMemcpyDeviceToHost, st));
+    if (deferred) {
+        HIPCHK(hipEventRecord(e->done_ev, st));
+        if (count == 0 || mapped_host_ptr(out)) return 0;
+        HIPCHK(hipEventSynchronize(e->done_ev));
+        return 0;
+    }
     if (out_on_device != QDSP_HIP_LINK_PIPELINED) HIPCHK(wait_stream(st));
     return 0;
 }
@@ -1973,6 +1998,42 @@ int qdsp_hip_synth_iq_dev(int device, void* d_out, int64_t first_sample, int64_t
     hipLaunchKernelGGL((qk::synth_iq_kernel<NT>), dim3((unsigned)grid), dim3(NT), 0, static_cast<hipStream_t>(stream),
                        static_cast<float*>(d_out), (long long)first_sample, (long long)count, key);
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// Completion events for QDSP_HIP_LINK_HOST_DEFERRED (the consumer of a host buffer waits, not the producer).
+int qdsp_hip_event_create(int device, void** ev) {
+    if (!ev) return QDSP_HIP_EINVAL;
+    *ev = nullptr;
+    HIPCHK(hipSetDevice(device));
+    hipEvent_t e;
+    HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *ev = e;
+    return 0;
+}
+int qdsp_hip_event_destroy(void* ev) {
+    if (ev) HIPCHK(hipEventDestroy(static_cast<hipEvent_t>(ev)));
+    return 0;
+}
+int qdsp_hip_event_wait(void* ev) {
+    if (!ev) return QDSP_HIP_EINVAL;
+    hipEvent_t e = static_cast<hipEvent_t>(ev);
+    static const int spin_us = env_int("QDSP_HIP_SYNC_SPIN_US", 200);
+    if (spin_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        do {
+            const hipError_t q = hipEventQuery(e);
+            if (q == hipSuccess) return 0;
+            if (q != hipErrorNotReady) return -(int)q;
+        } while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(spin_us));
+    }
+    HIPCHK(hipEventSynchronize(e));
+    return 0;
+}
+int qdsp_hip_set_done_event(void* h, void* ev) {
+    Engine* e = any_engine(h);
+    if (!e) return QDSP_HIP_EINVAL;
+    e->done_ev = static_cast<hipEvent_t>(ev);
     return 0;
 }
 

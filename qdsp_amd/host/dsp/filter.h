@@ -27,6 +27,34 @@ inline int hipBlockFail(const char* who, int rc) {
     fprintf(stderr, "[qdsp_hip] %s: %s (%d)\n", who, qdsp_hip_error_string(rc), rc);
     return -1;
 }
+// Two completion events, used in turn, for a block whose output goes to a host consumer: the block hands the
+// host buffer over with its kernel possibly still running and stream<T>::read() on the consumer's side waits
+// (QDSP_HIP_LINK_HOST_DEFERRED).  Two suffice: a stream holds one block in flight, and the consumer has waited
+// for an event before the producer can swap twice more.  QDSP_HIP_NO_DEFERRED_HOST=1: wait in the producer.
+struct done_events {
+    void* ev[2] = {nullptr, nullptr};
+    int k = 0;
+    bool off = false;
+    ~done_events() {
+        for (void* e : ev) { if (e) { qdsp_hip_event_destroy(e); } }
+    }
+    // the link code for a host output of `handle`, and the event to pass to markWritten()
+    int arm(void* handle, void*& evt) {
+        evt = nullptr;
+        if (off) { return QDSP_HIP_LINK_HOST; }
+        if (!ev[0]) {
+            const char* no = getenv("QDSP_HIP_NO_DEFERRED_HOST");
+            if ((no && atoi(no)) || qdsp_hip_event_create(hipDeviceForBlocks(), &ev[0]) != 0 || qdsp_hip_event_create(hipDeviceForBlocks(), &ev[1]) != 0) {
+                off = true;
+                return QDSP_HIP_LINK_HOST;
+            }
+        }
+        k ^= 1;
+        if (qdsp_hip_set_done_event(handle, ev[k]) != 0) { return QDSP_HIP_LINK_HOST; }
+        evt = ev[k];
+        return QDSP_HIP_LINK_HOST_DEFERRED;
+    }
+};
 }  // namespace detail
 
 template <class T>
@@ -88,12 +116,13 @@ public:
         const bool outDev = out.consumerTakesDevice && out.ensureDevice(detail::hipDeviceForBlocks());
         const void* src = inDev ? static_cast<const void*>(_in->devReadBuf) : static_cast<const void*>(_in->readBuf);
         void* dst = outDev ? static_cast<void*>(out.devWriteBuf) : static_cast<void*>(out.writeBuf);
-        const int inLink = _in->linkIn(), outLink = out.linkOut(outDev);
+        void* evt = nullptr;
+        const int inLink = _in->linkIn(), outLink = outDev ? out.linkOut(true) : done.arm(handle, evt);
         const int rc = kComplex ? qdsp_hip_fir_cf32_process_ex(handle, src, inLink, count, dst, outLink)
                                 : qdsp_hip_fir_f32_process_ex(handle, src, inLink, count, dst, outLink);
         _in->flush();
         if (rc != 0) { return detail::hipBlockFail("FIR::run", rc); }
-        out.markWritten(outLink);
+        out.markWritten(outLink, evt);
         if (!out.swap(count)) { return -1; }
         return count;
     }
@@ -113,6 +142,7 @@ private:
     dsp::filter_window::generic_window* _window = nullptr;
     std::vector<float> taps;
     void* handle = nullptr;
+    detail::done_events done;
 };
 
 }  // namespace dsp

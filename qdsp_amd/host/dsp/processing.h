@@ -77,11 +77,12 @@ public:
         const bool outDev = out.consumerTakesDevice && out.ensureDevice(detail::hipDeviceForBlocks());
         const void* src = inDev ? static_cast<const void*>(_in->devReadBuf) : static_cast<const void*>(_in->readBuf);
         void* dst = outDev ? static_cast<void*>(out.devWriteBuf) : static_cast<void*>(out.writeBuf);
-        const int outLink = out.linkOut(outDev);
+        void* evt = nullptr;
+        const int outLink = outDev ? out.linkOut(true) : done.arm(handle, evt);
         const int rc = qdsp_hip_xlate_cf32_process_ex(handle, src, _in->linkIn(), count, dst, outLink);
         _in->flush();
         if (rc != 0) { return detail::hipBlockFail("FrequencyXlator::run", rc); }
-        out.markWritten(outLink);
+        out.markWritten(outLink, evt);
         if (!out.swap(count)) { return -1; }
         return count;
     }
@@ -105,6 +106,7 @@ private:
     float deltaRe = 1.0f, deltaIm = 0.0f;
     stream<complex_t>* _in = nullptr;
     void* handle = nullptr;
+    detail::done_events done;
 };
 
 }  // namespace dsp

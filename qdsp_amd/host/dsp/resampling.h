@@ -106,12 +106,13 @@ public:
         const bool outDev = out.consumerTakesDevice && out.ensureDevice(detail::hipDeviceForBlocks());
         const void* src = inDev ? static_cast<const void*>(_in->devReadBuf) : static_cast<const void*>(_in->readBuf);
         void* dst = outDev ? static_cast<void*>(out.devWriteBuf) : static_cast<void*>(out.writeBuf);
-        const int inLink = _in->linkIn(), outLink = out.linkOut(outDev);
+        void* evt = nullptr;
+        const int inLink = _in->linkIn(), outLink = outDev ? out.linkOut(true) : done.arm(handle, evt);
         const int outCount = kPair ? qdsp_hip_decim_cf32_process_ex(handle, src, inLink, count, dst, outLink)
                                    : qdsp_hip_decim_f32_process_ex(handle, src, inLink, count, dst, outLink);
         _in->flush();
         if (outCount < 0) { return detail::hipBlockFail("PolyphaseResampler::run", outCount); }
-        out.markWritten(outLink);
+        out.markWritten(outLink, evt);
         if (!out.swap(outCount)) { return -1; }
         return count;
     }
@@ -145,6 +146,7 @@ private:
     float _inSampleRate = 1.0f, _outSampleRate = 1.0f;
     std::vector<float> taps;
     void* handle = nullptr;
+    detail::done_events done;
 };
 
 }  // namespace dsp

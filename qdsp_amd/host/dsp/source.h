@@ -54,10 +54,11 @@ public:
         if (!handle) { return -1; }
         const bool outDev = out.consumerTakesDevice && out.ensureDevice(detail::hipDeviceForBlocks());
         void* dst = outDev ? static_cast<void*>(out.devWriteBuf) : static_cast<void*>(out.writeBuf);
-        const int outLink = out.linkOut(outDev);
+        void* evt = nullptr;
+        const int outLink = outDev ? out.linkOut(true) : done.arm(handle, evt);
         const int rc = qdsp_hip_sine_cf32_generate(handle, _blockSize, dst, outLink);
         if (rc != 0) { return detail::hipBlockFail("SineSource::run", rc); }
-        out.markWritten(outLink);
+        out.markWritten(outLink, evt);
         if (!out.swap(_blockSize)) { return -1; }
         return _blockSize;
     }
@@ -81,6 +82,7 @@ private:
     int _blockSize = 0;
     float _sampleRate = 1.0f, _freq = 0.0f;
     void* handle = nullptr;
+    detail::done_events done;
 };
 
 template <class T>

@@ -103,6 +103,8 @@ public:
         writeOnDevice = false;
         readPipelined = writePipelined;
         writePipelined = false;
+        readDoneEvt = writeDoneEvt;
+        writeDoneEvt = nullptr;
         pending = size;
         slotFree = false;
         hasData = true;
@@ -114,7 +116,15 @@ public:
     int read() override {
         std::unique_lock<std::mutex> lk(mtx);
         waitFor(lk, [this] { return hasData || readerStopped; });
-        return readerStopped ? -1 : pending;
+        if (readerStopped) { return -1; }
+        const int n = pending;
+        void* evt = readDoneEvt;
+        readDoneEvt = nullptr;
+        lk.unlock();
+        // a GPU producer may have handed the block over with its kernel still running (QDSP_HIP_LINK_HOST_DEFERRED):
+        // the buffer is the consumer's only once that event has fired
+        if (evt) { (void)qdsp_hip_event_wait(evt); }
+        return n;
     }
 
     void flush() override {
@@ -148,7 +158,14 @@ public:
     bool consumerPipelined = false;    // set by a consumer that launches into that stream before it flushes
     int linkIn() const { return readOnDevice ? (readPipelined ? QDSP_HIP_LINK_PIPELINED : QDSP_HIP_LINK_DEVICE) : QDSP_HIP_LINK_HOST; }
     int linkOut(bool outDev) const { return outDev ? (consumerPipelined ? QDSP_HIP_LINK_PIPELINED : QDSP_HIP_LINK_DEVICE) : QDSP_HIP_LINK_HOST; }
-    void markWritten(int link) { writeOnDevice = link != QDSP_HIP_LINK_HOST; writePipelined = link == QDSP_HIP_LINK_PIPELINED; }
+    void markWritten(int link, void* doneEvt = nullptr) {
+        writeOnDevice = link == QDSP_HIP_LINK_DEVICE || link == QDSP_HIP_LINK_PIPELINED;
+        writePipelined = link == QDSP_HIP_LINK_PIPELINED;
+        writeDoneEvt = link == QDSP_HIP_LINK_HOST_DEFERRED ? doneEvt : nullptr;
+    }
+    // Deferred completion of a host block: set by the producer, waited for inside read()
+    void* writeDoneEvt = nullptr;
+    void* readDoneEvt = nullptr;
 
 private:
     // A GPU-backed neighbour answers within tens of microseconds, less than a futex sleep and wake-up costs:

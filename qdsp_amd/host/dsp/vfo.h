@@ -67,11 +67,12 @@ public:
         const bool outDev = out.consumerTakesDevice && out.ensureDevice(hipDeviceForBlocks());
         const void* src = inDev ? static_cast<const void*>(_in->devReadBuf) : static_cast<const void*>(_in->readBuf);
         void* dst = outDev ? static_cast<void*>(out.devWriteBuf) : static_cast<void*>(out.writeBuf);
-        const int outLink = out.linkOut(outDev);
+        void* evt = nullptr;
+        const int outLink = outDev ? out.linkOut(true) : done.arm(handle, evt);
         const int outCount = qdsp_hip_xlate_fir_decim_cf32_process_ex(handle, src, _in->linkIn(), count, dst, outLink);
         _in->flush();
         if (outCount < 0) { return hipBlockFail("VFO::run", outCount); }
-        out.markWritten(outLink);
+        out.markWritten(outLink, evt);
         if (!out.swap(outCount)) { return -1; }
         return count;
     }
@@ -81,6 +82,7 @@ public:
 private:
     stream<complex_t>* _in = nullptr;
     void* handle = nullptr;
+    detail::done_events done;
 };
 }  // namespace detail
 
