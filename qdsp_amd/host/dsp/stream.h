@@ -19,7 +19,9 @@
 // consumer sees `readOnDevice` and reads devReadBuf: no PCIe round trip between adjacent GPU
 // blocks.  Host blocks never look at these members, so the reference protocol is unchanged.
 // Between two blocks that both launch before they swap / flush (FIR, PolyphaseResampler, FrequencyXlator, VFO,
-// SineSource) the link is "pipelined": see the members at the end of the class.
+// SineSource, Splitter) the link is "pipelined": see the members at the end of the class.  Towards a host
+// consumer a HIP-backed producer may swap a block in while its kernel is still running; the completion event it
+// recorded travels with the buffer and read() waits for it, so a consumer never sees an unfinished block.
 #pragma once
 #include <chrono>
 #include <condition_variable>
