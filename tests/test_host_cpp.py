@@ -193,6 +193,36 @@ def test_graph_device_resident_chain(harness, data):
 
 
 @gpu
+def test_graph_many_small_blocks_through_pipelined_links(harness, data):
+    """The same three-block chain and the Splitter fan-out fed hundreds of small blocks back to back: every
+    hand-over between the GPU blocks is a pipelined link (nobody waits for a kernel), the last block leaves the
+    wait to the sink's read().  A missed ordering -- a buffer read before it was written, or reused before it was
+    read -- shows up as a wrong block."""
+    d, x = data
+    taps = O.lowpass_taps_f64(128, 0.2)
+    taps.tofile(d / "t128b.f32")
+    b = 1_000
+    run([harness, "chain", str(d / "x.cf32"), str(d / "ycs.cf32"), str(b), str(d / "t128b.f32"), "48000", "-5000", "48000", "12000"])
+    y = np.fromfile(d / "ycs.cf32", dtype=np.complex64)
+    xl = O.Xlator(48000.0, -5000.0, exact=True, volk_gain=True)
+    fir = O.Fir(taps, acc=O.ACC_F64)
+    L, M = O.resamp_ratio(48000.0, 12000.0)
+    n = O.blackman_tap_count(6000.0, 6000.0, 48000.0)
+    rs = O.Resampler(O.blackman_taps(6000.0, 48000.0, n, factor=float(L)), L, M, acc=O.ACC_F64)
+    want = np.concatenate([rs.process(fir.process(xl.process(x[i:i + b]))) for i in range(0, len(x), b)])
+    assert len(x) // b >= 100 and len(y) == len(want) and rel_rms(y, want) < 3e-6
+    nv = 4
+    b = 2_000
+    run([harness, "split", str(d / "x.cf32"), str(d / "yss"), str(b), str(nv), "2400000", "240000", "200000"])
+    for i in range(nv):
+        y = np.fromfile(str(d / "yss") + f".{i}.cf32", dtype=np.complex64)
+        off = np.float32((np.float32(i) - np.float32(nv - 1) / np.float32(2.0)) * np.float32(2.4e6) / np.float32(nv))
+        v = O.Vfo(float(off), 2.4e6, 240e3, 200e3, exact_nco=True, volk_gain=True)
+        want = np.concatenate([v.process(x[j:j + b]) for j in range(0, len(x), b)])
+        assert len(y) == len(want) and rel_rms(y, want) < 3e-6, i
+
+
+@gpu
 def test_graph_splitter_to_vfos(harness, data):
     """source -> Splitter -> 4 x VFO -> sinks (the channelizer shape of the reference)."""
     d, x = data
