@@ -136,6 +136,10 @@ hipError_t wait_event(hipEvent_t ev, hipStream_t s) {
     return hipEventSynchronize(ev);
 }
 
+// (Ordering the two ends of a link with events instead -- every handle on its own stream, two events per device
+// buffer of the stream<T>, hipStreamWaitEvent before and hipEventRecord behind each kernel -- was built and
+// measured: the cross-stream dependencies cost more than the serialisation they remove; SineSource -> VFO 23 -> 27 us
+// per block, Splitter -> 4 / 16 x VFO 80 -> 120 / 386 -> 615 us.)
 // One in-order stream per device for "pipelined" device-resident links (QDSP_HIP_LINK_PIPELINED): a producer
 // launches into it and hands its block over without waiting; the consumer launches into the same stream, so
 // the GPU runs the two in launch order -- which is the order the stream<T> protocol imposes on the host threads
@@ -1111,11 +1115,14 @@ int64_t process_ex(Engine* e, const void* in, int in_dev, int count, void* out, 
         // the consumer waits (stream<T>::read does, on the event that travels with the buffer); only a host INPUT
         // and a pageable output (whose "async" copy is not) still need this call to wait
         HIPCHK(hipEventRecord(e->done_ev, st));
-        if (in_dev && (direct_out || nout == 0 || mapped_host_ptr(out))) return nout;
+        // (a device input from a producer outside the shared stream must have been read before this call returns
+        // and the block flushes it: only a pipelined input lets the call go without waiting)
+        if (in_dev == QDSP_HIP_LINK_PIPELINED && (direct_out || nout == 0 || mapped_host_ptr(out))) return nout;
         HIPCHK(hipEventSynchronize(e->done_ev));
         return nout;
     }
-    if (!(out_dev == QDSP_HIP_LINK_PIPELINED && in_dev)) HIPCHK(st == e->stream ? wait_stream(st) : wait_event(e->ev0, st));
+    if (!(out_dev == QDSP_HIP_LINK_PIPELINED && in_dev == QDSP_HIP_LINK_PIPELINED))
+        HIPCHK(st == e->stream ? wait_stream(st) : wait_event(e->ev0, st));
     return nout;
 }
 
