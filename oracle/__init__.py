@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libqdsp_oracle.so")
 
-ACC_F32, ACC_FMA, ACC_F64 = 0, 1, 2
+ACC_F32, ACC_FMA, ACC_F64, ACC_SIMD = 0, 1, 2, 3   # ACC_SIMD: lane-partial sums + FMA, the shape of VOLK's SIMD kernels
 
 _lib = None
 

@@ -49,7 +49,14 @@
 #define ORACLE_HOT
 #endif
 
-enum { ORACLE_ACC_F32 = 0, ORACLE_ACC_FMA = 1, ORACLE_ACC_F64 = 2 };
+enum { ORACLE_ACC_F32 = 0, ORACLE_ACC_FMA = 1, ORACLE_ACC_F64 = 2, ORACLE_ACC_SIMD = 3 };
+
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(QDSP_ORACLE_NO_CLONES)
+/* clones that may use FMA instructions (AVX-512F implies FMA3; "fma" = the AVX/FMA3 machines) */
+#define ORACLE_HOT_FMA __attribute__((target_clones("avx512f", "fma", "default")))
+#else
+#define ORACLE_HOT_FMA
+#endif
 
 /* ------------------------------------------------------------------------------------ */
 /* dot products                                                                          */
@@ -93,6 +100,65 @@ ORACLE_HOT static void dot_rows_f32(const float* x, const float* taps, int ntaps
         }
         for (long j = 0; j < m; j++) y[i0 + j] = a[j];
     }
+}
+
+/* ORACLE_ACC_SIMD: the shape of VOLK's SIMD dot-product kernels (volk_32fc_32f_dot_prod_32fc_a_avx /
+ * _avx512f and friends, called at filter.h:65, resampling.h:123): ONE output at a time, the tap loop
+ * vectorised -- SIMD_LANES float lanes of partial sums (8 complex samples per 512-bit vector, every tap
+ * duplicated over a sample's re and im lanes), one fused multiply-add per lane and vector, a horizontal
+ * add at the end.  The rounding differs from the generic order (lane-partial sums, fused products), which
+ * is what a real VOLK build on an AVX machine returns; it is the `value_simd` figure of bench.py's CPU
+ * baseline and is checked against the FP64 oracle like every other order.
+ * `taps2` = the taps duplicated (t0,t0,t1,t1,...), 2*ntaps floats; x = interleaved complex window. */
+#define SIMD_LANES 64 /* four 16-float vectors in flight (VOLK's kernels unroll by four): hides the FMA latency */
+#define SIMD_TAIL 16  /* then single vectors, then a scalar tail */
+#define DOT_LANES_BODY(N2, XP, TP, RE, IM, CPLX)                                                              \
+    {                                                                                                         \
+        const int nv_ = (N2) / SIMD_LANES * SIMD_LANES, nt_ = (N2) / SIMD_TAIL * SIMD_TAIL;                   \
+        float acc_[SIMD_LANES], act_[SIMD_TAIL];                                                              \
+        for (int j = 0; j < SIMD_LANES; j++) acc_[j] = 0.0f;                                                  \
+        for (int j = 0; j < SIMD_TAIL; j++) act_[j] = 0.0f;                                                   \
+        for (int k = 0; k < nv_; k += SIMD_LANES)                                                             \
+            for (int j = 0; j < SIMD_LANES; j++) acc_[j] = fmaf((XP)[k + j], (TP)[k + j], acc_[j]);           \
+        for (int k = nv_; k < nt_; k += SIMD_TAIL)                                                            \
+            for (int j = 0; j < SIMD_TAIL; j++) act_[j] = fmaf((XP)[k + j], (TP)[k + j], act_[j]);            \
+        for (int j = 0; j < SIMD_TAIL; j++) act_[j] += (acc_[j] + acc_[j + 16]) + (acc_[j + 32] + acc_[j + 48]); \
+        /* horizontal add as a tree that keeps re / im lane parity (offsets 8, 4, 2 are even) */              \
+        float t8_[8], t4_[4];                                                                                 \
+        for (int j = 0; j < 8; j++) t8_[j] = act_[j] + act_[j + 8];                                           \
+        for (int j = 0; j < 4; j++) t4_[j] = t8_[j] + t8_[j + 4];                                             \
+        RE = t4_[0] + t4_[2];                                                                                 \
+        IM = t4_[1] + t4_[3];                                                                                 \
+        if (CPLX) {                                                                                           \
+            for (int k = nt_; k < (N2); k += 2) { RE = fmaf((XP)[k], (TP)[k], RE); IM = fmaf((XP)[k + 1], (TP)[k + 1], IM); } \
+        } else {                                                                                              \
+            RE += IM;                                                                                         \
+            for (int k = nt_; k < (N2); k++) RE = fmaf((XP)[k], (TP)[k], RE);                                 \
+        }                                                                                                     \
+    }
+ORACLE_HOT_FMA static void dot_lanes_cf32_rows(const float* x, const float* taps2, int ntaps, long n, long step, float* y) {
+    const int n2 = 2 * ntaps;
+    for (long i = 0; i < n; i++) {
+        const float* xp = x + 2 * i * step;
+        float re, im;
+        DOT_LANES_BODY(n2, xp, taps2, re, im, 1)
+        y[2 * i] = re;
+        y[2 * i + 1] = im;
+    }
+}
+ORACLE_HOT_FMA static void dot_lanes_f32_rows(const float* x, const float* taps, int ntaps, long n, long step, float* y) {
+    for (long i = 0; i < n; i++) {
+        const float* xp = x + i * step;
+        float a, unused;
+        DOT_LANES_BODY(ntaps, xp, taps, a, unused, 0)
+        (void)unused;
+        y[i] = a;
+    }
+}
+static float* dup_taps(const float* taps, int ntaps) {
+    float* t2 = (float*)malloc((size_t)2 * ntaps * sizeof(float) + 64);
+    if (t2) for (int k = 0; k < ntaps; k++) { t2[2 * k] = taps[k]; t2[2 * k + 1] = taps[k]; }
+    return t2;
 }
 
 /* Single dot product with a selectable accumulator (used where the window start and the
@@ -149,6 +215,13 @@ static long fir_block(const float* taps, int ntaps, float* hist, const float* in
     if (acc == ORACLE_ACC_F32) {
         if (ch == 2) dot_rows_cf32(buffer + 2, taps, ntaps, count, 1, out);
         else dot_rows_f32(buffer + 1, taps, ntaps, count, 1, out);
+    } else if (acc == ORACLE_ACC_SIMD) {
+        if (ch == 2) {
+            float* t2 = dup_taps(taps, ntaps);
+            if (!t2) { free(buffer); return -2; }
+            dot_lanes_cf32_rows(buffer + 2, t2, ntaps, count, 1, out);
+            free(t2);
+        } else dot_lanes_f32_rows(buffer + 1, taps, ntaps, count, 1, out);
     } else {
         for (long i = 0; i < count; i++)
             dot_one(buffer + (size_t)(i + 1) * ch, taps, ntaps, ch, acc, out + (size_t)i * ch);
@@ -233,6 +306,17 @@ static long resamp_block(const float* taps, int ntaps, int interp, int decim, fl
     if (interp == 1 && acc == ORACLE_ACC_F32) {
         if (ch == 2) dot_rows_cf32(buffer, phases, tpp, outCount, decim, out);
         else dot_rows_f32(buffer, phases, tpp, outCount, decim, out);
+    } else if (acc == ORACLE_ACC_SIMD) {
+        /* one output at a time, window start and phase per output (resampling.h:121-125) */
+        float* t2 = ch == 2 ? dup_taps(phases, interp * tpp) : NULL;
+        if (ch == 2 && !t2) { free(phases); free(buffer); return -2; }
+        long i = 0;
+        for (long o = 0; o < outCount; o++, i += decim) {
+            int phase = (int)(i % interp);
+            if (ch == 2) dot_lanes_cf32_rows(buffer + (size_t)(i / interp) * 2, t2 + (size_t)phase * tpp * 2, tpp, 1, 1, out + (size_t)o * 2);
+            else dot_lanes_f32_rows(buffer + (size_t)(i / interp), phases + (size_t)phase * tpp, tpp, 1, 1, out + (size_t)o);
+        }
+        free(t2);
     } else {
         long i = 0;
         for (long o = 0; o < outCount; o++, i += decim) {

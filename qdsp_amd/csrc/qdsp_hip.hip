@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <new>
@@ -87,6 +88,10 @@ struct Engine {
     int fft_ntaps = -1;         // tap count d_fft_H was built for (-1: not built)
     unsigned long long fft_dphase = 0;   // NCO increment d_fft_H was built for (fused VFO), 0 otherwise
     std::vector<float> taps_host;
+    // A retune (set_phase_inc) may come from a control thread while the worker is inside process*: the new
+    // increment is staged here as the two float bit patterns (0 = nothing staged: a zero increment is refused)
+    // and applied by whoever next enters a call that reads the NCO state (apply_pending_inc).
+    std::atomic<unsigned long long> pending_inc{0};
     // tuning / introspection
     int R = 0, NT = 0;          // 0 = pick automatically
     Launch last;
@@ -311,13 +316,30 @@ int configure(Engine* e, const float* taps, int ntaps, int interp, int decim) {
     return 0;
 }
 
-void set_inc(Engine* e, float re, float im) {
+void set_inc_now(Engine* e, float re, float im) {
     e->raw_valid = false;   // (a retune: the rotated history stays the truth, see launch_fft)
     e->inc_re = re;
     e->inc_im = im;
     e->dturns = turns_of(re, im);
     e->dphase = fx_of_turns(e->dturns);
     e->gm1 = (float)(hypotl((long double)re, (long double)im) - 1.0L);
+}
+
+// setters: stage the increment; the worker thread applies it between two calls, never in the middle of one
+void set_inc(Engine* e, float re, float im) {
+    unsigned int a, b;
+    memcpy(&a, &re, 4);
+    memcpy(&b, &im, 4);
+    e->pending_inc.store(((unsigned long long)a << 32) | b, std::memory_order_release);
+}
+void apply_pending_inc(Engine* e) {
+    const unsigned long long v = e->pending_inc.exchange(0ULL, std::memory_order_acq_rel);
+    if (!v) return;
+    const unsigned int a = (unsigned int)(v >> 32), b = (unsigned int)v;
+    float re, im;
+    memcpy(&re, &a, 4);
+    memcpy(&im, &b, 4);
+    set_inc_now(e, re, im);
 }
 
 int ensure_io(Engine* e, int max_block) {
@@ -973,6 +995,7 @@ int launch_xlate_inc(Engine* e, const void* d_in, int64_t count, void* d_out, un
 // One run() worth of work on device pointers.  Returns the output count.
 int64_t process_dev(Engine* e, const void* d_in, int64_t count, void* d_out, void* stream) {
     if (count < 0 || (count > 0 && ((!d_in && e->kind != KIND_SINE) || !d_out))) return QDSP_HIP_EINVAL;
+    apply_pending_inc(e);
     HIPCHK(hipSetDevice(e->device));
     hipStream_t s = static_cast<hipStream_t>(stream);  // NULL == HIP's default stream
     const int64_t nout = out_size(e, count);
@@ -1071,7 +1094,10 @@ void* mapped_host_ptr(void* p) {
 // device-resident companion of a stream): copies only where a side is on the host.
 int64_t process_ex(Engine* e, const void* in, int in_dev, int count, void* out, int out_dev) {
     if (count < 0 || (count > 0 && (!in || !out))) return QDSP_HIP_EINVAL;
-    if ((!in_dev || !out_dev) && count > e->max_block) {
+    // (a deferred host output is a host output: it goes through the staging buffer unless the kernel can store
+    // straight into the pinned buffer)
+    const bool out_host = out_dev == QDSP_HIP_LINK_HOST || out_dev == QDSP_HIP_LINK_HOST_DEFERRED;
+    if ((!in_dev || out_host) && count > e->max_block) {
         int rc = ensure_io(e, count);
         if (rc) return rc;
     }
@@ -1159,6 +1185,7 @@ int set_history(Engine* e, const float* hist) {
 // those samples are rotated here with the phases they would have had: phase - H*dphase onward.
 int set_history_dev(Engine* e, const void* d_hist, void* stream) {
     if (!d_hist) return QDSP_HIP_EINVAL;
+    apply_pending_inc(e);
     e->raw_valid = false;
     HIPCHK(hipSetDevice(e->device));
     if (e->H <= 0) return 0;
@@ -1348,6 +1375,7 @@ int chan_launch_uniform(Chan* c, const void* d_in, int64_t count, int64_t nout, 
 
 int64_t chan_process_dev(Chan* c, const void* d_in, int64_t count, void* d_out, int64_t out_stride, void* stream) {
     if (count < 0 || c->vfo.empty()) return QDSP_HIP_EINVAL;
+    for (Engine* e : c->vfo) apply_pending_inc(e);
     const int64_t nout = out_size(c->vfo[0], count);
     if (out_stride < nout) return QDSP_HIP_EINVAL;
     {
@@ -1494,7 +1522,11 @@ int qdsp_hip_memcpy_d2d_link(int device, void* d_dst, const void* d_src, size_t 
     hipStream_t st = shared_stream(device);
     if (!st) return QDSP_HIP_ENOMEM;
     HIPCHK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, st));
-    if (out_link != QDSP_HIP_LINK_PIPELINED) HIPCHK(hipStreamSynchronize(st));
+    // Only a pipelined INPUT may be released with the copy still queued (its producer launches into this same
+    // stream, behind the copy).  A plain device input comes from a producer on some other stream (Add / Multiply,
+    // a host-fed Splitter): it reuses the buffer two blocks later whatever this stream has got to, so the copy
+    // must have read it before the caller flushes.
+    if (!(in_link == QDSP_HIP_LINK_PIPELINED && out_link == QDSP_HIP_LINK_PIPELINED)) HIPCHK(hipStreamSynchronize(st));
     return 0;
 }
 int qdsp_hip_memcpy_d2h_link(int device, void* h_dst, const void* d_src, size_t bytes, int in_link) {
@@ -1626,7 +1658,7 @@ int qdsp_hip_xlate_cf32_create(void** h, int device, float inc_re, float inc_im,
     int rc = create(h, KIND_XLATE, device, 2, true, false, max_block);
     if (rc) return rc;
     Engine* e = static_cast<Engine*>(*h);
-    set_inc(e, inc_re, inc_im);
+    set_inc_now(e, inc_re, inc_im);
     rc = ensure_io(e, max_block);
     if (rc) { destroy(e); *h = nullptr; }
     return rc;
@@ -1666,6 +1698,7 @@ int qdsp_hip_xlate_cf32_set_phase(void* h, float re, float im) {
 int qdsp_hip_xlate_cf32_advance(void* h, int64_t n) {
     Engine* e = as_engine(h, KIND_XLATE);
     if (!e) return QDSP_HIP_EINVAL;
+    apply_pending_inc(e);
     e->phase += (unsigned long long)n * e->dphase;
     e->raw_valid = false;
     return 0;
@@ -1684,7 +1717,7 @@ int qdsp_hip_sine_cf32_create(void** h, int device, float inc_re, float inc_im, 
     int rc = create(h, KIND_SINE, device, 2, true, false, max_block);
     if (rc) return rc;
     Engine* e = static_cast<Engine*>(*h);
-    set_inc(e, inc_re, inc_im);
+    set_inc_now(e, inc_re, inc_im);
     rc = ensure_io(e, max_block);
     if (rc) { destroy(e); *h = nullptr; }
     return rc;
@@ -1692,7 +1725,7 @@ int qdsp_hip_sine_cf32_create(void** h, int device, float inc_re, float inc_im, 
 int qdsp_hip_sine_cf32_generate(void* h, int count, void* out, int out_on_device) {
     Engine* e = as_engine(h, KIND_SINE);
     if (!e || count < 0 || (count > 0 && !out)) return QDSP_HIP_EINVAL;
-    if (!out_on_device && count > e->max_block) {
+    if ((out_on_device == QDSP_HIP_LINK_HOST || out_on_device == QDSP_HIP_LINK_HOST_DEFERRED) && count > e->max_block) {
         int rc = ensure_io(e, count);
         if (rc) return rc;
     }
@@ -1754,7 +1787,7 @@ int qdsp_hip_xlate_fir_decim_cf32_create(void** h, int device, const float* taps
     int rc = create(h, KIND_VFO, device, 2, true, true, max_block);
     if (rc) return rc;
     Engine* e = static_cast<Engine*>(*h);
-    set_inc(e, inc_re, inc_im);
+    set_inc_now(e, inc_re, inc_im);
     rc = configure(e, taps, ntaps, interp, decim);
     if (!rc) rc = ensure_io(e, max_block);
     if (rc) { destroy(e); *h = nullptr; }
@@ -1796,6 +1829,7 @@ int qdsp_hip_xlate_fir_decim_cf32_set_phase(void* h, float re, float im) {
 int qdsp_hip_xlate_fir_decim_cf32_advance(void* h, int64_t n) {
     Engine* e = as_engine(h, KIND_VFO);
     if (!e) return QDSP_HIP_EINVAL;
+    apply_pending_inc(e);
     e->phase += (unsigned long long)n * e->dphase;
     e->raw_valid = false;
     return 0;
@@ -1907,6 +1941,7 @@ int qdsp_hip_chan_cf32_history_len(void* h) {
 int qdsp_hip_chan_cf32_set_history_dev(void* h, const void* d_hist, void* s) {
     Chan* c = as_chan(h);
     if (!c || !d_hist) return QDSP_HIP_EINVAL;
+    for (Engine* e : c->vfo) apply_pending_inc(e);
     HIPCHK(hipSetDevice(c->device));
     int inv;
     long long dd[64];
@@ -1925,7 +1960,7 @@ int qdsp_hip_chan_cf32_set_history_dev(void* h, const void* d_hist, void* s) {
 int qdsp_hip_chan_cf32_advance(void* h, int64_t n) {
     Chan* c = as_chan(h);
     if (!c) return QDSP_HIP_EINVAL;
-    for (Engine* e : c->vfo) { e->phase += (unsigned long long)n * e->dphase; e->raw_valid = false; }
+    for (Engine* e : c->vfo) { apply_pending_inc(e); e->phase += (unsigned long long)n * e->dphase; e->raw_valid = false; }
     return 0;
 }
 int qdsp_hip_chan_cf32_channels(void* h) {

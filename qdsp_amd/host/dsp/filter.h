@@ -68,7 +68,9 @@ public:
     FIR(stream<T>* in, dsp::filter_window::generic_window* window) { init(in, window); }
 
     ~FIR() {
+        const bool live = base::running;   // a live block's input stream is alive (the reference's own rule: stop() touches it)
         base::stop();
+        if (live && _in) { _in->releaseConsumer(); }
         if (handle) { kComplex ? qdsp_hip_fir_cf32_destroy(handle) : qdsp_hip_fir_f32_destroy(handle); }
     }
 
@@ -81,19 +83,16 @@ public:
         if (rc != 0) { handle = nullptr; detail::hipBlockFail("FIR::init", rc); }
         base::registerInput(_in);
         base::registerOutput(&out);
-        _in->consumerTakesDevice = handle != nullptr;
-        _in->consumerPipelined = handle != nullptr;
+        _in->claimConsumer(handle != nullptr, true);
     }
 
     void setInput(stream<T>* in) {
         std::lock_guard<std::mutex> lck(base::ctrlMtx);
         base::tempStop();
         base::unregisterInput(_in);
-        _in->consumerTakesDevice = false;
-        _in->consumerPipelined = false;
+        _in->releaseConsumer();
         _in = in;
-        _in->consumerTakesDevice = handle != nullptr;
-        _in->consumerPipelined = handle != nullptr;
+        _in->claimConsumer(handle != nullptr, true);
         base::registerInput(_in);
         base::tempStart();
     }

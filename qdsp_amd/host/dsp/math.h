@@ -30,7 +30,12 @@ class math_block : public generic_block<math_block<T, OP>> {
 public:
     math_block() {}
     ~math_block() {
+        const bool live = base::running;
         base::stop();
+        if (live) {
+            if (_a) { _a->releaseConsumer(); }
+            if (_b) { _b->releaseConsumer(); }
+        }
         if (handle) { qdsp_hip_math_destroy(handle); }
     }
 
@@ -42,8 +47,8 @@ public:
         base::registerInput(a);
         base::registerInput(b);
         base::registerOutput(&out);
-        _a->consumerTakesDevice = handle != nullptr;
-        _b->consumerTakesDevice = handle != nullptr;
+        _a->claimConsumer(handle != nullptr, false);
+        _b->claimConsumer(handle != nullptr, false);
     }
 
     int run() override {

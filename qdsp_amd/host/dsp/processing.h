@@ -26,7 +26,9 @@ public:
     FrequencyXlator(stream<complex_t>* in, float sampleRate, float freq) { init(in, sampleRate, freq); }
 
     ~FrequencyXlator() {
+        const bool live = base::running;
         base::stop();
+        if (live && _in) { _in->releaseConsumer(); }
         if (handle) { qdsp_hip_xlate_cf32_destroy(handle); }
     }
 
@@ -39,8 +41,7 @@ public:
         if (rc != 0) { handle = nullptr; detail::hipBlockFail("FrequencyXlator::init", rc); }
         base::registerInput(_in);
         base::registerOutput(&out);
-        _in->consumerTakesDevice = handle != nullptr;
-        _in->consumerPipelined = handle != nullptr;
+        _in->claimConsumer(handle != nullptr, true);
     }
 
     // (sic) the reference names its input setter setInputSize (processing.h:26)
@@ -48,11 +49,9 @@ public:
         std::lock_guard<std::mutex> lck(base::ctrlMtx);
         base::tempStop();
         base::unregisterInput(_in);
-        _in->consumerTakesDevice = false;
-        _in->consumerPipelined = false;
+        _in->releaseConsumer();
         _in = in;
-        _in->consumerTakesDevice = handle != nullptr;
-        _in->consumerPipelined = handle != nullptr;
+        _in->claimConsumer(handle != nullptr, true);
         base::registerInput(_in);
         base::tempStart();
     }

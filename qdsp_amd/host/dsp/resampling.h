@@ -30,7 +30,9 @@ public:
     }
 
     ~PolyphaseResampler() {
+        const bool live = base::running;
         base::stop();
+        if (live && _in) { _in->releaseConsumer(); }
         if (handle) { kPair ? qdsp_hip_decim_cf32_destroy(handle) : qdsp_hip_decim_f32_destroy(handle); }
     }
 
@@ -47,19 +49,16 @@ public:
         if (rc != 0) { handle = nullptr; detail::hipBlockFail("PolyphaseResampler::init", rc); }
         base::registerInput(_in);
         base::registerOutput(&out);
-        _in->consumerTakesDevice = handle != nullptr;
-        _in->consumerPipelined = handle != nullptr;
+        _in->claimConsumer(handle != nullptr, true);
     }
 
     void setInput(stream<T>* in) {
         std::lock_guard<std::mutex> lck(base::ctrlMtx);
         base::tempStop();
         base::unregisterInput(_in);
-        _in->consumerTakesDevice = false;
-        _in->consumerPipelined = false;
+        _in->releaseConsumer();
         _in = in;
-        _in->consumerTakesDevice = handle != nullptr;
-        _in->consumerPipelined = handle != nullptr;
+        _in->claimConsumer(handle != nullptr, true);
         base::registerInput(_in);
         base::tempStart();
     }

@@ -23,23 +23,25 @@ class Splitter : public generic_block<Splitter<T>> {
 public:
     Splitter() {}
     Splitter(stream<T>* in) { init(in); }
+    ~Splitter() {
+        const bool live = base::running;
+        base::stop();
+        if (live && _in) { _in->releaseConsumer(); }
+    }
 
     void init(stream<T>* in) {
         _in = in;
         base::registerInput(_in);
-        _in->consumerTakesDevice = true;   // it can forward a device-resident block as is
-        _in->consumerPipelined = true;     // ... with copies queued behind the producer's kernel (stream.h)
+        _in->claimConsumer(true, true);    // it can forward a device-resident block as is, with copies queued behind the producer's kernel (stream.h)
     }
 
     void setInput(stream<T>* in) {
         std::lock_guard<std::mutex> lck(base::ctrlMtx);
         base::tempStop();
         base::unregisterInput(_in);
-        _in->consumerTakesDevice = false;
-        _in->consumerPipelined = false;
+        _in->releaseConsumer();
         _in = in;
-        _in->consumerTakesDevice = true;
-        _in->consumerPipelined = true;
+        _in->claimConsumer(true, true);
         base::registerInput(_in);
         base::tempStart();
     }

@@ -19,6 +19,7 @@ protected:
 
     void attach(stream<T>* in) {
         _in = in;
+        _in->releaseConsumer();   // a host consumer: whatever GPU block read this stream before, the producer fills readBuf again
         base::registerInput(_in);
     }
 

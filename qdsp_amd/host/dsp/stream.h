@@ -23,6 +23,7 @@
 // consumer a HIP-backed producer may swap a block in while its kernel is still running; the completion event it
 // recorded travels with the buffer and read() waits for it, so a consumer never sees an unfinished block.
 #pragma once
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
@@ -151,13 +152,25 @@ public:
     T* devReadBuf = nullptr;
     bool writeOnDevice = false;        // producer: the block being swapped in lives in devWriteBuf
     bool readOnDevice = false;         // consumer: the block just read lives in devReadBuf
-    bool consumerTakesDevice = false;  // set by a HIP-backed consumer on its input stream
+    // set by a HIP-backed consumer on its input stream, cleared when it lets go of the stream or a host consumer
+    // attaches (claimConsumer / releaseConsumer below); read by the producer's worker thread while setInput() on a
+    // control thread may change it, hence atomic
+    std::atomic<bool> consumerTakesDevice{false};
     // Pipelined link (QDSP_HIP_LINK_PIPELINED, qdsp_hip.h): producer and consumer both launch into the library's
     // in-order stream before they swap / flush, so the producer does not wait for its kernel and the GPU runs the
     // two back to back; the host threads only exchange buffers.
     bool writePipelined = false;       // producer: the block being swapped in may still be in flight on that stream
     bool readPipelined = false;        // consumer: ... so read it on the same stream
-    bool consumerPipelined = false;    // set by a consumer that launches into that stream before it flushes
+    std::atomic<bool> consumerPipelined{false};    // set by a consumer that launches into that stream before it flushes
+    // The consumer end of the link.  A HIP-backed block claims the stream when it registers it as its input
+    // (takesDevice: it reads devReadBuf; pipelined: it launches before it flushes); a host consumer (sinks, any
+    // reference block) and a consumer that re-plumbs or dies while live release it, so the producer goes back to
+    // filling the host buffers.
+    void claimConsumer(bool takesDevice, bool pipelined) {
+        consumerTakesDevice.store(takesDevice);
+        consumerPipelined.store(takesDevice && pipelined);
+    }
+    void releaseConsumer() { claimConsumer(false, false); }
     int linkIn() const { return readOnDevice ? (readPipelined ? QDSP_HIP_LINK_PIPELINED : QDSP_HIP_LINK_DEVICE) : QDSP_HIP_LINK_HOST; }
     int linkOut(bool outDev) const { return outDev ? (consumerPipelined ? QDSP_HIP_LINK_PIPELINED : QDSP_HIP_LINK_DEVICE) : QDSP_HIP_LINK_HOST; }
     void markWritten(int link, void* doneEvt = nullptr) {

@@ -30,7 +30,9 @@ class XlatingResampler : public generic_block<XlatingResampler> {
 public:
     XlatingResampler() {}
     ~XlatingResampler() {
+        const bool live = base::running;
         base::stop();
+        if (live && _in) { _in->releaseConsumer(); }
         if (handle) { qdsp_hip_xlate_fir_decim_cf32_destroy(handle); }
     }
 
@@ -41,8 +43,7 @@ public:
         if (rc != 0) { handle = nullptr; hipBlockFail("VFO::init", rc); }
         base::registerInput(_in);
         base::registerOutput(&out);
-        _in->consumerTakesDevice = handle != nullptr;
-        _in->consumerPipelined = handle != nullptr;
+        _in->claimConsumer(handle != nullptr, true);
     }
 
     void configure(const std::vector<float>& taps, int interp, int decim) {

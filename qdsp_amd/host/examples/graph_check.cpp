@@ -24,6 +24,10 @@
 //                      prints input Msamples/s and microseconds per block
 //   graph_check split  <in.cf32> <out_prefix> <block> <n> <inSR> <outSR> <bw>
 //                      source -> Splitter -> n x VFO(offset_i = (i - (n-1)/2) * inSR/n) -> sinks
+//   graph_check mulsplit <in.cf32> <out_prefix> <block> <n> <inSR> <outSR> <bw>
+//                      source -> Splitter (host-fed) -> Multiply(x, x) -> Splitter -> n x VFO -> sinks: the second
+//                      Splitter's input comes from a producer OUTSIDE the library's pipelined stream, so its
+//                      device-to-device copies must have read the block before it is flushed
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -490,6 +494,62 @@ int main(int argc, char** argv) {
             o.write(reinterpret_cast<const char*>(cols[i]->data.data()), (std::streamsize)(cols[i]->data.size() * sizeof(complex_t)));
         }
         printf("split ok: %d channels, %zu in, %zu out each\n", n, feed.data.size(), cols[0]->data.size());
+        for (auto* s : sinks) { delete s; }
+        for (auto* v : vfos) { delete v; }
+        for (auto* l : links) { delete l; }
+        for (auto* c : cols) { delete c; }
+        return 0;
+    }
+    if (mode == "mulsplit" && argc >= 9) {
+        const int n = atoi(argv[5]);
+        const float inSR = (float)atof(argv[6]), outSR = (float)atof(argv[7]), bw = (float)atof(argv[8]);
+        Feed<complex_t> feed;
+        feed.data = readAll<complex_t>(in);
+        feed.block = block;
+        const long nblocks = (long)((feed.data.size() + block - 1) / block);
+        HandlerSource<complex_t> src(Feed<complex_t>::pull, &feed);
+        Splitter<complex_t> split0(&src.out);
+        stream<complex_t> la, lb;
+        split0.bindStream(&la);
+        split0.bindStream(&lb);
+        Multiply<complex_t> mul(&la, &lb);
+        Splitter<complex_t> split(&mul.out);
+        std::vector<stream<complex_t>*> links;
+        std::vector<VFO*> vfos;
+        std::vector<Collect<complex_t>*> cols;
+        std::vector<HandlerSink<complex_t>*> sinks;
+        for (int i = 0; i < n; i++) {
+            links.push_back(new stream<complex_t>());
+            const float off = ((float)i - (float)(n - 1) / 2.0f) * inSR / (float)n;
+            vfos.push_back(new VFO(links[i], off, inSR, outSR, bw));
+            split.bindStream(links[i]);
+            cols.push_back(new Collect<complex_t>());
+            sinks.push_back(new HandlerSink<complex_t>(vfos[i]->out, Collect<complex_t>::push, cols[i]));
+        }
+        for (auto* s : sinks) { s->start(); }
+        for (auto* v : vfos) { v->start(); }
+        split.start();
+        mul.start();
+        split0.start();
+        src.start();
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < n; i++) {
+            while (cols[i]->blocks.load() < nblocks) {
+                std::this_thread::sleep_for(std::chrono::milliseconds(1));
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) { fprintf(stderr, "mulsplit graph timed out\n"); return 3; }
+            }
+        }
+        src.stop();
+        split0.stop();
+        mul.stop();
+        split.stop();
+        for (auto* v : vfos) { v->stop(); }
+        for (auto* s : sinks) { s->stop(); }
+        for (int i = 0; i < n; i++) {
+            std::ofstream o(std::string(out) + "." + std::to_string(i) + ".cf32", std::ios::binary);
+            o.write(reinterpret_cast<const char*>(cols[i]->data.data()), (std::streamsize)(cols[i]->data.size() * sizeof(complex_t)));
+        }
+        printf("mulsplit ok: %d channels, %zu in, %zu out each\n", n, feed.data.size(), cols[0]->data.size());
         for (auto* s : sinks) { delete s; }
         for (auto* v : vfos) { delete v; }
         for (auto* l : links) { delete l; }

@@ -1,14 +1,20 @@
 """Time-axis sharding of one long IQ stream over the ranks of a node.
 
 The FIR / decimator / fused-VFO path has no recurrence: y[n] needs x[n-H .. n] only.  So a
-stream is cut into contiguous chunks, one per rank (one process per GPU), and the ONLY
-exchange is each rank's last H input samples (H = ntaps-1 for the FIR, taps-per-phase for
-the resampler) handed to the next rank as that rank's filter history: a point-to-point
-send/recv of ~2 KB to the ring neighbour over xGMI (torch.distributed `nccl` == RCCL on
-ROCm).  There is no all-reduce / all-gather anywhere on the data path.  The NCO needs no
-communication at all: rank r starts its phase accumulator at r*chunk (`advance`).
+stream is cut into chunks, one per rank (one process per GPU), and the ONLY exchange is each
+rank's last H input samples (H = ntaps-1 for the FIR, taps-per-phase for the resampler)
+handed to the next rank as that rank's filter history: a point-to-point send/recv of ~2 KB
+to the ring neighbour over xGMI (torch.distributed `nccl` == RCCL on ROCm).  There is no
+all-reduce / all-gather anywhere on the data path.  The NCO needs no communication at all:
+every rank puts its phase accumulator at its chunk's first sample (`*_advance`).
 
 The reference has no distributed layer; this module is new, not a translation.
+
+Two cuts of the stream are supported:
+  * `partition` + `exchange_halo`: ONE contiguous chunk per rank (a stream that exists up front);
+  * `RingStream`: a stream that keeps coming -- block-cyclic, step s / rank r owns samples
+    [(s*world + r)*n, +n) -- with the halo hand-off of every step prefetched under the previous
+    step's kernel.  bench.py and the multi-rank tests run through this class.
 
 Chunk starts are aligned so the sharded result equals the single-call result:
   * multiples of `decim`, so the resampler's per-call phase restart (src/dsp/resampling.h:
@@ -41,29 +47,35 @@ def chunk_alignment(decim: int = 1, interp: int = 1, rotator_cadence: int = 0) -
 
 def partition(total: int, world: int, hist: int, align: int = 1) -> list[Chunk]:
     """Contiguous, aligned, near-equal chunks covering [0, total).  Every chunk except the
-    last is a multiple of `align`; every chunk except possibly the last holds at least
-    `hist` samples so one neighbour hop suffices for the halo."""
-    if world <= 0 or total < 0 or align <= 0:
+    last is a multiple of `align`.  Every chunk that has a successor holds at least `hist`
+    samples, so one neighbour hop suffices for the halo: when the stream is too short for
+    that on `world` ranks a ValueError says so (use fewer ranks) -- trailing ranks are never
+    silently left with a short or empty chunk that they would have to forward a halo from."""
+    if world <= 0 or total < 0 or align <= 0 or hist < 0:
         raise ValueError("bad partition arguments")
     per = -(-total // world)            # ceil
     per = -(-per // align) * align      # round up to the alignment
-    if world > 1 and per < hist:
-        raise ValueError(f"chunk of {per} samples is shorter than the {hist}-sample halo; use fewer ranks")
     chunks = []
     for r in range(world):
         s = min(r * per, total)
         e = min(s + per, total)
         chunks.append(Chunk(r, world, s, e - s, 0 if r == 0 else hist))
+    if world > 1:
+        for c in chunks[:-1]:
+            if c.count < hist:
+                raise ValueError(
+                    f"rank {c.rank} would own {c.count} samples, fewer than the {hist}-sample halo its successor "
+                    f"needs ({total} samples over {world} ranks, alignment {align}); use fewer ranks")
     return chunks
 
 
 def exchange_halo(tail, hist_out, rank: int, world: int, group=None):
-    """Ring-neighbour halo: send `tail` (my last H input samples) to rank+1, receive the
-    previous rank's tail into `hist_out`.  Rank 0 receives nothing (its history is the
-    stream's zero initial state: the caller zeroes / resets it); the last rank sends nothing.
-    Works on any torch.distributed backend (nccl/RCCL on GPUs, gloo on CPU tensors).
-    Returns after the transfers have completed from the caller's point of view (for nccl:
-    enqueued on the current stream, ordered before subsequent kernels on it)."""
+    """Ring-neighbour halo of a contiguous partition: send `tail` (my last H input samples) to
+    rank+1, receive the previous rank's tail into `hist_out`.  Rank 0 receives nothing (its
+    history is the stream's zero initial state: the caller zeroes / resets it); the last rank
+    sends nothing.  Works on any torch.distributed backend (nccl/RCCL on GPUs, gloo on CPU
+    tensors).  Returns after the transfers have completed from the caller's point of view
+    (for nccl: enqueued on the current stream, ordered before subsequent kernels on it)."""
     import torch.distributed as dist
 
     if world == 1:
@@ -76,3 +88,148 @@ def exchange_halo(tail, hist_out, rank: int, world: int, group=None):
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+
+
+class RingStream:
+    """One rank's end of a continuous stream processed block-cyclically on `world` ranks.
+
+    Step s of rank r processes samples [(s*world + r)*n, +n).  The halo that step needs is the
+    tail (last H input samples) of the chunk just before it in the stream: chunk (s, r-1) for
+    r > 0, chunk (s-1, world-1) for rank 0 (zeros at s = 0).  So every step all ranks send the
+    tail of their chunk to their ring successor; ranks > 0 use what arrives in the same step,
+    rank 0 what arrived one step earlier.  That tail is INPUT, known before the step is
+    computed: `step(x, out, next_x=...)` posts the exchange for the following step right after
+    this step's history is installed and BEFORE this step's kernel is launched, so the RCCL
+    send/recv (on RCCL's own stream, ordered behind what is already queued on the compute
+    stream) runs under the kernel instead of in front of it.
+
+    op         a qdsp_amd.ops operator with history (`Fir`, `Resampler`, `Vfo`, `Channelizer`), or an
+               `Xlator` (no halo; only the NCO bookkeeping applies)
+    transport  "device": halos travel as device tensors through the process group (nccl == RCCL;
+               world 1 with an initialised group = the rank is its own ring neighbour, which
+               exercises the real send/recv on a one-GPU box);
+               "host": halos are staged through CPU tensors (gloo) -- several ranks sharing one
+               GPU, where RCCL refuses to run; used by the one-GPU rehearsal tests.
+    The NCO (if the operator has one) is put at this rank's first sample on construction and
+    stepped over the other ranks' chunks after every step -- no communication.
+    """
+
+    NBUF = 3   # receive buffers in rotation: rank 0 reads the one filled a step earlier while the next one is in flight
+
+    def __init__(self, op, n: int, rank: int, world: int, *, group=None, transport: str = "device",
+                 prefetch: bool = True, align: int = 1, exchange: bool | None = None):
+        import torch
+
+        if transport not in ("device", "host"):
+            raise ValueError("transport must be 'device' or 'host'")
+        if n <= 0 or n % max(1, align):
+            raise ValueError(f"chunk of {n} samples is not a positive multiple of the alignment {align}")
+        self.op, self.n, self.rank, self.world = op, int(n), int(rank), int(world)
+        self.group, self.transport = group, transport
+        self.H = int(getattr(op, "history_len", 0) or 0) if hasattr(op, "set_history_dev") else 0
+        if self.world > 1 and self.n < self.H:
+            raise ValueError(f"chunk of {n} samples is shorter than the {self.H}-sample halo")
+        self.has_nco = hasattr(op, "advance")
+        # world 1: exchange only when asked to (the self-ring of the one-GPU RCCL test / bench mode)
+        self.exchange = (self.world > 1) if exchange is None else bool(exchange)
+        self.exchange = self.exchange and self.H > 0
+        self.prefetch = bool(prefetch) and self.exchange and transport == "device"
+        # (an operator may name the device its tensors live on -- the CPU tests drive this class with a host-side
+        # stand-in; the HIP operators of qdsp_amd.ops live on cuda:<op.device>)
+        self.device = torch.device(getattr(op, "torch_device", None) or f"cuda:{getattr(op, 'device', 0)}")
+        self.step_index = 0
+        self._pending = None          # (reqs, buffer index) of the exchange in flight
+        self._posted = 0              # exchanges posted so far
+        if self.exchange:
+            z = lambda: torch.zeros(max(self.H, 1), dtype=torch.complex64, device=self.device)  # noqa: E731
+            self._recv = [z() for _ in range(self.NBUF)]
+            self._zeros = z()
+        if self.has_nco and self.world > 1:
+            op.advance(self.rank * self.n)
+
+    # -- the exchange -------------------------------------------------------------------------
+    def _post(self, x):
+        """Start the hand-off for the step that will process `x`: my tail -> successor, predecessor's -> me."""
+        import torch
+        import torch.distributed as dist
+
+        k = self._posted % self.NBUF
+        self._posted += 1
+        nxt, prv = (self.rank + 1) % self.world, (self.rank - 1) % self.world
+        if self.transport == "host":
+            tail_h = x[x.numel() - self.H:].cpu()
+            halo_h = torch.empty(self.H, dtype=torch.complex64)
+            reqs = dist.batch_isend_irecv([
+                dist.P2POp(dist.isend, torch.view_as_real(tail_h), nxt, self.group),
+                dist.P2POp(dist.irecv, torch.view_as_real(halo_h), prv, self.group),
+            ])
+            return (reqs, k, halo_h, tail_h)
+        # sent straight from the chunk (a contiguous view): `x` is the input of the step this exchange belongs to,
+        # so it stays untouched until that step has waited for the exchange
+        reqs = dist.batch_isend_irecv([
+            dist.P2POp(dist.isend, torch.view_as_real(x[x.numel() - self.H:]), nxt, self.group),
+            dist.P2POp(dist.irecv, torch.view_as_real(self._recv[k]), prv, self.group),
+        ])
+        return (reqs, k, None, None)
+
+    def _complete(self, pending):
+        reqs, k, halo_h, _ = pending
+        for r in reqs:
+            r.wait()
+        if halo_h is not None:
+            self._recv[k].copy_(halo_h)
+        return k
+
+    def step(self, x, out=None, next_x=None):
+        """Process this rank's chunk `x` (n samples, device tensor) of the current step.  `next_x`: the
+        chunk of the following step if it is already resident (its halo is then prefetched under this
+        step's kernel).  Returns the operator's output."""
+        if x.numel() != self.n:
+            raise ValueError(f"chunk of {x.numel()} samples, expected {self.n}")
+        if self.exchange:
+            if self._pending is None:
+                self._pending = self._post(x)
+            k = self._complete(self._pending)
+            self._pending = None
+            if self.rank == 0:
+                # what just arrived is the last rank's tail of THIS step = my halo of the NEXT step;
+                # this step reads what arrived one step earlier (the stream's zero state at step 0)
+                src = self._recv[(k - 1) % self.NBUF] if self.step_index > 0 else self._zeros
+            else:
+                src = self._recv[k]
+            self.op.set_history_dev(src)     # *_set_history_dev: asynchronous, on the current stream
+            if self.prefetch and next_x is not None:
+                self._pending = self._post(next_x)
+        y = self.op.process(x, out)
+        self.step_index += 1
+        if self.has_nco and self.world > 1:
+            self.op.advance((self.world - 1) * self.n)      # the call itself advanced by n
+        return y
+
+    def drain(self):
+        """Complete an exchange posted for a step that will not run (every rank has one in flight)."""
+        if self._pending is not None:
+            for r in self._pending[0]:
+                r.wait()
+            self._pending = None
+
+    def stream_position(self) -> int:
+        """First sample of the chunk the next step() of this rank processes."""
+        return (self.step_index * self.world + self.rank) * self.n
+
+
+def process_stream(op, chunks, n: int, rank: int, world: int, **kw):
+    """Run `chunks` (an iterable of this rank's device tensors, one per step, in stream order)
+    through `op` on a `RingStream`; yields the outputs.  The iterable is read one chunk ahead so
+    each step's successor halo is prefetched."""
+    rs = RingStream(op, n, rank, world, **kw)
+    it = iter(chunks)
+    try:
+        cur = next(it)
+    except StopIteration:
+        return
+    while cur is not None:
+        nxt = next(it, None)
+        yield rs.step(cur, next_x=nxt)
+        cur = nxt
+    rs.drain()

@@ -70,3 +70,34 @@ def test_phase_delta_matches_reference_formula():
     for fs, f in ((4.0, 1.0), (2.4e6, 123456.0), (48000.0, -7000.0)):
         d = O.Xlator(fs, f).delta
         assert phase_delta(fs, f) == (float(d[0]), float(d[1]))
+
+
+def test_bench_starts_its_own_ranks_before_touching_the_gpu(monkeypatch):
+    """`python bench.py --gpus N` with no launcher in the environment starts N ranks through torch.distributed.run as a
+    CHILD process (never an exec of itself) and returns their exit code; it does so before importing torch."""
+    import importlib
+    import subprocess
+    import sys
+
+    sys.path.insert(0, ROOT) if ROOT not in sys.path else None
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert ex.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("def main():"):]
+    assert body.index("launch_ranks(args)") < body.index("import torch")     # nothing GPU-related runs first

@@ -648,6 +648,46 @@ def test_vfo_set_history_dev_rotates_raw_samples(ops, gold):
         assert rel_rms(y2, y[cut // dec:]) < 2e-6, dec
 
 
+@pytest.mark.parametrize("kind", ["fir", "fir_direct", "fir_f32", "decim8", "decim3"])
+def test_fir_and_resampler_set_history_dev(ops, gold, kind):
+    """Multi-GPU halo for the handles without an NCO (qdsp_hip_fir_cf32_set_history_dev and friends): a second handle
+    given the neighbour's tail (history_len INPUT samples, device memory) continues the stream where the first one
+    would be -- FIR in both forms, FIR<float>, and resamplers (chunk start a multiple of the decimation)."""
+    import torch
+
+    taps = gold["taps256"]
+    n, cut = 300_000, 150_000
+    x = O.synth_iq(0, n, seed=91)
+    if kind == "fir_f32":
+        x = np.ascontiguousarray(x.real)
+
+    def make():
+        if kind in ("fir", "fir_direct"):
+            op = ops.Fir(taps, max_block=0)
+            op.set_mode(op.DIRECT if kind == "fir_direct" else op.FFT)
+            return op, 1
+        if kind == "fir_f32":
+            return ops.Fir(taps, complex_data=False, max_block=0), 1
+        dec = 8 if kind == "decim8" else 3
+        return ops.Resampler(taps, 1, dec, max_block=0), dec
+
+    whole, dec = make()
+    y = whole.process(dev(x)).cpu().numpy()
+    second, _ = make()
+    H = second.history_len
+    assert H == (255 if dec == 1 else 256)
+    second.set_history_dev(dev(x[cut - H:cut]))
+    y2 = second.process(dev(x[cut:])).cpu().numpy()
+    torch.cuda.synchronize()
+    assert cut % dec == 0 and len(y2) == len(y) - cut // dec
+    if kind == "fir_direct":
+        assert np.array_equal(y2, y[cut:])             # same k-ordered fmaf chain on the same samples
+    else:
+        assert rel_rms(y2, y[cut // dec:]) < 2e-6
+    # and the history it leaves behind is the stream's own tail
+    assert np.array_equal(second.get_history(), whole.get_history())
+
+
 @pytest.mark.parametrize("mode", ["uniform", "per_channel"])
 def test_channelizer_time_sharded_halo(ops, gold, mode):
     """BASELINE configs[4] at N > 1: a second handle started mid-stream from advance() and the

@@ -1,0 +1,140 @@
+"""The N > 1 path with the HIP operators (BASELINE configs[3] and the 8-GPU leg of configs[4]) on
+the one-GPU test box: 2 and 4 ranks share cuda:0, every rank runs the HIP kernel of its chunk behind
+qdsp_amd.sharding.RingStream (the runner bench.py --gpus N uses), halos travel over gloo as CPU tensors
+(RCCL refuses several ranks on one device); plus one rank as its own ring neighbour over real RCCL.
+The concatenated outputs are compared with the UNSHARDED CPU oracle of the whole stream.
+At most 4 worker processes + this one use the GPU at a time (the box allows 6)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle as O
+from conftest import rel_rms
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+WORKER = os.path.join(HERE, "_ring_gpu_worker.py")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_ranks(case, backend, world, outdir, steps, n):
+    port = str(_free_port())
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = [subprocess.Popen([sys.executable, WORKER, case, backend, str(world), str(r), port, str(outdir), str(steps), str(n)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=420)[0])
+    finally:
+        for p in procs:            # the exact processes started here, nothing else
+            if p.poll() is None:
+                p.kill()
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} of {case}/{backend}/{world} failed:\n{o[-3000:]}"
+
+
+def _expected(case, x):
+    from bench import lowpass_taps
+
+    if case == "fir256":
+        return O.Fir(lowpass_taps(256, 1 / 16), acc=O.ACC_F64).process(x)
+    if case == "decim8":
+        return O.Resampler(lowpass_taps(256, 1 / 16), 1, 8, acc=O.ACC_F64).process(x)
+    xl = O.Xlator(1.0, 0.1234, exact=True, volk_gain=True)
+    if case == "xlate_fir_decim8":
+        return O.Resampler(lowpass_taps(256, 1 / 16), 1, 8, acc=O.ACC_F64).process(xl.process(x))
+    if case == "vfo50":
+        return O.Resampler(lowpass_taps(401, 0.4 / 50), 1, 50, acc=O.ACC_F64).process(xl.process(x))
+    raise AssertionError(case)
+
+
+def _collect(case, outdir, world, steps):
+    return [np.load(os.path.join(outdir, f"{case}_{s}_{r}.npy")) for s in range(steps) for r in range(world)]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("case", ["fir256", "xlate_fir_decim8", "decim8"])
+def test_ranks_on_one_gpu_match_unsharded_oracle(tmp_path, case, world):
+    """configs[3] shape (256-tap FIR, chunk-sharded, 255-sample halo) and configs[2] sharded the same way."""
+    steps, n = 2, 1 << 17
+    _run_ranks(case, "gloo", world, tmp_path, steps, n)
+    y = np.concatenate(_collect(case, tmp_path, world, steps))
+    x = O.synth_iq(0, steps * world * n, seed=4321)
+    want = _expected(case, x)
+    assert len(y) == len(want)
+    assert rel_rms(y, want) < 2e-6
+    # a wrong or missing halo is an O(1) error in the first 255 outputs of a chunk: check those windows on their own
+    per = len(want) // (steps * world)
+    for c in range(1, steps * world):
+        w0 = c * per
+        assert rel_rms(y[w0:w0 + 64], want[w0:w0 + 64]) < 1e-5, (case, world, c)
+    assert open(os.path.join(tmp_path, f"{case}_kernel_0.txt")).read() == "fir_fft_kernel"
+
+
+def test_large_decimation_vfo_on_two_ranks(tmp_path):
+    """The VFO's everyday shape (401 taps, decimate by 50: resamp_any_kernel) sharded over two ranks; chunks are
+    multiples of lcm(50, 512) = 12800 samples (per-call phase restart and the VOLK gain cadence both line up)."""
+    from qdsp_amd.sharding import chunk_alignment
+
+    case, world, steps, n = "vfo50", 2, 2, 12800 * 8
+    assert chunk_alignment(50, 1, 512) == 12800
+    _run_ranks(case, "gloo", world, tmp_path, steps, n)
+    y = np.concatenate(_collect(case, tmp_path, world, steps))
+    x = O.synth_iq(0, steps * world * n, seed=4321)
+    want = _expected(case, x)
+    assert len(y) == len(want) and rel_rms(y, want) < 2e-6
+    per = len(want) // (steps * world)
+    for c in range(1, steps * world):
+        assert rel_rms(y[c * per:c * per + 8], want[c * per:c * per + 8]) < 1e-5, c
+    assert open(os.path.join(tmp_path, f"{case}_kernel_0.txt")).read() == "resamp_any_kernel"
+    with pytest.raises(AssertionError):
+        _run_ranks(case, "gloo", world, tmp_path, steps, 1 << 17)     # 2^17 % 12800 != 0: RingStream refuses, the ranks exit non-zero
+
+
+def test_channelizer_64_on_two_ranks(tmp_path):
+    """The multi-GPU leg of configs[4]: time-sharded, all 64 channels on every rank, 256-sample raw halo."""
+    from bench import lowpass_taps
+
+    case, world, steps, n = "chan64", 2, 2, 1 << 16
+    _run_ranks(case, "gloo", world, tmp_path, steps, n)
+    ys = _collect(case, tmp_path, world, steps)
+    y = np.concatenate(ys, axis=1)
+    x = O.synth_iq(0, steps * world * n, seed=4321)
+    taps = lowpass_taps(256, 1 / 128)
+    assert y.shape == (64, len(x) // 64)
+    assert open(os.path.join(tmp_path, f"{case}_kernel_0.txt")).read() == "chan_uniform_kernel"
+    for c in (0, 7, 31, 32, 63):
+        xl = O.Xlator(1.0, -(c - 31.5) / 64.0, exact=True, volk_gain=True)
+        want = O.Resampler(taps, 1, 64, acc=O.ACC_F64).process(xl.process(x))
+        assert rel_rms(y[c], want) < 4e-6, c
+        per = len(want) // (steps * world)
+        for k in range(1, steps * world):
+            assert rel_rms(y[c][k * per:k * per + 8], want[k * per:k * per + 8]) < 2e-5, (c, k)
+
+
+@pytest.mark.parametrize("case", ["fir256", "xlate_fir_decim8"])
+def test_rccl_self_ring_matches_unsharded_oracle(tmp_path, case):
+    """One rank as its own ring neighbour over real RCCL (nccl backend): the halo of step s+1 is this rank's own
+    tail of step s, sent and received through batch_isend_irecv on device tensors and prefetched under the kernel --
+    the transport the 8-GPU run uses, with world = 1 so the result is the plain unsharded stream."""
+    steps, n = 4, 1 << 17
+    _run_ranks(case, "nccl", 1, tmp_path, steps, n)
+    y = np.concatenate(_collect(case, tmp_path, 1, steps))
+    x = O.synth_iq(0, steps * n, seed=4321)
+    want = _expected(case, x)
+    assert len(y) == len(want) and rel_rms(y, want) < 2e-6
+    per = len(want) // steps
+    for c in range(1, steps):
+        assert rel_rms(y[c * per:c * per + 64], want[c * per:c * per + 64]) < 1e-5, (case, c)

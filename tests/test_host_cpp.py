@@ -237,6 +237,24 @@ def test_graph_splitter_to_vfos(harness, data):
 
 
 @gpu
+def test_graph_multiply_into_splitter_to_vfos(harness, data):
+    """source -> Splitter -> Multiply(x, x) -> Splitter -> 8 x VFO -> sinks.  The second Splitter's input is a
+    device-resident block from a producer that does not launch into the library's pipelined stream (the math block has
+    its own stream), while its outputs are pipelined links: its queued device-to-device copies must have read the block
+    before it flushes the input (qdsp_hip_memcpy_d2d_link), or the Multiply overwrites it two blocks later."""
+    d, x = data
+    b, n = 25_000, 8
+    run([harness, "mulsplit", str(d / "x.cf32"), str(d / "yms"), str(b), str(n), "2400000", "240000", "200000"])
+    x2 = O.math_op(2, x, x)
+    for i in range(n):
+        y = np.fromfile(str(d / "yms") + f".{i}.cf32", dtype=np.complex64)
+        off = np.float32((np.float32(i) - np.float32(n - 1) / np.float32(2.0)) * np.float32(2.4e6) / np.float32(n))
+        v = O.Vfo(float(off), 2.4e6, 240e3, 200e3, exact_nco=True, volk_gain=True)
+        want = np.concatenate([v.process(x2[j:j + b]) for j in range(0, len(x2), b)])
+        assert len(y) == len(want) and rel_rms(y, want) < 3e-6, i
+
+
+@gpu
 def test_integration_patch_b_fir(harness, data):
     """INTEGRATION.md section B compiled: a block that keeps its own stream / window types and only swaps the
     VOLK loop for qdsp_hip_fir_cf32_process (examples/patch_b_fir.cpp)."""

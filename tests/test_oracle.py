@@ -198,3 +198,22 @@ def test_math_blocks_known_answers():
     want = np.complex64(complex(np.float32(np.float32(xr * yr) - np.float32(xi * yi)), np.float32(np.float32(xr * yi) + np.float32(xi * yr))))
     assert O.math_op(2, x, y)[0] == want
 
+
+
+def test_simd_lane_order_variant_is_the_same_filter():
+    """ACC_SIMD (lane-partial sums + FMA, the shape of VOLK's SIMD kernels; bench.py's `value_simd`) computes the same
+    FIR / resampler as the generic order: both sit within FP32 summation noise of the FP64 accumulation."""
+    x = O.synth_iq(0, 30_000, seed=3)
+    for ntaps in (4, 63, 64, 255, 256, 257):
+        taps = O.lowpass_taps_f64(ntaps, 1 / 16)
+        want = O.Fir(taps, acc=O.ACC_F64).process(x)
+        a, b = O.Fir(taps, acc=O.ACC_SIMD), O.Fir(taps, acc=O.ACC_SIMD)
+        y = a.process(x)
+        assert rel_rms(y, want) < 5e-7, ntaps
+        yb = np.concatenate([b.process(x[:7777]), b.process(x[7777:])])     # history carried as for every other order
+        assert np.array_equal(y, yb)
+        xr = np.ascontiguousarray(x.real)
+        assert rel_rms(O.Fir(taps, complex_data=False, acc=O.ACC_SIMD).process(xr), O.Fir(taps, complex_data=False, acc=O.ACC_F64).process(xr)) < 5e-7
+    taps = O.lowpass_taps_f64(256, 1 / 16)
+    for L, M in ((1, 8), (3, 2), (2, 3), (1, 50)):
+        assert rel_rms(O.Resampler(taps, L, M, acc=O.ACC_SIMD).process(x), O.Resampler(taps, L, M, acc=O.ACC_F64).process(x)) < 5e-7, (L, M)

@@ -88,3 +88,103 @@ def test_sharded_equals_unsharded(tmp_path, world, case):
         assert np.abs(y - want).max() < 1e-6      # phase restart per rank: float rounding of the seed only
     else:
         assert np.array_equal(y, want)            # same arithmetic, same order: bit-identical
+
+
+# ---------------------------------------------------------------------------------------------
+# RingStream (the block-cyclic runner bench.py and the GPU multi-rank tests use), driven on CPU
+# tensors over gloo with the oracle standing in for the per-rank operator.
+# ---------------------------------------------------------------------------------------------
+class _OracleOp:
+    """The operator surface RingStream needs (history_len, set_history_dev, process, advance, torch_device),
+    backed by the oracle.  `vfo`: history arrives as RAW input samples and is rotated here with the NCO phases
+    those samples had, as qdsp_hip_xlate_fir_decim_cf32_set_history_dev does."""
+
+    torch_device = "cpu"
+
+    def __init__(self, case):
+        taps = O.lowpass_taps_f64(256, 1 / 16)
+        self.case = case
+        self.op = O.Fir(taps) if case == "fir" else O.Resampler(taps, 1, 8)
+        self.history_len = 255 if case == "fir" else 256
+        self.pos = 0
+        if case == "vfo":
+            self.xl = O.Xlator(1.0, 0.1234, exact=True, volk_gain=True)
+            self.dt = np.arctan2(float(self.xl.delta[1]), float(self.xl.delta[0])) / (2 * np.pi)
+            self.advance = self._advance            # (only NCO-bearing operators have advance())
+
+    def _advance(self, n):
+        self.pos += int(n)
+
+    def _rot(self, x, first):
+        self.xl.turns.value = (first * self.dt) % 1.0
+        return self.xl.process(x)
+
+    def set_history_dev(self, t):
+        h = t.numpy().copy()
+        if self.case == "vfo":
+            # (the magnitude sawtooth restarts per call: history samples sit at the END of the previous chunk,
+            # whose length is a multiple of 512, so they carry gains |inc|^(512-H..511))
+            pad = np.zeros(512 - self.history_len, np.complex64)
+            h = self._rot(np.concatenate([pad, h]), self.pos - 512)[len(pad):]
+        buf = np.zeros(len(self.op.hist), np.float32)
+        buf[len(buf) - 2 * self.history_len:] = h.view(np.float32)
+        self.op.hist[:] = buf
+
+    def process(self, x, out=None):
+        a = x.numpy()
+        if self.case == "vfo":
+            a = self._rot(a, self.pos)
+            self.pos += len(a)
+        return torch.from_numpy(self.op.process(a))
+
+
+def _ring_worker(rank, world, port, case, outdir, steps, n):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        x = O.synth_iq(0, steps * world * n, seed=78)
+        align = sharding.chunk_alignment(1 if case == "fir" else 8, 1, 512 if case == "vfo" else 0)
+        rs = sharding.RingStream(_OracleOp(case), n, rank, world, align=align)
+        chunks = [torch.from_numpy(x[(s * world + rank) * n:(s * world + rank + 1) * n].copy()) for s in range(steps)]
+        ys = list(sharding.process_stream(rs.op, chunks, n, rank, world, align=align)) if case == "decim8" else \
+            [rs.step(c, next_x=chunks[i + 1] if i + 1 < steps else None) for i, c in enumerate(chunks)]
+        rs.drain()
+        assert rs.stream_position() == (steps * world + rank) * n or case == "decim8"
+        for s, y in enumerate(ys):
+            np.save(os.path.join(outdir, f"{case}_{s}_{rank}.npy"), y.numpy())
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("case", ["fir", "decim8", "vfo"])
+def test_ring_stream_block_cyclic_equals_unsharded(tmp_path, world, case):
+    """Step s / rank r owns samples [(s*world + r)*n, +n): rank 0 reads the halo that arrived a step earlier,
+    the others the one of the same step; the NCO is stepped over the other ranks' chunks without communication."""
+    steps, n = 3, 2048
+    mp.spawn(_ring_worker, args=(world, _free_port(), case, str(tmp_path), steps, n), nprocs=world, join=True)
+    y = np.concatenate([np.load(tmp_path / f"{case}_{s}_{r}.npy") for s in range(steps) for r in range(world)])
+    x = O.synth_iq(0, steps * world * n, seed=78)
+    taps = O.lowpass_taps_f64(256, 1 / 16)
+    if case == "fir":
+        want = O.Fir(taps).process(x)
+    elif case == "decim8":
+        want = O.Resampler(taps, 1, 8).process(x)
+    else:
+        want = O.Resampler(taps, 1, 8).process(O.Xlator(1.0, 0.1234, exact=True, volk_gain=True).process(x))
+    assert len(y) == len(want)
+    if case == "vfo":
+        assert np.abs(y - want).max() < 1e-6
+    else:
+        assert np.array_equal(y, want)
+
+
+def test_partition_refuses_short_trailing_chunks():
+    with pytest.raises(ValueError):
+        sharding.partition(1000, 8, 255, 512)        # ranks 2..7 would own nothing yet be asked for a halo
+    ch = sharding.partition(1000, 2, 255, 512)
+    assert [c.count for c in ch] == [512, 488]
+    with pytest.raises(ValueError):
+        sharding.RingStream(_OracleOp("fir"), 1000, 0, 2, align=512)   # chunk not a multiple of the alignment
