@@ -388,6 +388,10 @@ def run_workload(name: str, args, ctx) -> dict:
     flops = w["flops"]
     if kinfo["name"] == "fir_fft_kernel":
         flops = 1524.0 * 256 / (4097 - w["ntaps"])
+    elif kinfo["name"] == "pfb_dec8_kernel":
+        # polyphase overlap-save, one wave per segment of 4096 inputs: ~2860 VALU instructions per wave (PMC), of which
+        # ~950 are fused multiply-adds: ~3800 FLOP per lane x 64 lanes / (8 * (513 - ntaps/8)) new input samples
+        flops = 3800.0 * 64 / (8 * (513 - (w["ntaps"] + 7) // 8))
     elif kinfo["name"] == "chan_uniform_kernel":
         # per lane and wave tile (16 output times x 64 channels = 1024 input samples per wave): 64 complex
         # MACs (512), radix-16 (~200), twiddles (~90), radix-4 across the quad (~220), per-channel

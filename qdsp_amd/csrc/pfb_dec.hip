@@ -1,0 +1,321 @@
+// pfb_dec.hip -- polyphase overlap-save decimate-by-8 kernel, one wave per segment (design notes: pfb_dec.hip.h).
+// Own translation unit, built with -fno-slp-vectorize like fft_fir.hip (scalar f32 butterflies, no v_pk shuffles).
+#include "pfb_dec.hip.h"
+#include "cfft.hip.h"
+
+namespace qk {
+
+namespace {
+
+// cos / sin of 2 pi n / 64 (forward twiddle W64^n = (c, -s))
+__device__ constexpr float kCos64[64] = {
+    1.f, 0.995184727f, 0.98078528f, 0.956940336f, 0.923879533f, 0.881921264f, 0.831469612f, 0.773010453f, 0.707106781f, 0.634393284f,
+    0.555570233f, 0.471396737f, 0.382683432f, 0.290284677f, 0.195090322f, 0.0980171403f, 0.f, -0.0980171403f, -0.195090322f, -0.290284677f,
+    -0.382683432f, -0.471396737f, -0.555570233f, -0.634393284f, -0.707106781f, -0.773010453f, -0.831469612f, -0.881921264f, -0.923879533f,
+    -0.956940336f, -0.98078528f, -0.995184727f, -1.f, -0.995184727f, -0.98078528f, -0.956940336f, -0.923879533f, -0.881921264f, -0.831469612f,
+    -0.773010453f, -0.707106781f, -0.634393284f, -0.555570233f, -0.471396737f, -0.382683432f, -0.290284677f, -0.195090322f, -0.0980171403f,
+    0.f, 0.0980171403f, 0.195090322f, 0.290284677f, 0.382683432f, 0.471396737f, 0.555570233f, 0.634393284f, 0.707106781f, 0.773010453f,
+    0.831469612f, 0.881921264f, 0.923879533f, 0.956940336f, 0.98078528f, 0.995184727f};
+__device__ constexpr float kSin64[64] = {
+    0.f, 0.0980171403f, 0.195090322f, 0.290284677f, 0.382683432f, 0.471396737f, 0.555570233f, 0.634393284f, 0.707106781f, 0.773010453f,
+    0.831469612f, 0.881921264f, 0.923879533f, 0.956940336f, 0.98078528f, 0.995184727f, 1.f, 0.995184727f, 0.98078528f, 0.956940336f,
+    0.923879533f, 0.881921264f, 0.831469612f, 0.773010453f, 0.707106781f, 0.634393284f, 0.555570233f, 0.471396737f, 0.382683432f,
+    0.290284677f, 0.195090322f, 0.0980171403f, 0.f, -0.0980171403f, -0.195090322f, -0.290284677f, -0.382683432f, -0.471396737f, -0.555570233f,
+    -0.634393284f, -0.707106781f, -0.773010453f, -0.831469612f, -0.881921264f, -0.923879533f, -0.956940336f, -0.98078528f, -0.995184727f,
+    -1.f, -0.995184727f, -0.98078528f, -0.956940336f, -0.923879533f, -0.881921264f, -0.831469612f, -0.773010453f, -0.707106781f,
+    -0.634393284f, -0.555570233f, -0.471396737f, -0.382683432f, -0.290284677f, -0.195090322f, -0.0980171403f};
+
+__host__ __device__ constexpr int rev8(int k) { return ((k & 1) << 2) | (k & 2) | ((k >> 2) & 1); }
+
+// In-register 8-point DFT over v[0], v[S], ... v[7S] (decimation in frequency).  X[k] is left at v[rev8(k) * S].
+template <bool INV, int S> __device__ __forceinline__ void fft8(float2* v) {
+    constexpr float r = 0.70710678118654752f;
+    const float2 a0 = cadd(v[0], v[4 * S]), b0 = csub(v[0], v[4 * S]);
+    const float2 a1 = cadd(v[S], v[5 * S]), d1 = csub(v[S], v[5 * S]);
+    const float2 a2 = cadd(v[2 * S], v[6 * S]), d2 = csub(v[2 * S], v[6 * S]);
+    const float2 a3 = cadd(v[3 * S], v[7 * S]), d3 = csub(v[3 * S], v[7 * S]);
+    // odd half: * W8^n, n = 1, 2, 3 (forward W8 = exp(-j 2pi/8); inverse: conjugate)
+    const float2 b1 = INV ? make_float2((d1.x - d1.y) * r, (d1.x + d1.y) * r) : make_float2((d1.x + d1.y) * r, (d1.y - d1.x) * r);
+    const float2 b2 = mulj<INV>(d2);
+    const float2 b3 = INV ? make_float2((-d3.x - d3.y) * r, (d3.x - d3.y) * r) : make_float2((d3.y - d3.x) * r, (-d3.x - d3.y) * r);
+    // 4-point DFTs of (a0..a3) -> X[0,2,4,6] and of (b0..b3) -> X[1,3,5,7]
+    const float2 c0 = cadd(a0, a2), e0 = csub(a0, a2), c1 = cadd(a1, a3), e1 = mulj<INV>(csub(a1, a3));
+    const float2 f0 = cadd(b0, b2), g0 = csub(b0, b2), f1 = cadd(b1, b3), g1 = mulj<INV>(csub(b1, b3));
+    v[0] = cadd(c0, c1);          // X0
+    v[S] = csub(c0, c1);          // X4
+    v[2 * S] = cadd(e0, e1);      // X2
+    v[3 * S] = csub(e0, e1);      // X6
+    v[4 * S] = cadd(f0, f1);      // X1
+    v[5 * S] = csub(f0, f1);      // X5
+    v[6 * S] = cadd(g0, g1);      // X3
+    v[7 * S] = csub(g0, g1);      // X7
+}
+
+// value of `v` in the lane this one is paired with by the DPP control CTRL (all rows, all banks)
+template <int CTRL> __device__ __forceinline__ float dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+constexpr int kDppHalfMirror = 0x141;   // lane l <-> 7 - l inside each group of 8
+constexpr int kDppXor2 = 0x4E;          // quad_perm [2,3,0,1]
+constexpr int kDppXor1 = 0xB1;          // quad_perm [1,0,3,2]
+
+__device__ __forceinline__ float4 lds_read4(const float2* p) { return *reinterpret_cast<const float4*>(p); }
+
+}  // namespace
+
+// Segment b (one wave): input positions S0 + [0, 4096), S0 = 8 (b Lo - Q); outputs n' = b Lo + a' - (Q-1) for the
+// inverse's elements a' in [Q-1, 512).  Lane l = c + 8 g': column c = l & 7, g' = l >> 3.
+template <bool ROT>
+__global__ __launch_bounds__(kPfbNT, 2) void pfb_dec8_kernel(const PfbArgs a) {
+    __shared__ __attribute__((aligned(16))) float2 sTab[kPfbTableElems];          // G | TW | TI1 | TI2
+    __shared__ __attribute__((aligned(16))) float2 sEx[kPfbNT / 64][64 * kPfbRow];  // wave-private exchange buffers
+    const int t = threadIdx.x;
+    const int H = a.H;
+
+    if ((int)blockIdx.x == a.nwg) {
+        // history hand-over (resampling.h:129): last H samples of hist ++ in, in the form the handle keeps them
+        for (int i = t; i < H; i += kPfbNT) {
+            const long long g = a.count - H + i;
+            float2 v;
+            if (g < 0) {
+                v = a.hist_keep[g + H];
+                if (ROT && a.hist_raw_next) a.hist_raw_next[i] = a.hist[g + H];
+            } else {
+                v = a.in[g];
+                if (ROT) {
+                    const double2 p = fx_phasor(a.phase_in0 + (unsigned long long)g * a.dphase);
+                    const float gain = fmaf((float)(int)(g & 511), a.gm1, 1.0f);
+                    if (a.hist_raw_next) a.hist_raw_next[i] = make_float2(v.x * gain, v.y * gain);
+                    v = cmulc<false>(v, make_float2((float)p.x * gain, (float)p.y * gain));
+                }
+            }
+            a.hist_next[i] = v;
+        }
+        return;
+    }
+
+    // tables -> LDS, once per workgroup (51 KB from L2)
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.tables);
+        float4* dst = reinterpret_cast<float4*>(sTab);
+        for (int i = t; i < kPfbTableElems / 2; i += kPfbNT) dst[i] = src[i];
+    }
+    __syncthreads();
+    const float2* sG = sTab;
+    const float2* sTW = sTab + 512 * kPfbRow;
+    const float2* sTI1 = sTW + 64 * kPfbRow;
+    const float2* sTI2 = sTI1 + 64 * kPfbRow;
+
+    const int l = t & 63, wv = t >> 6;
+    float2* E = sEx[wv];
+    const int c = l & 7, hi3 = l >> 3;       // writer: (column, g'); round reader: (column, mu = kq)
+    const bool cb2 = (c & 4) != 0, cb1 = (c & 2) != 0, cb0 = (c & 1) != 0;
+
+    const int nwaves = a.nwg * (kPfbNT / 64);
+    const int wave0 = (int)blockIdx.x * (kPfbNT / 64) + wv;
+
+    float2 el = make_float2(1.0f, 0.0f);     // exp(j 2pi 8 l dphase): this lane's outputs sit at elements l + 64 b1
+    double2 pb = make_double2(1.0, 0.0);     // exp(j 2pi ph(first output of the segment)), advanced per segment
+    if (ROT) {
+        // output n' sits at stream position 8 n' - 1 and gets phase0 + (8 n' - 1) dphase; n' = b Lo - (Q-1) + a'.
+        // Lane part from the host's table, segment part from exactly rounded FP64 powers of the per-segment step:
+        // no sincos in this kernel (it cost a small call ~6 us at launch)
+        el = sTI2[8 * kPfbRow + l];
+        pb = a.pb_base;
+#pragma unroll
+        for (int k = 0; k < 12; k++)
+            if ((wave0 >> k) & 1) pb = dcmul(pb, a.seg_pow[k]);
+    }
+
+    // Software pipeline: the NEXT segment's rows are requested during the rounds of the current one, each row into
+    // the registers a round has just emptied (row 8 rev8(rho) + q' dies in round rho), so the loads have the rest of the
+    // rounds and the whole inverse to land and the wave never sits on an empty segment (PMC of the first version: 37 %
+    // of wave cycles in s_waitcnt vmcnt at 2 waves per SIMD).  A segment that is not interior (history / zero fill at
+    // the ends of the call) is re-read through the checked path when its turn comes; the prefetch for it reads a
+    // clamped in-range address and is discarded.
+    const long long last_start = a.count - kPfbSeg;       // (the dispatch guarantees count >= 4096)
+    auto seg_start = [&](int b) { return 8LL * ((long long)b * a.Lo - a.Q); };
+    auto clamped = [&](long long s0) { return s0 < 0 ? 0LL : (s0 > last_start ? last_start : s0); };
+    float2 v[64];
+    {
+        const float2* __restrict__ p = a.in + clamped(seg_start(wave0 < a.nseg ? wave0 : 0)) + l;
+#pragma unroll
+        for (int r = 0; r < 64; r++) v[r] = p[64 * r];
+    }
+#pragma unroll 1
+    for (int b = wave0; b < a.nseg; b += nwaves) {
+        const long long S0 = seg_start(b);
+        // ---- v[8 j + q'] = seg[512 j + 64 q' + l] (whole 512-byte rows), already requested ---------------------
+        if (S0 >= 0 && S0 <= last_start) {
+            if (ROT && a.gm1 != 0.0f) {
+                // VOLK's magnitude sawtooth 1 + (g mod 512) gm1 on the INPUT samples: g = S0 + 512 j + 64 q' + l takes
+                // eight values per lane and segment (512 j drops out)
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const float gg = fmaf((float)(int)((S0 + 64 * q + l) & 511), a.gm1, 1.0f);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) v[8 * j + q] = make_float2(v[8 * j + q].x * gg, v[8 * j + q].y * gg);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 64; r++) {
+                const long long g = S0 + 64 * r + l;
+                float2 x = make_float2(0.0f, 0.0f);
+                if (g < 0) { if (g + H >= 0) x = a.hist[g + H]; }       // (ROT: de-rotated by the host side, gain kept)
+                else if (g < a.count) {
+                    x = a.in[g];
+                    if (ROT && a.gm1 != 0.0f) {
+                        const float gg = fmaf((float)(int)(g & 511), a.gm1, 1.0f);
+                        x = make_float2(x.x * gg, x.y * gg);
+                    }
+                }
+                v[r] = x;
+            }
+        }
+        // where this wave's next segment starts (clamped into the buffer: see above)
+        const float2* __restrict__ pn = a.in + clamped(seg_start(b + nwaves < a.nseg ? b + nwaves : b)) + l;
+        float2 vn[64];
+        // ---- forward, column index a = 64 j + 8 q' + g', bin k = k0 + 8 kq + 64 kg ----------------------------
+        // pass 1 over j (for every q'): A[k0][q'] at v[8 rev8(k0) + q']
+#pragma unroll
+        for (int q = 0; q < 8; q++) fft8<false, 8>(v + q);
+        // twiddle W64^(q' k0): compile-time constants once the loops are unrolled
+#pragma unroll
+        for (int k0 = 1; k0 < 8; k0++) {
+#pragma unroll
+            for (int q = 1; q < 8; q++) {
+                const int n = (k0 * q) & 63;
+                const float wc = kCos64[n], ws = -kSin64[n];      // W64^n = wc + j ws
+                const float2 x = v[8 * rev8(k0) + q];
+                v[8 * rev8(k0) + q] = make_float2(fmaf(x.x, wc, -x.y * ws), fmaf(x.x, ws, x.y * wc));
+            }
+        }
+        // pass 2 over q' (for every k0): B[k0][kq] at v[8 rev8(k0) + rev8(kq)]
+#pragma unroll
+        for (int r = 0; r < 8; r++) fft8<false, 1>(v + 8 * r);
+
+        // ---- eight rounds (k0 = rho): exchange over g', last pass, spectrum product, column sum --------------
+        float2 yr[8];   // yr[rho] = Y[rho + 8 mu + 64 c]   (mu = l >> 3, c = l & 7 after the reduce-scatter)
+#pragma unroll
+        for (int rho = 0; rho < 8; rho++) {
+            // writer (g', c): B[rho][kq] -> row (kq, c), column g'
+#pragma unroll
+            for (int kq = 0; kq < 8; kq++) E[(kq * 8 + c) * kPfbRow + hi3] = v[8 * rev8(rho) + rev8(kq)];
+            // the registers of row group rev8(rho) are free now: request the same rows of the next segment
+#pragma unroll
+            for (int q = 0; q < 8; q++) vn[8 * rev8(rho) + q] = pn[64 * (8 * rev8(rho) + q)];
+            __builtin_amdgcn_wave_barrier();
+            // reader (c, mu = kq): row l holds the eight g' of bin prefix m = rho + 8 mu
+            float2 r8[8], tw[8], gg[8];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float4 x = lds_read4(E + l * kPfbRow + 2 * i);
+                r8[2 * i] = make_float2(x.x, x.y);
+                r8[2 * i + 1] = make_float2(x.z, x.w);
+                const float4 w4 = lds_read4(sTW + (rho * 8 + hi3) * kPfbRow + 2 * i);
+                tw[2 * i] = make_float2(w4.x, w4.y);
+                tw[2 * i + 1] = make_float2(w4.z, w4.w);
+                const float4 g4 = lds_read4(sG + (rho * 64 + l) * kPfbRow + 2 * i);
+                gg[2 * i] = make_float2(g4.x, g4.y);
+                gg[2 * i + 1] = make_float2(g4.z, g4.w);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // twiddle W512^(g' m), pass 3 over g' -> X_c[m + 64 kg] at r8[rev8(kg)]
+#pragma unroll
+            for (int g = 1; g < 8; g++) r8[g] = cmulc<false>(r8[g], tw[g]);
+            fft8<false, 1>(r8);
+            float2 pr[8];   // pr[kg] = G_c[k] X_c[k]
+#pragma unroll
+            for (int kg = 0; kg < 8; kg++) pr[kg] = cmulc<false>(r8[rev8(kg)], gg[kg]);
+            // reduce-scatter over the eight columns (lanes c = 0..7 of each group of 8): lane c ends up with the sum for kg = c
+            float2 s4[4], s2[2];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {   // partner 7 - c: differs in bit 2; keep the half kg bit 2 == c bit 2
+                const float2 keep = cb2 ? pr[4 + i] : pr[i], send = cb2 ? pr[i] : pr[4 + i];
+                s4[i] = make_float2(keep.x + dpp<kDppHalfMirror>(send.x), keep.y + dpp<kDppHalfMirror>(send.y));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++) {   // partner c ^ 2
+                const float2 keep = cb1 ? s4[2 + i] : s4[i], send = cb1 ? s4[i] : s4[2 + i];
+                s2[i] = make_float2(keep.x + dpp<kDppXor2>(send.x), keep.y + dpp<kDppXor2>(send.y));
+            }
+            {                               // partner c ^ 1
+                const float2 keep = cb0 ? s2[1] : s2[0], send = cb0 ? s2[0] : s2[1];
+                yr[rho] = make_float2(keep.x + dpp<kDppXor1>(send.x), keep.y + dpp<kDppXor1>(send.y));
+            }
+        }
+
+        // ---- inverse 512-point transform of Y: y[a'] = sum_k Y[k] V^(a' k), V = exp(+j 2pi/512) ---------------
+        // I0: lane (kg = c, mu) holds Y[rho + 8 mu + 64 kg]  ->  lane m reads Y[m + 64 kg], kg = 0..7
+#pragma unroll
+        for (int rho = 0; rho < 8; rho++) E[(rho + 8 * hi3) * 9 + c] = yr[rho];
+        __builtin_amdgcn_wave_barrier();
+        float2 z[8];
+#pragma unroll
+        for (int kg = 0; kg < 8; kg++) z[kg] = E[l * 9 + kg];
+        __builtin_amdgcn_wave_barrier();
+        // pass I1 over kg -> alpha = a' mod 8 at z[rev8(alpha)]; twiddle V512^(m alpha)
+        fft8<true, 1>(z);
+        float2 zt[8];
+        zt[0] = z[0];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float4 w4 = lds_read4(sTI1 + l * kPfbRow + 2 * i);
+            if (i) zt[2 * i] = cmulc<false>(z[rev8(2 * i)], make_float2(w4.x, w4.y));
+            zt[2 * i + 1] = cmulc<false>(z[rev8(2 * i + 1)], make_float2(w4.z, w4.w));
+        }
+        // I2: row alpha, column m  ->  lane (m0 = l & 7, alpha = l >> 3) reads m = m0 + 8 m1
+#pragma unroll
+        for (int al = 0; al < 8; al++) E[al * 72 + l] = zt[al];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int m1 = 0; m1 < 8; m1++) z[m1] = E[hi3 * 72 + c + 8 * m1];
+        __builtin_amdgcn_wave_barrier();
+        // pass I2 over m1 -> b0 at z[rev8(b0)]; twiddle V64^(m0 b0)   (a' = alpha + 8 b0 + 64 b1)
+        fft8<true, 1>(z);
+        zt[0] = z[0];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float4 w4 = lds_read4(sTI2 + c * kPfbRow + 2 * i);
+            if (i) zt[2 * i] = cmulc<false>(z[rev8(2 * i)], make_float2(w4.x, w4.y));
+            zt[2 * i + 1] = cmulc<false>(z[rev8(2 * i + 1)], make_float2(w4.z, w4.w));
+        }
+        // I3: row (b0, alpha), column m0  ->  lane alpha + 8 b0 reads its row
+#pragma unroll
+        for (int b0 = 0; b0 < 8; b0++) E[(8 * b0 + hi3) * 9 + c] = zt[b0];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int m0 = 0; m0 < 8; m0++) z[m0] = E[l * 9 + m0];
+        __builtin_amdgcn_wave_barrier();
+        // pass I3 over m0 -> b1 at z[rev8(b1)]: element a' = l + 64 b1
+        fft8<true, 1>(z);
+
+        // ---- store the Lo valid outputs, rotated by the NCO (fused VFO) ------------------------------------
+        float2 q = make_float2(1.0f, 0.0f);
+        if (ROT) {
+            q = cmulc<false>(make_float2((float)pb.x, (float)pb.y), el);
+            pb = dcmul(pb, a.rot_step);
+        }
+        const long long nb = (long long)b * a.Lo - (a.Q - 1);
+#pragma unroll
+        for (int b1 = 0; b1 < 8; b1++) {
+            const int ap = l + 64 * b1;
+            const long long n = nb + ap;
+            float2 y = z[rev8(b1)];
+            if (ROT) y = cmulc<false>(y, (b1 == 0) ? q : cmulc<false>(q, a.wtab[b1]));
+            if (ap >= a.Q - 1 && n < a.nout) a.out[n] = y;
+        }
+#pragma unroll
+        for (int r = 0; r < 64; r++) v[r] = vn[r];
+    }
+}
+
+int launch_pfb_dec(const PfbArgs& a, hipStream_t stream) {
+    if (a.rot) hipLaunchKernelGGL((pfb_dec8_kernel<true>), dim3(a.nwg + 1), dim3(kPfbNT), 0, stream, a);
+    else hipLaunchKernelGGL((pfb_dec8_kernel<false>), dim3(a.nwg + 1), dim3(kPfbNT), 0, stream, a);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
+}  // namespace qk

@@ -5,6 +5,7 @@
 #include "kernels.hip.h"
 #include "fft_fir.hip.h"
 #include "chan.hip.h"
+#include "pfb_dec.hip.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -87,6 +88,10 @@ struct Engine {
     float2* d_fft_TB = nullptr;
     int fft_ntaps = -1;         // tap count d_fft_H was built for (-1: not built)
     unsigned long long fft_dphase = 0;   // NCO increment d_fft_H was built for (fused VFO), 0 otherwise
+    // polyphase overlap-save decimate-by-8 (pfb_dec.hip.h): column spectra + twiddles, built for (pfb_ntaps, pfb_dphase)
+    float2* d_pfb = nullptr;
+    int pfb_ntaps = -1;
+    unsigned long long pfb_dphase = 0;
     std::vector<float> taps_host;
     // A retune (set_phase_inc) may come from a control thread while the worker is inside process*: the new
     // increment is staged here as the two float bit patterns (0 = nothing staged: a zero increment is refused)
@@ -293,6 +298,7 @@ int configure(Engine* e, const float* taps, int ntaps, int interp, int decim) {
     if (rc) return rc;
     e->taps_host.assign(taps, taps + ntaps);
     e->fft_ntaps = -1;
+    e->pfb_ntaps = -1;
     const size_t bytes = (size_t)(newH > 0 ? newH : 1) * e->ch * sizeof(float);
     float* nh[2] = {nullptr, nullptr};
     for (int i = 0; i < 2; i++) {
@@ -398,6 +404,7 @@ void destroy(Engine* e) {
     if (e->d_fft_H) (void)hipFree(e->d_fft_H);
     if (e->d_fft_TA) (void)hipFree(e->d_fft_TA);
     if (e->d_fft_TB) (void)hipFree(e->d_fft_TB);
+    if (e->d_pfb) (void)hipFree(e->d_pfb);
     for (int i = 0; i < 2; i++)
         if (e->d_hist[i]) (void)hipFree(e->d_hist[i]);
     if (e->d_in) (void)hipFree(e->d_in);
@@ -846,7 +853,167 @@ int fft_prepare(Engine* e) {
 int launch_xlate_inc(Engine* e, const void* d_in, int64_t count, void* d_out, unsigned long long phase0, unsigned long long dphase, float gm1,
                      hipStream_t s);
 
+// ---- polyphase overlap-save decimate-by-8 (pfb_dec.hip) ---------------------------------------------
+// Serves PolyphaseResampler<complex_t> / the fused VFO with interp 1, decim 8 on calls big enough to fill the chip
+// with one segment per wave (8 waves per CU: measured crossover against the per-segment fir_fft_kernel<8> in
+// scripts/tune_call_size.py).
+bool pfb_eligible(const Engine* e, int64_t count) {
+    if (e->ch != 2 || e->L != 1 || e->M != qk::kPfbD || e->ntaps < 2) return false;
+    if (e->kind != KIND_DECIM && e->kind != KIND_VFO) return false;
+    if ((e->ntaps + qk::kPfbD - 1) / qk::kPfbD > qk::kPfbMaxQ) return false;
+    if (env_int("QDSP_HIP_NO_PFB", 0)) return false;
+    // measured crossover (scripts/tune_pfb_threshold.py, 256 taps): a lone segment takes a wave ~7 us (15 us per call
+    // with the table load) where fir_fft_kernel<8> needs 8 us, so the per-segment kernels keep the reference-sized
+    // calls; from 2^23 samples (decimator) / 2^24 (fused VFO) on this form is ahead, 1.2x at 2^27
+    return count >= (int64_t)env_int("QDSP_HIP_PFB_MIN_COUNT", e->rotate ? 1 << 24 : 1 << 23);
+}
+
+int pfb_prepare(Engine* e) {
+    const unsigned long long key_dphase = e->rotate ? e->dphase : 0;
+    if (e->pfb_ntaps == e->ntaps && e->d_pfb && e->pfb_dphase == key_dphase) return 0;
+    constexpr int F = qk::kPfbF, D = qk::kPfbD, R = qk::kPfbRow;
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    const int N = e->ntaps, Q = (N + D - 1) / D;
+    // g[j] = taps[N-1-j] (x exp(j (N-1-j) dphase) for the fused VFO: the mixer folded into the taps, fft_fir.hip.h)
+    std::vector<long double> gr((size_t)Q * D, 0.0L), gi((size_t)Q * D, 0.0L);
+    for (int j = 0; j < N; j++) {
+        const long double h = (long double)e->taps_host[N - 1 - j];
+        long double c = 1.0L, sn = 0.0L;
+        if (e->rotate) {
+            const long double tt = ldexpl((long double)e->dphase, -64) * (long double)(N - 1 - j);
+            c = cosl(two_pi * (tt - floorl(tt)));
+            sn = sinl(two_pi * (tt - floorl(tt)));
+        }
+        gr[j] = h * c;
+        gi[j] = h * sn;
+    }
+    std::vector<long double> cs(F), ss(F);
+    for (int i = 0; i < F; i++) { cs[i] = cosl(two_pi * i / F); ss[i] = sinl(two_pi * i / F); }
+    std::vector<float2> tab((size_t)qk::kPfbTableElems, make_float2(0.0f, 0.0f));
+    // G: row (k0*64 + kq*8 + c), element kg: spectrum of column c's filter gamma_c[q] = g[8q + 7 - c] at bin k0 + 8 kq + 64 kg, / 512
+    for (int c = 0; c < D; c++)
+        for (int k = 0; k < F; k++) {
+            long double re = 0.0L, im = 0.0L;
+            for (int q = 0; q < Q; q++) {
+                const int j = D * q + (D - 1 - c), idx = (int)(((long long)q * k) % F);
+                re += gr[j] * cs[idx] + gi[j] * ss[idx];      // (gr + j gi)(cs - j ss)
+                im += gi[j] * cs[idx] - gr[j] * ss[idx];
+            }
+            const int k0 = k & 7, kq = (k >> 3) & 7, kg = k >> 6;
+            tab[(size_t)((k0 * 64 + kq * 8 + c) * R + kg)] = make_float2((float)(re / F), (float)(im / F));
+        }
+    float2* TW = tab.data() + 512 * R;     // row (k0*8 + kq), element g': W512^(g' (k0 + 8 kq))
+    for (int k0 = 0; k0 < 8; k0++)
+        for (int kq = 0; kq < 8; kq++)
+            for (int g = 0; g < 8; g++) {
+                const int idx = (g * (k0 + 8 * kq)) % F;
+                TW[(k0 * 8 + kq) * R + g] = make_float2((float)cs[idx], (float)(-ss[idx]));
+            }
+    float2* TI1 = TW + 64 * R;             // row m, element alpha: exp(+j 2pi m alpha / 512)
+    for (int m = 0; m < 64; m++)
+        for (int al = 0; al < 8; al++) TI1[m * R + al] = make_float2((float)cs[(m * al) % F], (float)ss[(m * al) % F]);
+    float2* TI2 = TI1 + 64 * R;            // row m0, element b0: exp(+j 2pi m0 b0 / 64)
+    for (int m0 = 0; m0 < 8; m0++)
+        for (int b0 = 0; b0 < 8; b0++) TI2[m0 * R + b0] = make_float2((float)cs[(8 * m0 * b0) % F], (float)ss[(8 * m0 * b0) % F]);
+    float2* EL = TI2 + 8 * R;              // exp(j 2pi 8 l dphase): the NCO over a lane's element offset (fused VFO)
+    for (int l = 0; l < 64; l++) {
+        double c = 1.0, sn = 0.0;
+        if (e->rotate) unit_of_fx(e->dphase, (long double)(8 * l), &c, &sn);
+        EL[l] = make_float2((float)c, (float)sn);
+    }
+    if (!e->d_pfb) HIPCHK(hipMalloc(&e->d_pfb, tab.size() * sizeof(float2)));
+    HIPCHK(hipDeviceSynchronize());   // (retune / new taps: nothing in flight may still read the old tables)
+    HIPCHK(hipMemcpy(e->d_pfb, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice));
+    e->pfb_ntaps = N;
+    e->pfb_dphase = key_dphase;
+    return 0;
+}
+
+int launch_xlate_inc(Engine* e, const void* d_in, int64_t count, void* d_out, unsigned long long phase0, unsigned long long dphase, float gm1,
+                     hipStream_t s);
+
+// The overlap-save kernels of the fused VFO filter RAW samples while the handle keeps its history rotated (the direct
+// kernels and *_set_history_dev use that form; a call may switch form with its size): the H samples are de-rotated once
+// per call into a side buffer -- exp(-j phi(g)), g = -H .. -1 -- unless the previous overlap-save call left them there.
+int raw_history(Engine* e, hipStream_t s, const float2** hist, float2** hist_raw_next) {
+    *hist_raw_next = nullptr;
+    if (!(e->rotate && e->H > 0)) return 0;
+    if (!e->d_hist_raw[0] || e->hist_raw_cap < e->H) {
+        for (int i = 0; i < 2; i++) {
+            if (e->d_hist_raw[i]) HIPCHK(hipFree(e->d_hist_raw[i]));
+            e->d_hist_raw[i] = nullptr;
+            HIPCHK(hipMalloc(&e->d_hist_raw[i], (size_t)e->H * sizeof(float2)));
+        }
+        e->hist_raw_cap = e->H;
+        e->raw_valid = false;
+    }
+    if (!e->raw_valid || env_int("QDSP_HIP_NO_RAW_CARRY", 0)) {
+        const unsigned long long ph_first = e->phase - (unsigned long long)e->H * e->dphase;   // phase of history sample 0
+        const Launch keep = e->last;
+        const int rc = launch_xlate_inc(e, e->d_hist[e->cur], e->H, e->d_hist_raw[e->cur], 0ULL - ph_first, 0ULL - e->dphase, 0.0f, s);
+        e->last = keep;
+        if (rc) return rc;
+    }
+    *hist = reinterpret_cast<const float2*>(e->d_hist_raw[e->cur]);
+    *hist_raw_next = reinterpret_cast<float2*>(e->d_hist_raw[e->cur ^ 1]);
+    return 0;
+}
+
+int launch_pfb(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d_out, hipStream_t s) {
+    int rc = pfb_prepare(e);
+    if (rc) return rc;
+    qk::PfbArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = static_cast<const float2*>(d_in);
+    a.out = static_cast<float2*>(d_out);
+    a.hist = reinterpret_cast<const float2*>(e->d_hist[e->cur]);
+    a.hist_keep = a.hist;
+    a.hist_next = reinterpret_cast<float2*>(e->d_hist[e->cur ^ 1]);
+    rc = raw_history(e, s, &a.hist, &a.hist_raw_next);
+    if (rc) return rc;
+    a.tables = e->d_pfb;
+    a.count = count;
+    a.nout = nout;
+    a.H = e->H;
+    a.Q = (e->ntaps + qk::kPfbD - 1) / qk::kPfbD;
+    a.Lo = qk::kPfbF + 1 - a.Q;
+    a.nseg = (int)((nout + a.Lo - 1) / a.Lo);
+    // persistent workgroups of 4 waves, one segment per wave at a time; 2 workgroups resident per CU (72 KB of LDS,
+    // ~220 VGPRs), QDSP_HIP_PFB_WG_PER_CU queued per CU
+    int nwg = 256 * env_int("QDSP_HIP_PFB_WG_PER_CU", 2);
+    if (nwg > 1024) nwg = 1024;
+    const int need = (a.nseg + 3) / 4;
+    if (nwg > need) nwg = need;
+    if (nwg < 1) nwg = 1;
+    a.nwg = nwg;
+    a.rot = e->rotate ? 1 : 0;
+    if (a.rot) {
+        a.phase_in0 = e->phase;
+        a.phase0 = e->phase - (unsigned long long)(e->ntaps - 1) * e->dphase;
+        a.dphase = e->dphase;
+        a.gm1 = e->volk_gain ? e->gm1 : 0.0f;
+        unit_of_fx(e->dphase, 8.0L * (long double)a.Lo * (long double)(4 * nwg), &a.rot_step.x, &a.rot_step.y);
+        if (4 * nwg > 4096) return QDSP_HIP_EINVAL;     // (seg_pow covers wave indices below 2^12)
+        unit_of_fx(a.phase0 - (unsigned long long)(8 * (a.Q - 1) + 1) * a.dphase, 1.0L, &a.pb_base.x, &a.pb_base.y);
+        for (int k = 0; k < 12; k++) unit_of_fx(e->dphase, 8.0L * (long double)a.Lo * (long double)(1 << k), &a.seg_pow[k].x, &a.seg_pow[k].y);
+        for (int b1 = 0; b1 < 8; b1++) {
+            double c, sn;
+            unit_of_fx(e->dphase, (long double)(512 * b1), &c, &sn);
+            a.wtab[b1] = make_float2((float)c, (float)sn);
+        }
+    }
+    rc = qk::launch_pfb_dec(a, s);
+    if (rc) return rc;
+    e->raw_valid = e->rotate && e->H > 0;   // (the caller flips cur: the raw hand-over then sits at d_hist_raw[cur])
+    e->last.name = "pfb_dec8_kernel";
+    e->last.grid = nwg + 1;
+    e->last.block = qk::kPfbNT;
+    e->last.lds = (int)((qk::kPfbTableElems + 4 * 64 * qk::kPfbRow) * sizeof(float2));
+    return 0;
+}
+
 int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d_out, hipStream_t s) {
+    if (pfb_eligible(e, count)) return launch_pfb(e, d_in, count, nout, d_out, s);
     int rc = fft_prepare(e);
     if (rc) return rc;
     qk::FftArgs a;
@@ -856,30 +1023,8 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
     a.hist = reinterpret_cast<const float2*>(e->d_hist[e->cur]);
     a.hist_keep = a.hist;
     a.hist_next = reinterpret_cast<float2*>(e->d_hist[e->cur ^ 1]);
-    if (e->rotate && e->H > 0) {
-        // The history is kept rotated (the direct kernels and *_set_history_dev use that form; a call may switch
-        // form with its size), the overlap-save kernels filter RAW samples: de-rotate the H samples once per call
-        // into a side buffer -- exp(-j phi(g)), g = -H .. -1 -- instead of carrying an FP64 sincos in the first
-        // segment's load path of the big kernel (its registers cost the grouped kernel 20 spilled VGPRs).
-        if (!e->d_hist_raw[0] || e->hist_raw_cap < e->H) {
-            for (int i = 0; i < 2; i++) {
-                if (e->d_hist_raw[i]) HIPCHK(hipFree(e->d_hist_raw[i]));
-                e->d_hist_raw[i] = nullptr;
-                HIPCHK(hipMalloc(&e->d_hist_raw[i], (size_t)e->H * sizeof(float2)));
-            }
-            e->hist_raw_cap = e->H;
-            e->raw_valid = false;
-        }
-        if (!e->raw_valid || env_int("QDSP_HIP_NO_RAW_CARRY", 0)) {
-            const unsigned long long ph_first = e->phase - (unsigned long long)e->H * e->dphase;   // phase of history sample 0
-            const Launch keep = e->last;
-            rc = launch_xlate_inc(e, e->d_hist[e->cur], e->H, e->d_hist_raw[e->cur], 0ULL - ph_first, 0ULL - e->dphase, 0.0f, s);
-            e->last = keep;
-            if (rc) return rc;
-        }
-        a.hist = reinterpret_cast<const float2*>(e->d_hist_raw[e->cur]);
-        a.hist_raw_next = reinterpret_cast<float2*>(e->d_hist_raw[e->cur ^ 1]);
-    }
+    rc = raw_history(e, s, &a.hist, &a.hist_raw_next);
+    if (rc) return rc;
     a.Hf = e->d_fft_H;
     a.TA = e->d_fft_TA;
     a.TB = e->d_fft_TB;

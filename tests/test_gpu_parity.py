@@ -270,6 +270,67 @@ def test_fft_decimator_vs_oracle(ops, dec, ntaps):
     assert rel_rms(y, run_blocks(d, x, sizes)) < TOL_FFT
 
 
+@pytest.mark.parametrize("rot", [False, True])
+@pytest.mark.parametrize("ntaps", [2, 17, 64, 255, 256, 257, 700, 1024])
+def test_polyphase_overlap_save_decimator_vs_oracle(ops, monkeypatch, ntaps, rot):
+    """pfb_dec8_kernel (qdsp_amd/csrc/pfb_dec.hip): decimate-by-8 as eight 512-point transforms of the polyphase columns,
+    one wave per segment -- the form large calls take (AUTO: >= 2^23 samples; forced here at test size).  Ragged calls:
+    the first segment reads the history, the last ones are zero-filled, call lengths that are no multiple of a
+    segment's 481 outputs, a call shorter than one segment; history and NCO carried across calls; against the FP64
+    oracle and, for the fused VFO, inside the north_star bar against the reference's recursive phasor on the first
+    8192 samples."""
+    import torch
+
+    monkeypatch.setenv("QDSP_HIP_PFB_MIN_COUNT", "0")
+    taps = O.lowpass_taps_f64(ntaps, 1 / 16).astype(np.float32) if ntaps > 8 else np.arange(1, ntaps + 1, dtype=np.float32)
+    x = O.synth_iq(0, 500_000, seed=800 + ntaps)
+    cuts = [0, 8 * 13001, 8 * 13001 + 8 * 9, 8 * 30000 + 3, 8 * 30000 + 4096 + 3, 500_000]
+    inc = ops.phase_delta(1.0, 0.1234)
+    op = ops.Vfo(taps, 1, 8, inc, max_block=0) if rot else ops.Resampler(taps, 1, 8, max_block=0)
+    op.set_mode(op.FFT)
+    ys = []
+    for a, b in zip(cuts, cuts[1:]):
+        ys.append(op.process(dev(x[a:b])).cpu().numpy())
+        assert op.last_kernel()["name"] == "pfb_dec8_kernel"
+    torch.cuda.synchronize()
+    y = np.concatenate(ys)
+    rs = O.Resampler(taps, 1, 8, acc=O.ACC_F64)
+    xl = O.Xlator(1.0, 0.1234, exact=True, volk_gain=True)
+    want = np.concatenate([rs.process(xl.process(x[a:b]) if rot else x[a:b]) for a, b in zip(cuts, cuts[1:])])
+    assert len(y) == len(want) and rel_rms(y, want) < 1e-6          # measured ~2e-7: 512-point transforms round less than 4096-point ones
+    assert np.abs(y - want).max() < 4e-6 * np.abs(want).max()
+    if rot:
+        g, rg = O.Xlator(1.0, 0.1234), O.Resampler(taps, 1, 8)
+        wg = rg.process(g.process(x[:8192]))
+        assert rel_rms(y[:1024], wg) < TOL_RMS
+    # the same stream through the 4096-point kernels and the direct form: one operator, three factorizations
+    monkeypatch.setenv("QDSP_HIP_NO_PFB", "1")
+    op2 = ops.Vfo(taps, 1, 8, inc, max_block=0) if rot else ops.Resampler(taps, 1, 8, max_block=0)
+    op2.set_mode(op2.FFT)
+    y2 = np.concatenate([op2.process(dev(x[a:b])).cpu().numpy() for a, b in zip(cuts, cuts[1:])])
+    assert op2.last_kernel()["name"] == "fir_fft_kernel" and rel_rms(y, y2) < 2e-6
+    assert np.allclose(op.get_history(), op2.get_history(), rtol=0, atol=2e-6)       # same (rotated) history handed over
+
+
+def test_polyphase_overlap_save_decimator_switches_forms_mid_stream(ops, gold, monkeypatch):
+    """A stream whose calls alternate between the polyphase kernel (big calls) and the direct / 4096-point forms (small
+    calls): the history each leaves -- rotated, plus the raw side copy of the overlap-save forms -- serves the next."""
+    taps = gold["taps256"]
+    x = O.synth_iq(0, 300_000, seed=31)
+    inc = ops.phase_delta(1.0, 0.1234)
+    monkeypatch.setenv("QDSP_HIP_PFB_MIN_COUNT", "100000")
+    op = ops.Vfo(taps, 1, 8, inc, max_block=0)
+    cuts = [0, 120_000, 120_000 + 4096, 240_000, 240_008, 300_000]
+    ys, names = [], []
+    for a, b in zip(cuts, cuts[1:]):
+        ys.append(op.process(dev(x[a:b])).cpu().numpy())
+        names.append(op.last_kernel()["name"])
+    assert names[0] == "pfb_dec8_kernel" and names[2] == "pfb_dec8_kernel" and names[1] != "pfb_dec8_kernel"
+    xl, rs = O.Xlator(1.0, 0.1234, exact=True, volk_gain=True), O.Resampler(taps, 1, 8, acc=O.ACC_F64)
+    want = np.concatenate([rs.process(xl.process(x[a:b])) for a, b in zip(cuts, cuts[1:])])
+    assert rel_rms(np.concatenate(ys), want) < 2e-6
+
+
 @pytest.mark.parametrize("dec", [3, 5, 10, 17, 64])
 @pytest.mark.parametrize("ntaps", [97, 256])
 def test_fft_any_decimation_vs_oracle(ops, dec, ntaps):
@@ -1099,7 +1160,7 @@ def test_vfo_history_forms_across_kernel_switches(ops, gold):
 
 def test_calls_beyond_2_31_samples(ops, gold):
     """One call of 2^31 + 65553 samples (16 GiB in: sample indices past 2^31, byte offsets past 2^34) through the mixer,
-    the overlap-save FIR, the grouped decimator and the large-decimation direct kernel.  Windows right after the 2^31
+    the overlap-save FIR, the polyphase overlap-save decimator and the large-decimation direct kernel.  Windows right after the 2^31
     boundary and at the very end are recomputed by a fresh instance on a short slice (started on a multiple of
     lcm(512, decim) so that the polyphase counter, the NCO -- advanced to the slice start -- and VOLK's gain
     sawtooth line up) and must agree."""
@@ -1115,7 +1176,8 @@ def test_calls_beyond_2_31_samples(ops, gold):
     plans = [
         ("xlate", 1, 0, lambda: ops.Xlator(phase_inc=inc, max_block=0), "xlate_kernel"),
         ("fir256", 1, 256, lambda: ops.Fir(gold["taps256"], max_block=0), "fir_fft_kernel"),
-        ("vfo8", 8, 256, lambda: ops.Vfo(gold["taps256"], 1, 8, inc, max_block=0), "fir_fft_kernel"),
+        # (the big call takes the polyphase one-wave-per-segment kernel, the 66 000-sample reference slices the 4096-point one)
+        ("vfo8", 8, 256, lambda: ops.Vfo(gold["taps256"], 1, 8, inc, max_block=0), "pfb_dec8_kernel"),
         ("vfo50", 50, 401, lambda: ops.Vfo(t401, 1, 50, inc, max_block=0), "resamp_any_kernel"),
     ]
     for name, M, ntaps, mk, kernel in plans:
@@ -1143,10 +1205,11 @@ def test_calls_beyond_2_31_samples(ops, gold):
         torch.cuda.empty_cache()
 
 
-def test_bench_size_cross_checks(ops, gold):
+def test_bench_size_cross_checks(ops, gold, monkeypatch):
     """The bench's size (2^27 samples per call = 1 GiB in: byte offsets past 2^31): independent kernels must agree.
-    Overlap-save FIR vs direct form; fused overlap-save VFO vs NCO kernel -> decimator; polyphase channelizer vs
-    one fused kernel per channel; spot windows of the FIR against the CPU oracle."""
+    Overlap-save FIR vs direct form; fused polyphase overlap-save VFO (pfb_dec8_kernel) vs NCO kernel -> 4096-point
+    overlap-save decimator; polyphase channelizer vs one fused kernel per channel; spot windows of the FIR and of the
+    fused VFO against the CPU oracle."""
     import torch
 
     n = 1 << 27
@@ -1170,9 +1233,28 @@ def test_bench_size_cross_checks(ops, gold):
     inc = ops.phase_delta(1.0, 0.1234)
     v = ops.Vfo(taps, 1, 8, inc)
     yv = v.process(x)
-    assert v.last_kernel()["name"] == "fir_fft_kernel" and yv.numel() == n // 8
+    assert v.last_kernel()["name"] == "pfb_dec8_kernel" and yv.numel() == n // 8
+    for start in (0, (1 << 26) + 8 * 1543, n - 8 * 9000):        # oracle windows of the fused VFO, incl. past the 2^31-byte mark
+        lo = max(start - 256, 0)
+        xh = O.synth_iq(lo, 65_536 + (start - lo), seed=1234)
+        xlo = O.Xlator(1.0, 0.1234, exact=True, volk_gain=True)
+        dt = np.arctan2(float(xlo.delta[1]), float(xlo.delta[0])) / (2 * np.pi)
+        xlo.turns.value = (lo * dt) % 1.0
+        rot = xlo.process(xh) if lo % 512 == 0 else None
+        if rot is None:                                           # keep the VOLK gain sawtooth aligned: rotate from a multiple of 512
+            lo2 = lo - lo % 512
+            xh2 = O.synth_iq(lo2, 65_536 + (start - lo2), seed=1234)
+            xlo.turns.value = (lo2 * dt) % 1.0
+            rot = xlo.process(xh2)[lo - lo2:]
+        want = O.Resampler(taps, 1, 8, acc=O.ACC_F64).process(rot)[(start - lo) // 8:]
+        got = yv[start // 8:start // 8 + len(want)].cpu().numpy()
+        sl = slice(40 if start else 0, None)
+        assert rel_rms(got[sl], want[sl]) < 2e-6, start
+    monkeypatch.setenv("QDSP_HIP_NO_PFB", "1")
     xl, rs = ops.Xlator(phase_inc=inc), ops.Resampler(taps, 1, 8)
     y2 = rs.process(xl.process(x))
+    assert rs.last_kernel()["name"] == "fir_fft_kernel"
+    monkeypatch.delenv("QDSP_HIP_NO_PFB")
     assert (yv - y2).abs().max().item() < 2e-5 * y2.abs().max().item()
     del y2, yv
     incs = [ops.phase_delta(1.0, -(c - 31.5) / 64.0) for c in range(64)]
