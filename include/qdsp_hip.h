@@ -297,6 +297,14 @@ int qdsp_hip_chan_cf32_create(void** h, int device, const float* taps, int ntaps
 int qdsp_hip_chan_cf32_process(void* h, const float* in_iq, int count, float* out_iq, int out_stride);
 int64_t qdsp_hip_chan_cf32_process_dev(void* h, const void* d_in, int64_t count, void* d_out,
                                        int64_t out_stride, void* hip_stream);
+/* The same operator inside a block graph (Splitter -> N x VFO with identical filters, src/dsp/routing.h:47-57): ONE batched
+ * launch, channel c's samples into its own stream buffer outs[c] with link code out_links[c] (QDSP_HIP_LINK_HOST_DEFERRED:
+ * pinned host buffer, stored by the kernel itself, complete once `done_event` has fired -- or QDSP_HIP_LINK_HOST: complete on
+ * return; QDSP_HIP_LINK_DEVICE / _PIPELINED as for *_process_ex).  Always the per-channel (non-uniform) form.  Returns the
+ * per-channel output count; QDSP_HIP_ESIZE / _EINVAL when a buffer cannot be served this way (pageable or > 1 MiB host
+ * output, taps beyond LDS): the caller then runs the channels one by one. */
+int64_t qdsp_hip_chan_cf32_process_links(void* h, const void* in, int in_link, int count, void* const* outs, const int* out_links,
+                                         void* done_event);
 int64_t qdsp_hip_chan_cf32_out_size(void* h, int64_t count);
 int qdsp_hip_chan_cf32_set_phase_inc(void* h, int chan, float phase_inc_re, float phase_inc_im);
 int qdsp_hip_chan_cf32_set_mode(void* h, int mode);

@@ -403,7 +403,7 @@ struct AnyArgs {
 // M = 2 mod 4 in this form -- pairs instead of groups of four inside a row -- also lost: 0.41 vs 0.35 ms at M = 50;
 // its 2-way conflicts cost less than the row bookkeeping.)
 template <int CH, int NT, bool ROT, bool LT, bool PAD>
-__global__ __launch_bounds__(NT) void resamp_any_kernel(const AnyArgs a) {
+__device__ __forceinline__ void resamp_any_body(const AnyArgs& a) {
     using T = typename Smp<CH>::T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* tl = reinterpret_cast<float*>(smem_raw);                       // LT: [L][a.Pp]
@@ -554,6 +554,54 @@ __global__ __launch_bounds__(NT) void resamp_any_kernel(const AnyArgs a) {
             out[n] = acc;
         }
     }
+}
+
+template <int CH, int NT, bool ROT, bool LT, bool PAD>
+__global__ __launch_bounds__(NT) void resamp_any_kernel(const AnyArgs a) {
+    resamp_any_body<CH, NT, ROT, LT, PAD>(a);
+}
+
+// The same operator for N channels in ONE launch (Splitter -> N x VFO at arbitrary offsets, src/dsp/routing.h:47-57 +
+// src/dsp/vfo.h:19-36: non-uniform qdsp_hip_chan_cf32 plans): blockIdx.y = channel.  All channels share the input, the
+// taps and the tile geometry; what differs per channel -- the NCO increment with the staging constants derived from it,
+// the two history buffers -- sits in a device table that is rewritten only on a retune, what changes every call (the
+// NCO phase at the first sample) travels in the kernel arguments, and the output rows lie out_stride apart.  The
+// block's input is read from memory once per channel but from L2 after the first (a 1e6-sample block is 8 MB).
+constexpr int kAnyBatchMax = 128;           // channels per launch (phase0[] rides in the kernel arguments: 1 KB)
+struct AnyChanConst {
+    const void* hist[2];                    // the channel's two history buffers; `cur` selects the one to read
+    unsigned long long dphase;
+    double2 rot_nt, rot_8nt;
+    float2 rot_k[8];
+    float gm1;
+    int pad_;
+};
+struct AnyBatchArgs {
+    AnyArgs a;                              // shared part (in, taps, geometry); per-channel fields are patched in
+    const AnyChanConst* tab;                // [nchan]
+    long long out_stride;                   // complex samples between the channels' output rows
+    int cur;                                // history parity of this call (all channels flip together)
+    int use_ptrs;                           // 1: channel c writes to outs[c] (N separate stream buffers: Splitter -> N x VFO inside a graph)
+    unsigned long long phase0[kAnyBatchMax];
+    void* outs[kAnyBatchMax];
+};
+template <int NT, bool LT, bool PAD>
+__global__ __launch_bounds__(NT) void resamp_any_batch_kernel(const AnyBatchArgs b) {
+    const int ch = blockIdx.y;
+    AnyArgs a = b.a;
+    const AnyChanConst& c = b.tab[ch];
+    a.hist = c.hist[b.cur];
+    a.hist_next = const_cast<void*>(c.hist[b.cur ^ 1]);
+    a.out = b.use_ptrs ? b.outs[ch] : static_cast<void*>(static_cast<float2*>(b.a.out) + (long long)ch * b.out_stride);
+    a.phase0 = b.phase0[ch];
+    a.dphase = c.dphase;
+    a.rot_nt = c.rot_nt;
+    a.rot_8nt = c.rot_8nt;
+#pragma unroll
+    for (int k = 0; k < 8; k++) a.rot_k[k] = c.rot_k[k];
+    a.gm1 = c.gm1;
+    a.nco_tab = nullptr;
+    resamp_any_body<2, NT, true, LT, PAD>(a);
 }
 
 // ---- short-filter integer decimator ---------------------------------------------------------

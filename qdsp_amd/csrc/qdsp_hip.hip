@@ -674,15 +674,18 @@ AnyPlan any_plan(int L, int M, int P, int ch) {
     return p;
 }
 
-template <int CH, bool ROT> int launch_any(Engine* e, qk::AnyArgs& a, hipStream_t s) {
+// Tile geometry of resamp_any_kernel into `a` (a.L / a.M / a.P / a.nout set by the caller); returns the dynamic LDS
+// bytes, 0 if the taps of one phase do not fit.
+size_t fill_any_geometry(qk::AnyArgs& a, int ch, bool* lt, bool* pad) {
     constexpr int NT = 256;
-    const AnyPlan pl = any_plan(a.L, a.M, a.P, CH);
-    if (pl.tile == 0) return QDSP_HIP_EINVAL;  // taps per phase beyond LDS
-    const bool lt = pl.tap_bytes != 0, pad = pl.pad;
+    const AnyPlan pl = any_plan(a.L, a.M, a.P, ch);
+    if (pl.tile == 0) return 0;  // taps per phase beyond LDS
+    *lt = pl.tap_bytes != 0;
+    *pad = pl.pad;
     const long long tile = pl.tile;
     a.Pp = pl.Pp;
     a.tap_bytes = pl.tap_bytes;
-    a.pad_inv = pad ? (unsigned)((1ULL << 32) / (unsigned)a.M) + 1u : 0u;
+    a.pad_inv = pl.pad ? (unsigned)((1ULL << 32) / (unsigned)a.M) + 1u : 0u;
     a.tile = (int)tile;
     a.ks_lanes = pl.ks_lanes;
     a.ks_shift = pl.ks_shift;
@@ -691,7 +694,14 @@ template <int CH, bool ROT> int launch_any(Engine* e, qk::AnyArgs& a, hipStream_
     a.nblocks = (int)((a.nout + tile - 1) / tile);
     a.step_d = (int)(((long long)NT * a.M) / a.L);
     a.step_p = (int)(((long long)NT * a.M) % a.L);
-    const size_t lds = (size_t)a.tap_bytes + (size_t)(pl.span + (pl.ks_lanes ? NT : 0)) * CH * sizeof(float);
+    return (size_t)a.tap_bytes + (size_t)(pl.span + (pl.ks_lanes ? NT : 0)) * ch * sizeof(float);
+}
+
+template <int CH, bool ROT> int launch_any(Engine* e, qk::AnyArgs& a, hipStream_t s) {
+    constexpr int NT = 256;
+    bool lt = false, pad = false;
+    const size_t lds = fill_any_geometry(a, CH, &lt, &pad);
+    if (lds == 0) return QDSP_HIP_EINVAL;  // taps per phase beyond LDS
     // persistent workgroups, 8 per CU (measured on the M = 50, 401-tap VFO, 32 KB of LDS each: 5 per CU -- what is
     // resident at once -- 0.41 ms per 2^27 samples, 8 .. 64 per CU 0.345-0.358)
     int nwg = 256 * env_int("QDSP_HIP_ANY_WG_PER_CU", 8);
@@ -1401,6 +1411,11 @@ struct Chan {
     float2* d_tw64 = nullptr;
     float* d_hist[2] = {nullptr, nullptr};   // P raw input samples (shared by all channels)
     int cur = 0;
+    // batched per-channel form (resamp_any_batch_kernel): the prototype's [L][P] phase table and the per-channel
+    // constants, re-uploaded when a channel is retuned or its buffers change (batch_key: what the table was built from)
+    float* d_phases = nullptr;
+    qk::AnyChanConst* d_batch = nullptr;
+    std::vector<qk::AnyChanConst> batch_key;
     Launch last;
 };
 Chan* as_chan(void* h) {
@@ -1414,6 +1429,8 @@ void chan_destroy(Chan* c) {
     for (Engine* e : c->vfo) destroy(e);
     if (c->d_taps) (void)hipFree(c->d_taps);
     if (c->d_tw64) (void)hipFree(c->d_tw64);
+    if (c->d_phases) (void)hipFree(c->d_phases);
+    if (c->d_batch) (void)hipFree(c->d_batch);
     for (int i = 0; i < 2; i++)
         if (c->d_hist[i]) (void)hipFree(c->d_hist[i]);
     if (c->d_in) (void)hipFree(c->d_in);
@@ -1518,6 +1535,119 @@ int chan_launch_uniform(Chan* c, const void* d_in, int64_t count, int64_t nout, 
     return 0;
 }
 
+// Non-uniform plans (arbitrary offsets, any channel count): ALL channels in one launch of resamp_any_batch_kernel
+// (blockIdx.y = channel).  Returns 1 if the batched form does not apply (the caller then loops over the channels).
+int chan_launch_batch(Chan* c, const void* d_in, int64_t count, int64_t nout, void* d_out, int64_t out_stride, hipStream_t s,
+                      void* const* out_ptrs = nullptr) {
+    constexpr int NT = 256;
+    Engine* e0 = c->vfo[0];
+    for (Engine* e : c->vfo)
+        if (e->cur != e0->cur || !e->rotate || e->ch != 2) return 1;
+    qk::AnyBatchArgs b;
+    memset(&b, 0, sizeof(b));
+    qk::AnyArgs& a = b.a;
+    a.L = e0->L;
+    a.M = e0->M;
+    a.P = e0->P;
+    a.count = count;
+    a.nout = nout;
+    bool lt = false, pad = false;
+    const size_t lds = fill_any_geometry(a, 2, &lt, &pad);
+    if (lds == 0) return 1;
+    if (!c->d_phases) {
+        // the reference's [interp][tapsPerPhase] table (buildTapPhases, resampling.h:137-166), whatever layout the
+        // per-channel engines keep their taps in
+        const int L = e0->L, P = e0->P, ntaps = e0->ntaps;
+        std::vector<float> host((size_t)L * P, 0.0f);
+        int curt = 0;
+        for (int tap = 0; tap < P; tap++)
+            for (int phase = 0; phase < L; phase++)
+                host[(size_t)((L - 1) - phase) * P + tap] = (curt < ntaps) ? e0->taps_host[curt++] : 0.0f;
+        HIPCHK(hipMalloc(&c->d_phases, host.size() * sizeof(float)));
+        HIPCHK(hipMemcpy(c->d_phases, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    // per-channel constants: rebuilt and uploaded only when something they were built from changed
+    std::vector<qk::AnyChanConst> key((size_t)c->nchan);
+    for (int i = 0; i < c->nchan; i++) {
+        Engine* e = c->vfo[i];
+        qk::AnyChanConst& k = key[i];
+        memset(&k, 0, sizeof(k));
+        k.hist[0] = e->d_hist[0];
+        k.hist[1] = e->d_hist[1];
+        k.dphase = e->dphase;
+        k.gm1 = e->volk_gain ? e->gm1 : 0.0f;
+    }
+    bool dirty = !c->d_batch || c->batch_key.size() != key.size();
+    for (size_t i = 0; !dirty && i < key.size(); i++)
+        dirty = key[i].hist[0] != c->batch_key[i].hist[0] || key[i].hist[1] != c->batch_key[i].hist[1] ||
+                key[i].dphase != c->batch_key[i].dphase || key[i].gm1 != c->batch_key[i].gm1;
+    if (dirty) {
+        for (size_t i = 0; i < key.size(); i++) {
+            qk::AnyArgs tmp;
+            memset(&tmp, 0, sizeof(tmp));
+            tmp.dphase = key[i].dphase;
+            fill_stage_rot(tmp, NT);
+            key[i].rot_nt = tmp.rot_nt;
+            key[i].rot_8nt = tmp.rot_8nt;
+            for (int k = 0; k < 8; k++) key[i].rot_k[k] = tmp.rot_k[k];
+        }
+        HIPCHK(hipDeviceSynchronize());     // (rare -- a retune: nothing in flight may still read the old table)
+        if (c->d_batch && c->batch_key.size() != key.size()) { HIPCHK(hipFree(c->d_batch)); c->d_batch = nullptr; }
+        if (!c->d_batch) HIPCHK(hipMalloc(&c->d_batch, key.size() * sizeof(qk::AnyChanConst)));
+        HIPCHK(hipMemcpy(c->d_batch, key.data(), key.size() * sizeof(qk::AnyChanConst), hipMemcpyHostToDevice));
+        c->batch_key = key;
+    }
+    a.in = d_in;
+    a.phases = c->d_phases;
+    // persistent workgroups per channel: the grid's x extent times the channels should fill the chip a few times over
+    int nwg = (256 * env_int("QDSP_HIP_ANY_WG_PER_CU", 8) + c->nchan - 1) / c->nchan;
+    if (nwg > a.nblocks) nwg = a.nblocks;
+    if (nwg < 1) nwg = 1;
+    a.nwg = nwg;
+    b.out_stride = out_stride;
+    b.cur = e0->cur;
+    for (int base = 0; base < c->nchan; base += qk::kAnyBatchMax) {
+        const int nb = (c->nchan - base < qk::kAnyBatchMax) ? c->nchan - base : qk::kAnyBatchMax;
+        b.tab = c->d_batch + base;
+        a.out = out_ptrs ? nullptr : static_cast<void*>(static_cast<float2*>(d_out) + (size_t)base * out_stride);
+        b.use_ptrs = out_ptrs ? 1 : 0;
+        for (int i = 0; i < nb; i++) {
+            b.phase0[i] = c->vfo[base + i]->phase;
+            b.outs[i] = out_ptrs ? out_ptrs[base + i] : nullptr;
+        }
+        const dim3 grid(nwg + 1, nb);
+        if (pad) {
+            if (lt) hipLaunchKernelGGL((qk::resamp_any_batch_kernel<NT, true, true>), grid, dim3(NT), lds, s, b);
+            else hipLaunchKernelGGL((qk::resamp_any_batch_kernel<NT, false, true>), grid, dim3(NT), lds, s, b);
+        } else {
+            if (lt) hipLaunchKernelGGL((qk::resamp_any_batch_kernel<NT, true, false>), grid, dim3(NT), lds, s, b);
+            else hipLaunchKernelGGL((qk::resamp_any_batch_kernel<NT, false, false>), grid, dim3(NT), lds, s, b);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    for (Engine* e : c->vfo) {
+        e->cur ^= 1;
+        e->phase += (unsigned long long)count * e->dphase;
+        e->raw_valid = false;
+    }
+    c->last.name = "resamp_any_batch_kernel";
+    c->last.grid = (nwg + 1) * c->nchan;
+    c->last.block = NT;
+    c->last.lds = (int)lds;
+    return 0;
+}
+
+// Batch or loop?  One launch wins wherever a per-channel call is launch- or latency-bound (reference-sized blocks:
+// 16 channels of a 1e6-sample block 403 us as 16 launches) and wherever resamp_any_kernel is what a channel would run
+// anyway; chip-filling calls of plans that have a faster dedicated kernel (overlap-save, strided-window) keep it.
+bool chan_batch_wins(const Chan* c, int64_t count) {
+    if (c->nchan < 2 || env_int("QDSP_HIP_NO_CHAN_BATCH", 0)) return false;
+    const Engine* e = c->vfo[0];
+    if (count <= (int64_t)env_int("QDSP_HIP_CHAN_BATCH_MAX_COUNT", 1 << 22)) return true;
+    const bool dedicated = (fft_eligible(e, count) || use_win(e) || use_core(e) || use_lm(e));
+    return !dedicated;
+}
+
 int64_t chan_process_dev(Chan* c, const void* d_in, int64_t count, void* d_out, int64_t out_stride, void* stream) {
     if (count < 0 || c->vfo.empty()) return QDSP_HIP_EINVAL;
     for (Engine* e : c->vfo) apply_pending_inc(e);
@@ -1530,6 +1660,14 @@ int64_t chan_process_dev(Chan* c, const void* d_in, int64_t count, void* d_out, 
         if (mode != 1 && chan_uniform_plan(c, &inv, dd)) {
             int rc = chan_launch_uniform(c, d_in, count, nout, d_out, out_stride, static_cast<hipStream_t>(stream));
             return rc ? rc : nout;
+        }
+    }
+    {
+        const int mode = c->mode ? c->mode : env_int("QDSP_HIP_FIR_MODE", 0);
+        if (mode == 0 && count > 0 && chan_batch_wins(c, count)) {
+            const int rc = chan_launch_batch(c, d_in, count, nout, d_out, out_stride, static_cast<hipStream_t>(stream));
+            if (rc == 0) return nout;
+            if (rc < 0) return rc;
         }
     }
     for (int i = 0; i < c->nchan; i++) {
@@ -2049,6 +2187,65 @@ int qdsp_hip_chan_cf32_process(void* h, const float* in, int count, float* out, 
                                 hipMemcpyDeviceToHost, c->stream));
     HIPCHK(wait_stream(c->stream));
     return (int)nout;
+}
+// Splitter -> N x VFO inside a block graph: one batched launch, every channel's output into its OWN stream buffer.
+int64_t qdsp_hip_chan_cf32_process_links(void* h, const void* in, int in_link, int count, void* const* outs, const int* out_links,
+                                         void* done_event) {
+    Chan* c = as_chan(h);
+    if (!c || count < 0 || !outs || !out_links || (count > 0 && !in)) return QDSP_HIP_EINVAL;
+    if (c->vfo.empty()) return QDSP_HIP_EINVAL;
+    for (Engine* e : c->vfo) apply_pending_inc(e);
+    HIPCHK(hipSetDevice(c->device));
+    const int64_t nout = out_size(c->vfo[0], count);
+    if (count == 0) return 0;
+    hipStream_t st = c->stream;
+    bool any_pipe = in_link == QDSP_HIP_LINK_PIPELINED, any_host = false, any_dev_sync = false;
+    for (int i = 0; i < c->nchan; i++) {
+        if (out_links[i] == QDSP_HIP_LINK_PIPELINED) any_pipe = true;
+        else if (out_links[i] == QDSP_HIP_LINK_DEVICE) any_dev_sync = true;
+        else if (out_links[i] == QDSP_HIP_LINK_HOST_DEFERRED || out_links[i] == QDSP_HIP_LINK_HOST) any_host = true;
+        else return QDSP_HIP_EINVAL;
+    }
+    if (any_pipe) {
+        st = shared_stream(c->device);
+        if (!st) return QDSP_HIP_ENOMEM;
+    }
+    // host outputs are stored by the kernel itself into the pinned, device-mapped stream buffers (as process_ex does
+    // for results up to QDSP_HIP_DIRECT_OUT_MAX_BYTES); anything else is not served here -- the caller falls back
+    std::vector<void*> dst((size_t)c->nchan);
+    const size_t out_bytes = (size_t)nout * sizeof(float2);
+    for (int i = 0; i < c->nchan; i++) {
+        if (out_links[i] == QDSP_HIP_LINK_HOST_DEFERRED || out_links[i] == QDSP_HIP_LINK_HOST) {
+            if (out_bytes > (size_t)env_int("QDSP_HIP_DIRECT_OUT_MAX_BYTES", 1 << 20)) return QDSP_HIP_ESIZE;
+            void* m = out_bytes ? mapped_host_ptr(outs[i]) : outs[i];
+            if (!m) return QDSP_HIP_ESIZE;
+            dst[i] = m;
+        } else {
+            dst[i] = outs[i];
+        }
+    }
+    const void* src = in;
+    if (in_link == QDSP_HIP_LINK_HOST) {
+        if (count > c->max_block || !c->d_in) {
+            if (c->d_in) HIPCHK(hipFree(c->d_in));
+            c->d_in = nullptr;
+            HIPCHK(hipMalloc(&c->d_in, (size_t)count * sizeof(float2)));
+            if (count > c->max_block) c->max_block = count;
+        }
+        HIPCHK(hipMemcpyAsync(c->d_in, in, (size_t)count * sizeof(float2), hipMemcpyHostToDevice, st));
+        src = c->d_in;
+    }
+    const int rc = chan_launch_batch(c, src, count, nout, nullptr, 0, st, dst.data());
+    if (rc != 0) return rc < 0 ? rc : QDSP_HIP_EINVAL;
+    bool must_wait = in_link != QDSP_HIP_LINK_PIPELINED || any_dev_sync;   // a host / plain device input is released on return
+    if (any_host) {
+        if (done_event) HIPCHK(hipEventRecord(static_cast<hipEvent_t>(done_event), st));
+        else must_wait = true;
+        for (int i = 0; i < c->nchan && !must_wait; i++)
+            if (out_links[i] == QDSP_HIP_LINK_HOST) must_wait = true;       // not deferred: complete on return
+    }
+    if (must_wait) HIPCHK(hipStreamSynchronize(st));
+    return nout;
 }
 int qdsp_hip_chan_cf32_set_phase_inc(void* h, int chan, float re, float im) {
     Chan* c = as_chan(h);

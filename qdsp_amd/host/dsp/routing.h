@@ -13,6 +13,7 @@
 
 #include "block.h"
 #include "filter.h"
+#include "vfo_bank.h"
 
 namespace dsp {
 
@@ -26,6 +27,7 @@ public:
     ~Splitter() {
         const bool live = base::running;
         base::stop();
+        dropBank();
         if (live && _in) { _in->releaseConsumer(); }
     }
 
@@ -49,6 +51,8 @@ public:
     void bindStream(stream<T>* s) {
         std::lock_guard<std::mutex> lck(base::ctrlMtx);
         base::tempStop();
+        dropBank();
+        bankOff = false;
         out.push_back(s);
         base::registerOutput(s);
         base::tempStart();
@@ -57,15 +61,123 @@ public:
     void unbindStream(stream<T>* s) {
         std::lock_guard<std::mutex> lck(base::ctrlMtx);
         base::tempStop();
+        dropBank();
+        bankOff = false;
         base::unregisterOutput(s);
         out.erase(std::remove(out.begin(), out.end(), s), out.end());
         base::tempStart();
     }
 
 private:
+    // ---- N identical VFOs behind the outputs: one batched launch per block (vfo_bank.h) ------------------------------
+    void dropBank() {
+        for (auto& m : members) { std::atomic_store(&m->ctl, std::shared_ptr<detail::vfo_bank_ctl>()); }
+        members.clear();
+        if (ctl) {
+            std::lock_guard<std::mutex> lk(ctl->m);
+            if (ctl->bank) { qdsp_hip_chan_cf32_destroy(ctl->bank); }
+            ctl->bank = nullptr;
+        }
+        ctl.reset();
+        for (void*& e : bankEvt) { if (e) { qdsp_hip_event_destroy(e); e = nullptr; } }
+    }
+
+    // all consumers idle (every link flushed): see whether they are N >= 2 live VFO cores of one design
+    bool buildBank() {
+        if (out.size() < 2) { return false; }
+        const char* no = getenv("QDSP_HIP_NO_VFO_BANK");
+        if (no && atoi(no)) { return false; }
+        std::vector<std::shared_ptr<detail::vfo_bank_member>> ms;
+        for (stream<T>* s : out) {
+            auto m = s->bankMember;
+            if (!m || !m->alive.load() || !m->out || std::atomic_load(&m->ctl)) { return false; }
+            ms.push_back(m);
+        }
+        for (auto& m : ms) {
+            if (m->taps != ms[0]->taps || m->interp != ms[0]->interp || m->decim != ms[0]->decim) { return false; }
+        }
+        std::vector<float> re, im;
+        for (auto& m : ms) { re.push_back(m->dRe); im.push_back(m->dIm); }
+        const int dev = detail::hipDeviceForBlocks();
+        void* h = nullptr;
+        if (qdsp_hip_chan_cf32_create(&h, dev, ms[0]->taps.data(), (int)ms[0]->taps.size(), ms[0]->interp, ms[0]->decim, (int)ms.size(),
+                                      re.data(), im.data(), 0) != 0) { return false; }
+        if (qdsp_hip_event_create(dev, &bankEvt[0]) != 0 || qdsp_hip_event_create(dev, &bankEvt[1]) != 0) {
+            qdsp_hip_chan_cf32_destroy(h);
+            for (void*& e : bankEvt) { if (e) { qdsp_hip_event_destroy(e); e = nullptr; } }
+            return false;
+        }
+        ctl = std::make_shared<detail::vfo_bank_ctl>();
+        ctl->bank = h;
+        members = ms;
+        for (size_t i = 0; i < members.size(); i++) {
+            members[i]->index = (int)i;
+            std::atomic_store(&members[i]->ctl, ctl);
+        }
+        // a retune that raced the build: push every member's current increment again (they are applied between blocks)
+        for (auto& m : members) { qdsp_hip_chan_cf32_set_phase_inc(h, m->index, m->dRe, m->dIm); }
+        return true;
+    }
+
+    // One block through the bank.  true: done (every link got its token block); false: not banked -- copy the block out
+    // as the reference does.  -1 in `stop`: a link is being stopped.
+    bool runBank(int count, bool& stop) {
+        stop = false;
+        if (bankOff) { return false; }
+        if (ctl && ctl->broken.load()) {
+            for (stream<T>* s : out) { if (!s->waitFlushed()) { stop = true; return false; } }
+            dropBank();
+        }
+        if (!ctl) {
+            for (stream<T>* s : out) { if (!s->waitFlushed()) { stop = true; return false; } }
+            if (!buildBank()) { bankOff = true; return false; }
+        }
+        const int dev = detail::hipDeviceForBlocks();
+        const size_t n = members.size();
+        std::vector<void*> outs(n);
+        std::vector<int> links(n);
+        void* evt = bankEvt[blockNo & 1];
+        for (size_t i = 0; i < n; i++) {
+            // member i has finished the previous block -- flushed its token AFTER swapping its output -- so the write
+            // buffer of its out stream is free
+            if (!out[i]->waitFlushed()) { stop = true; return false; }
+            stream<complex_t>* o = members[i]->out;
+            const bool outDev = o->consumerTakesDevice && o->ensureDevice(dev);
+            outs[i] = outDev ? static_cast<void*>(o->devWriteBuf) : static_cast<void*>(o->writeBuf);
+            links[i] = outDev ? o->linkOut(true) : QDSP_HIP_LINK_HOST_DEFERRED;
+        }
+        const void* src = _in->readOnDevice ? static_cast<const void*>(_in->devReadBuf) : static_cast<const void*>(_in->readBuf);
+        const long long rc = qdsp_hip_chan_cf32_process_links(ctl->bank, src, _in->linkIn(), count, outs.data(), links.data(), evt);
+        if (rc < 0) {
+            // not servable this way (pageable / oversized host buffer, taps beyond LDS): back to one kernel per VFO for good
+            dropBank();
+            bankOff = true;
+            return false;
+        }
+        for (size_t i = 0; i < n; i++) {
+            members[i]->outCount = (int)rc;
+            members[i]->outLink = links[i];
+            members[i]->evt = links[i] == QDSP_HIP_LINK_HOST_DEFERRED ? evt : nullptr;
+        }
+        blockNo++;
+        for (stream<T>* s : out) {
+            s->markWritten(QDSP_HIP_LINK_HOST);
+            if (!s->swap(count)) { stop = true; return true; }     // token block: the count, no samples
+        }
+        return true;
+    }
+
     int run() override {
         const int count = _in->read();
         if (count < 0) { return -1; }
+        if constexpr (std::is_same<T, complex_t>::value) {
+            bool stop = false;
+            const bool done = runBank(count, stop);
+            if (done || stop) {
+                _in->flush();
+                return stop ? -1 : count;
+            }
+        }
         const int dev = detail::hipDeviceForBlocks();
         const size_t bytes = (size_t)count * sizeof(T);
         bool hostCopyValid = !_in->readOnDevice;
@@ -98,6 +210,12 @@ private:
 
     stream<T>* _in = nullptr;
     std::vector<stream<T>*> out;
+    // bank state (complex_t only)
+    std::shared_ptr<detail::vfo_bank_ctl> ctl;
+    std::vector<std::shared_ptr<detail::vfo_bank_member>> members;
+    void* bankEvt[2] = {nullptr, nullptr};
+    unsigned blockNo = 0;
+    bool bankOff = false;     // decided: these consumers cannot be banked
 };
 
 }  // namespace dsp

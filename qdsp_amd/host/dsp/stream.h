@@ -27,6 +27,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
+#include <memory>
 #include <mutex>
 
 #include "qdsp_hip.h"
@@ -34,6 +35,8 @@
 #define STREAM_BUFFER_SIZE 1000000
 
 namespace dsp {
+
+namespace detail { struct vfo_bank_member; }
 
 // (sic) the reference spells it this way; blocks register streams through this base.
 class untyped_steam {
@@ -171,6 +174,16 @@ public:
         consumerPipelined.store(takesDevice && pipelined);
     }
     void releaseConsumer() { claimConsumer(false, false); }
+    // Splitter -> N x VFO banking (routing.h, vfo.h): a VFO core hangs its descriptor on its input stream; a Splitter
+    // that finds identical VFOs behind all its outputs runs them as ONE batched launch and only sends token blocks down
+    // these links (vfo_bank.h).  Set before the graph starts (VFO::init), read by the Splitter's worker.
+    std::shared_ptr<detail::vfo_bank_member> bankMember;
+    // Block until the consumer has released the block it was given (flush()), false if the writer side is being stopped.
+    bool waitFlushed() {
+        std::unique_lock<std::mutex> lk(mtx);
+        waitFor(lk, [this] { return slotFree || writerStopped; });
+        return !writerStopped;
+    }
     int linkIn() const { return readOnDevice ? (readPipelined ? QDSP_HIP_LINK_PIPELINED : QDSP_HIP_LINK_DEVICE) : QDSP_HIP_LINK_HOST; }
     int linkOut(bool outDev) const { return outDev ? (consumerPipelined ? QDSP_HIP_LINK_PIPELINED : QDSP_HIP_LINK_DEVICE) : QDSP_HIP_LINK_HOST; }
     void markWritten(int link, void* doneEvt = nullptr) {

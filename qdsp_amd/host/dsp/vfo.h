@@ -18,6 +18,7 @@
 
 #include "block.h"
 #include "filter.h"
+#include "vfo_bank.h"
 #include "window.h"
 
 namespace dsp {
@@ -32,12 +33,21 @@ public:
     ~XlatingResampler() {
         const bool live = base::running;
         base::stop();
+        member->alive.store(false);
+        if (auto ctl = std::atomic_load(&member->ctl)) { ctl->broken.store(true); }
         if (live && _in) { _in->releaseConsumer(); }
         if (handle) { qdsp_hip_xlate_fir_decim_cf32_destroy(handle); }
     }
 
     void init(stream<complex_t>* in, const std::vector<float>& taps, int interp, int decim, float dRe, float dIm) {
         _in = in;
+        member->taps = taps;
+        member->interp = interp;
+        member->decim = decim;
+        member->dRe = dRe;
+        member->dIm = dIm;
+        member->out = &out;
+        _in->bankMember = member;     // (a Splitter upstream may run identical VFOs as one batched launch: vfo_bank.h)
         const int rc = qdsp_hip_xlate_fir_decim_cf32_create(&handle, hipDeviceForBlocks(), taps.data(), (int)taps.size(), interp,
                                                             decim, dRe, dIm, STREAM_BUFFER_SIZE);
         if (rc != 0) { handle = nullptr; hipBlockFail("VFO::init", rc); }
@@ -49,6 +59,10 @@ public:
     void configure(const std::vector<float>& taps, int interp, int decim) {
         std::lock_guard<std::mutex> lck(base::ctrlMtx);
         base::tempStop();
+        member->taps = taps;
+        member->interp = interp;
+        member->decim = decim;
+        if (auto ctl = std::atomic_load(&member->ctl)) { ctl->broken.store(true); }   // a bank built for the old design is taken down by its Splitter
         if (handle) {
             const int rc = qdsp_hip_xlate_fir_decim_cf32_configure(handle, taps.data(), (int)taps.size(), interp, decim);
             if (rc != 0) { hipBlockFail("VFO::configure", rc); }
@@ -58,12 +72,27 @@ public:
 
     void setPhaseInc(float dRe, float dIm) {
         if (handle) { qdsp_hip_xlate_fir_decim_cf32_set_phase_inc(handle, dRe, dIm); }
+        member->dRe = dRe;
+        member->dIm = dIm;
+        if (auto ctl = std::atomic_load(&member->ctl)) {
+            std::lock_guard<std::mutex> lk(ctl->m);
+            if (ctl->bank) { qdsp_hip_chan_cf32_set_phase_inc(ctl->bank, member->index, dRe, dIm); }
+        }
     }
 
     int run() override {
         const int count = _in->read();
         if (count < 0) { return -1; }
         if (!handle) { return -1; }
+        if (std::atomic_load(&member->ctl)) {
+            // banked (Splitter -> N x identical VFO): the block is a token, the Splitter's batched launch has already put
+            // this channel's samples into out's write buffer.  Flush AFTER the swap: the Splitter takes the flush as
+            // "this member's write buffer is free again".
+            out.markWritten(member->outLink, member->evt);
+            const bool ok = out.swap(member->outCount);
+            _in->flush();
+            return ok ? count : -1;
+        }
         const bool inDev = _in->readOnDevice;
         const bool outDev = out.consumerTakesDevice && out.ensureDevice(hipDeviceForBlocks());
         const void* src = inDev ? static_cast<const void*>(_in->devReadBuf) : static_cast<const void*>(_in->readBuf);
@@ -79,6 +108,7 @@ public:
     }
 
     stream<complex_t> out;
+    std::shared_ptr<vfo_bank_member> member = std::make_shared<vfo_bank_member>();
 
 private:
     stream<complex_t>* _in = nullptr;

@@ -672,18 +672,73 @@ def test_channelizer_guard_bands_and_odd_strides(ops, gold, dec):
         assert np.array_equal(host[:, :no], want), (dec, n, stride, off)
 
 
-def test_channelizer_non_uniform_plan_falls_back(ops, gold):
-    """Arbitrary offsets (or another decimation) are served by one fused kernel per channel."""
+def test_channelizer_non_uniform_plan_one_batched_launch(ops, gold):
+    """Arbitrary offsets (Splitter -> N x VFO, routing.h:47-57 + vfo.h:19-36): ALL channels in ONE launch of
+    resamp_any_batch_kernel (blockIdx.y = channel; per-channel NCO / history from a device table), each channel
+    against the FP64 oracle of its own xlator -> resampler chain."""
     taps = gold["taps256"]
     n = 65_536
     x = O.synth_iq(0, n, seed=9)
-    incs = [ops.phase_delta(1.0, f) for f in (0.01, -0.2, 0.3333, 0.125)]
+    freqs = (0.01, -0.2, 0.3333, 0.125)
+    incs = [ops.phase_delta(1.0, f) for f in freqs]
     ch = ops.Channelizer(taps, 1, 64, incs, max_block=n)
     y = np.array(ch.process(x))
-    assert ch.last_kernel()["name"] != "chan_uniform_kernel" and y.shape == (4, n // 64)
-    for c, f in enumerate((0.01, -0.2, 0.3333, 0.125)):
+    k = ch.last_kernel()
+    assert k["name"] == "resamp_any_batch_kernel" and y.shape == (4, n // 64)
+    assert k["grid"] % 4 == 0                       # grid = (tiles + hand-over) x 4 channels: one launch
+    for c, f in enumerate(freqs):
         want = O.Resampler(taps, 1, 64, acc=O.ACC_F64).process(O.Xlator(1.0, f, exact=True, volk_gain=True).process(x))
         assert rel_rms(y[c], want) < 2e-6
+    # forced per-channel form (QDSP_HIP_FIR_DIRECT): one fused kernel per channel, same numbers to rounding
+    ch2 = ops.Channelizer(taps, 1, 64, incs, max_block=n)
+    ch2.set_mode(ch2.DIRECT)
+    y2 = np.array(ch2.process(x))
+    assert ch2.last_kernel()["name"] != "resamp_any_batch_kernel"
+    for c in range(4):
+        assert rel_rms(y[c], y2[c]) < 2e-6
+
+
+@pytest.mark.parametrize("plan", ["vfo50x16", "dec8x5", "r3_2x3", "dec10x130"])
+def test_channelizer_batched_stream_of_blocks(ops, plan):
+    """The batched per-channel kernel over a STREAM of reference-sized and ragged blocks (history and every channel's NCO
+    phase carried from call to call, a zero-length block in between, a retune of one channel mid-stream that
+    rewrites the device table), for the VFO's everyday shape (401 taps, decimate by 50, 16 channels), a short
+    decimate-by-8, a rational 3/2 plan and 130 channels (two launches of <= 128 channels)."""
+    import torch
+
+    L, M, ntaps, nch = {"vfo50x16": (1, 50, 401, 16), "dec8x5": (1, 8, 63, 5), "r3_2x3": (3, 2, 95, 3), "dec10x130": (1, 10, 97, 130)}[plan]
+    taps = (O.lowpass_taps_f64(ntaps, 0.4 / max(L, M)) * L).astype(np.float32)
+    freqs = [(-0.45 + 0.9 * (i + 0.37) / nch) for i in range(nch)]
+    incs = [ops.phase_delta(1.0, f) for f in freqs]
+    sizes = [50 * 2000, 50 * 7, 0, 50 * 400 + 50, 50 * 1311] if M == 50 else [20_000, 80, 0, 4000 + 2 * M, 30_000]
+    x = O.synth_iq(0, sum(sizes), seed=444)
+    ch = ops.Channelizer(taps, L, M, incs, max_block=0)
+    ys, pos = [], 0
+    retune_at, new_f = 2, 0.2718
+    for bi, m in enumerate(sizes):
+        if bi == retune_at:
+            re, im = ops.phase_delta(1.0, new_f)
+            from qdsp_amd import capi
+            capi.check(capi.load().qdsp_hip_chan_cf32_set_phase_inc(ch._h, 1, re, im))
+        blk = dev(x[pos:pos + m])
+        pos += m
+        ys.append(ch.process(blk).cpu().numpy())
+        if m:
+            assert ch.last_kernel()["name"] == "resamp_any_batch_kernel", plan
+    torch.cuda.synchronize()
+    y = np.concatenate(ys, axis=1)
+    check = range(nch) if nch <= 16 else (0, 1, 2, 64, 127, 128, 129)
+    for c in check:
+        rs = O.Resampler(taps, L, M, acc=O.ACC_F64)
+        xl = O.Xlator(1.0, freqs[c], exact=True, volk_gain=True)
+        want, pos = [], 0
+        for bi, m in enumerate(sizes):
+            if bi == retune_at and c == 1:
+                xl.delta[:] = O.Xlator(1.0, new_f).delta       # the phase carries on, the increment changes (setOffset, vfo.h:78-82)
+            want.append(rs.process(xl.process(x[pos:pos + m])))
+            pos += m
+        want = np.concatenate(want)
+        assert y[c].shape == want.shape and rel_rms(y[c], want) < 2e-6, (plan, c)
 
 
 def test_vfo_set_history_dev_rotates_raw_samples(ops, gold):
