@@ -290,6 +290,10 @@ def run_workload(name: str, args, ctx) -> dict:
 
     w = WORKLOADS[name]
     n = 1 << args.log2n
+    # chunk starts must be multiples of lcm(decim, 512) once the stream is cut over ranks (per-call phase restart of the
+    # resampler, VOLK gain cadence: qdsp_amd/sharding.py); a single rank runs one continuous stream and needs none
+    align = chunk_alignment(w["decim"], 1, 512 if w["rot"] else 0) if (world > 1 or self_ring) else 1
+    n -= n % align
     op = make_op(ops, name, local_rank)
     is_chan = name in ("chan64", "chan64m8")
     has_hist = name != "xlate"
@@ -302,7 +306,6 @@ def run_workload(name: str, args, ctx) -> dict:
     x = ops.synth_iq(n, first_sample=rank * n, seed=1234, device=local_rank)
     nout = n // w["decim"]
     out = torch.empty((w["nchan"], nout) if is_chan else nout, dtype=torch.complex64, device=dev)
-    align = chunk_alignment(w["decim"], 1, 512 if has_nco else 0)
     ring = RingStream(op, n, rank, world, transport="host" if rehearse else "device", align=align,
                       exchange=(world > 1 or self_ring),
                       prefetch=os.environ.get("QDSP_BENCH_NO_PREFETCH", "0") != "1")

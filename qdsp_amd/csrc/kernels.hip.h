@@ -140,7 +140,7 @@ __device__ __forceinline__ void stage_tile(const typename Smp<CH>::T* __restrict
     // sample made the fused VFO 30-50 % slower than the plain decimator in these memory-bound kernels.
     double2 ph;
     if (ROT) ph = tile >= 0 ? tile_phasor(a, tile, base, t) : phasor_fx(a.phase0 + (unsigned long long)(base + t) * a.dphase);
-    constexpr int K = 8;
+    constexpr int K = 8;    // (16 in one batch measured no faster at 4-5 workgroups per CU)
     for (int u0 = t; u0 < U; u0 += NT * K) {
         T v[K];
         if (base + u0 - t >= 0 && base + u0 - t + NT * K <= count) {       // block-uniform: the whole batch is plain input
@@ -364,6 +364,8 @@ struct AnyArgs {
     int tile;              // outputs per tile
     int nblocks;           // tiles
     int nwg;               // persistent workgroups (grid = nwg + 1: the last hands over history)
+    int xcd_tiles;         // > 0: tiles per XCD -- workgroup b (on XCD b & 7) walks the contiguous range [xcd * xcd_tiles, +xcd_tiles)
+                           // so that neighbouring tiles, which share a window of P samples, meet in ONE XCD's L2; 0: tile = b + k nwg
     int step_d, step_p;    // (NT*M) / L and (NT*M) % L
     unsigned pad_inv;      // PAD: ceil(2^32 / M), u / M == (u * pad_inv) >> 32 for every staged index u
     int ks_lanes;          // 0, or lanes per output S = NT / tile (interp 1, tile < NT): each takes ks_chunk taps
@@ -436,7 +438,15 @@ __device__ __forceinline__ void resamp_any_body(const AnyArgs& a) {
         }
     }
     T* __restrict__ out = static_cast<T*>(a.out);
-    for (int tile = blockIdx.x; tile < a.nblocks; tile += a.nwg) {
+    // Tiles overlap by the P-sample window (12 % of a 3200-sample tile at the VFO's 401 taps / decimate by 50).  Dealt
+    // round-robin, neighbours run on different XCDs (workgroup b sits on XCD b & 7) and each fetches the shared
+    // window from memory (PMC round 1: 1.28x the algorithmic bytes); with a contiguous range per XCD the second
+    // reader finds it in that XCD's L2 (round 2: 1.009x, profiles/r02_vfo50_summary.json).
+    const int xcd = a.xcd_tiles ? (int)(blockIdx.x & 7) : 0;
+    const int t_first = a.xcd_tiles ? xcd * a.xcd_tiles + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int t_step = a.xcd_tiles ? (a.nwg >> 3) : a.nwg;
+    const int t_end = a.xcd_tiles ? ((xcd + 1) * a.xcd_tiles < a.nblocks ? (xcd + 1) * a.xcd_tiles : a.nblocks) : a.nblocks;
+    for (int tile = t_first; tile < t_end; tile += t_step) {
         const long long n0 = (long long)tile * a.tile;
         long long n1 = n0 + a.tile;
         if (n1 > a.nout) n1 = a.nout;

@@ -708,6 +708,8 @@ template <int CH, bool ROT> int launch_any(Engine* e, qk::AnyArgs& a, hipStream_
     if (nwg > a.nblocks) nwg = a.nblocks;
     if (nwg < 1) nwg = 1;
     a.nwg = nwg;
+    // full persistent grids only: a contiguous tile range per XCD (kernels.hip.h)
+    a.xcd_tiles = (nwg >= 2048 && (nwg & 7) == 0 && !env_int("QDSP_HIP_ANY_NO_XCD", 0)) ? (a.nblocks + 7) / 8 : 0;
     fill_stage_rot(a, NT);
     if (pad) {
         if (lt) hipLaunchKernelGGL((qk::resamp_any_kernel<CH, NT, ROT, true, true>), dim3(nwg + 1), dim3(NT), lds, s, a);
