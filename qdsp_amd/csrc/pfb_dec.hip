@@ -61,6 +61,26 @@ constexpr int kDppXor1 = 0xB1;          // quad_perm [1,0,3,2]
 
 __device__ __forceinline__ float4 lds_read4(const float2* p) { return *reinterpret_cast<const float4*>(p); }
 
+// Results are written once and never read by this kernel: non-temporal stores (12 % of the traffic, but mixed into the
+// read stream they cost it a quarter of its rate -- scripts/micro/stream_read.hip: 64 rows read + 8 rows written per
+// wave and segment run 4.9-5.0 TB/s of reads with plain stores, 5.2 with non-temporal ones, 6.3 with none).
+typedef float v2f_nt __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_nt(float2* p, float2 v) {
+#ifdef PFB_PLAIN_STORES
+    *p = v;
+#else
+    __builtin_nontemporal_store((v2f_nt){v.x, v.y}, reinterpret_cast<v2f_nt*>(p));
+#endif
+}
+__device__ __forceinline__ float2 load_stream(const float2* p) {
+#ifdef PFB_NT_LOADS
+    const v2f_nt v = __builtin_nontemporal_load(reinterpret_cast<const v2f_nt*>(p));
+    return make_float2(v.x, v.y);
+#else
+    return *p;
+#endif
+}
+
 }  // namespace
 
 // Segment b (one wave): input positions S0 + [0, 4096), S0 = 8 (b Lo - Q); outputs n' = b Lo + a' - (Q-1) for the
@@ -140,7 +160,7 @@ __global__ __launch_bounds__(kPfbNT, 2) void pfb_dec8_kernel(const PfbArgs a) {
     {
         const float2* __restrict__ p = a.in + clamped(seg_start(wave0 < a.nseg ? wave0 : 0)) + l;
 #pragma unroll
-        for (int r = 0; r < 64; r++) v[r] = p[64 * r];
+        for (int r = 0; r < 64; r++) v[r] = load_stream(p + 64 * r);
     }
 #pragma unroll 1
     for (int b = wave0; b < a.nseg; b += nwaves) {
@@ -204,7 +224,7 @@ __global__ __launch_bounds__(kPfbNT, 2) void pfb_dec8_kernel(const PfbArgs a) {
             for (int kq = 0; kq < 8; kq++) E[(kq * 8 + c) * kPfbRow + hi3] = v[8 * rev8(rho) + rev8(kq)];
             // the registers of row group rev8(rho) are free now: request the same rows of the next segment
 #pragma unroll
-            for (int q = 0; q < 8; q++) vn[8 * rev8(rho) + q] = pn[64 * (8 * rev8(rho) + q)];
+            for (int q = 0; q < 8; q++) vn[8 * rev8(rho) + q] = load_stream(pn + 64 * (8 * rev8(rho) + q));
             __builtin_amdgcn_wave_barrier();
             // reader (c, mu = kq): row l holds the eight g' of bin prefix m = rho + 8 mu
             float2 r8[8], tw[8], gg[8];
@@ -304,7 +324,7 @@ __global__ __launch_bounds__(kPfbNT, 2) void pfb_dec8_kernel(const PfbArgs a) {
             const long long n = nb + ap;
             float2 y = z[rev8(b1)];
             if (ROT) y = cmulc<false>(y, (b1 == 0) ? q : cmulc<false>(q, a.wtab[b1]));
-            if (ap >= a.Q - 1 && n < a.nout) a.out[n] = y;
+            if (ap >= a.Q - 1 && n < a.nout) store_nt(a.out + n, y);
         }
 #pragma unroll
         for (int r = 0; r < 64; r++) v[r] = vn[r];
