@@ -305,6 +305,10 @@ int64_t qdsp_hip_chan_cf32_process_dev(void* h, const void* d_in, int64_t count,
  * output, taps beyond LDS): the caller then runs the channels one by one. */
 int64_t qdsp_hip_chan_cf32_process_links(void* h, const void* in, int in_link, int count, void* const* outs, const int* out_links,
                                          void* done_event);
+/* NCO phase (exact) and filter history of channel `chan` into (to_vfo != 0) or out of (to_vfo == 0) a stand-alone
+ * xlate_fir_decim_cf32 handle of the same design: how a Splitter hands running VFOs to a bank and back without a glitch.
+ * Synchronises the device; histories of different length are zeroed instead of copied. */
+int qdsp_hip_chan_cf32_move_channel_state(void* h, int chan, void* vfo_handle, int to_vfo);
 int64_t qdsp_hip_chan_cf32_out_size(void* h, int64_t count);
 int qdsp_hip_chan_cf32_set_phase_inc(void* h, int chan, float phase_inc_re, float phase_inc_im);
 int qdsp_hip_chan_cf32_set_mode(void* h, int mode);

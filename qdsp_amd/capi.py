@@ -135,6 +135,7 @@ def load():
     sig(p + "_process", i32, vp, vp, i32, vp, i32)
     sig(p + "_process_dev", i64, vp, vp, i64, vp, i64, vp)
     sig(p + "_process_links", i64, vp, vp, i32, i32, pvp, C.POINTER(i32), vp)
+    sig(p + "_move_channel_state", i32, vp, i32, vp, i32)
     sig(p + "_out_size", i64, vp, i64)
     sig(p + "_set_phase_inc", i32, vp, i32, C.c_float, C.c_float)
     sig(p + "_set_mode", i32, vp, i32)

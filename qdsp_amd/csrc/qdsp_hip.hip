@@ -2249,6 +2249,28 @@ int64_t qdsp_hip_chan_cf32_process_links(void* h, const void* in, int in_link, i
     if (must_wait) HIPCHK(hipStreamSynchronize(st));
     return nout;
 }
+// State hand-over between channel `chan` of a bank and a stand-alone fused-VFO handle of the same design: the NCO
+// phase (exact, 64-bit fixed point) and the filter history.  to_vfo != 0: channel -> handle, else handle -> channel.
+int qdsp_hip_chan_cf32_move_channel_state(void* h, int chan, void* vfo, int to_vfo) {
+    Chan* c = as_chan(h);
+    Engine* v = as_engine(vfo, KIND_VFO);
+    if (!c || !v || chan < 0 || chan >= c->nchan) return QDSP_HIP_EINVAL;
+    Engine* e = c->vfo[chan];
+    if (e->device != v->device) return QDSP_HIP_EINVAL;
+    apply_pending_inc(e);
+    apply_pending_inc(v);
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipDeviceSynchronize());          // (rare: a bank is built or taken down)
+    Engine* src = to_vfo ? e : v;
+    Engine* dst = to_vfo ? v : e;
+    dst->phase = src->phase;
+    dst->raw_valid = false;
+    if (src->H == dst->H && src->H > 0 && src->ch == dst->ch)
+        HIPCHK(hipMemcpy(dst->d_hist[dst->cur], src->d_hist[src->cur], (size_t)src->H * src->ch * sizeof(float), hipMemcpyDeviceToDevice));
+    else if (dst->H > 0)
+        HIPCHK(hipMemset(dst->d_hist[dst->cur], 0, (size_t)dst->H * dst->ch * sizeof(float)));
+    return 0;
+}
 int qdsp_hip_chan_cf32_set_phase_inc(void* h, int chan, float re, float im) {
     Chan* c = as_chan(h);
     if (!c || chan < 0 || chan >= c->nchan || (re == 0.0f && im == 0.0f)) return QDSP_HIP_EINVAL;

@@ -28,6 +28,7 @@ public:
         const bool live = base::running;
         base::stop();
         dropBank();
+        for (void*& e : bankEvt) { if (e) { qdsp_hip_event_destroy(e); e = nullptr; } }
         if (live && _in) { _in->releaseConsumer(); }
     }
 
@@ -71,6 +72,12 @@ public:
 private:
     // ---- N identical VFOs behind the outputs: one batched launch per block (vfo_bank.h) ------------------------------
     void dropBank() {
+        // every running VFO gets its channel's NCO phase and filter history back: it carries on without a glitch
+        if (ctl && ctl->bank) {
+            for (auto& m : members) {
+                if (m->alive.load() && m->handle) { qdsp_hip_chan_cf32_move_channel_state(ctl->bank, m->index, m->handle, 1); }
+            }
+        }
         for (auto& m : members) { std::atomic_store(&m->ctl, std::shared_ptr<detail::vfo_bank_ctl>()); }
         members.clear();
         if (ctl) {
@@ -79,7 +86,8 @@ private:
             ctl->bank = nullptr;
         }
         ctl.reset();
-        for (void*& e : bankEvt) { if (e) { qdsp_hip_event_destroy(e); e = nullptr; } }
+        // (the two completion events stay until the Splitter goes: a consumer downstream of a VFO may still be waiting
+        // on the one that travelled with the last banked block)
     }
 
     // all consumers idle (every link flushed): see whether they are N >= 2 live VFO cores of one design
@@ -90,22 +98,36 @@ private:
         std::vector<std::shared_ptr<detail::vfo_bank_member>> ms;
         for (stream<T>* s : out) {
             auto m = s->bankMember;
-            if (!m || !m->alive.load() || !m->out || std::atomic_load(&m->ctl)) { return false; }
+            if (!m || !m->alive.load() || std::atomic_load(&m->ctl)) { return false; }
             ms.push_back(m);
         }
-        for (auto& m : ms) {
-            if (m->taps != ms[0]->taps || m->interp != ms[0]->interp || m->decim != ms[0]->decim) { return false; }
+        // a consistent snapshot of every member's design
+        std::vector<float> taps0, re, im;
+        int interp0 = 0, decim0 = 0;
+        for (size_t i = 0; i < ms.size(); i++) {
+            std::lock_guard<std::mutex> lk(ms[i]->designMtx);
+            if (!ms[i]->out) { return false; }
+            if (i == 0) { taps0 = ms[i]->taps; interp0 = ms[i]->interp; decim0 = ms[i]->decim; }
+            else if (ms[i]->taps != taps0 || ms[i]->interp != interp0 || ms[i]->decim != decim0) { return false; }
+            re.push_back(ms[i]->dRe);
+            im.push_back(ms[i]->dIm);
         }
-        std::vector<float> re, im;
-        for (auto& m : ms) { re.push_back(m->dRe); im.push_back(m->dIm); }
+        if (taps0.empty()) { return false; }
         const int dev = detail::hipDeviceForBlocks();
         void* h = nullptr;
-        if (qdsp_hip_chan_cf32_create(&h, dev, ms[0]->taps.data(), (int)ms[0]->taps.size(), ms[0]->interp, ms[0]->decim, (int)ms.size(),
-                                      re.data(), im.data(), 0) != 0) { return false; }
-        if (qdsp_hip_event_create(dev, &bankEvt[0]) != 0 || qdsp_hip_event_create(dev, &bankEvt[1]) != 0) {
-            qdsp_hip_chan_cf32_destroy(h);
-            for (void*& e : bankEvt) { if (e) { qdsp_hip_event_destroy(e); e = nullptr; } }
+        if (qdsp_hip_chan_cf32_create(&h, dev, taps0.data(), (int)taps0.size(), interp0, decim0, (int)ms.size(), re.data(), im.data(), 0) != 0) {
             return false;
+        }
+        for (void*& e : bankEvt) {
+            if (!e && qdsp_hip_event_create(dev, &e) != 0) {
+                e = nullptr;
+                qdsp_hip_chan_cf32_destroy(h);
+                return false;
+            }
+        }
+        // a bank built mid-stream continues where the VFOs' own kernels stopped
+        for (size_t i = 0; i < ms.size(); i++) {
+            if (ms[i]->handle) { qdsp_hip_chan_cf32_move_channel_state(h, (int)i, ms[i]->handle, 0); }
         }
         ctl = std::make_shared<detail::vfo_bank_ctl>();
         ctl->bank = h;
@@ -115,7 +137,10 @@ private:
             std::atomic_store(&members[i]->ctl, ctl);
         }
         // a retune that raced the build: push every member's current increment again (they are applied between blocks)
-        for (auto& m : members) { qdsp_hip_chan_cf32_set_phase_inc(h, m->index, m->dRe, m->dIm); }
+        for (auto& m : members) {
+            std::lock_guard<std::mutex> lk(m->designMtx);
+            qdsp_hip_chan_cf32_set_phase_inc(h, m->index, m->dRe, m->dIm);
+        }
         return true;
     }
 

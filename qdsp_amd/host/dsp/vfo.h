@@ -41,16 +41,20 @@ public:
 
     void init(stream<complex_t>* in, const std::vector<float>& taps, int interp, int decim, float dRe, float dIm) {
         _in = in;
-        member->taps = taps;
-        member->interp = interp;
-        member->decim = decim;
-        member->dRe = dRe;
-        member->dIm = dIm;
-        member->out = &out;
-        _in->bankMember = member;     // (a Splitter upstream may run identical VFOs as one batched launch: vfo_bank.h)
         const int rc = qdsp_hip_xlate_fir_decim_cf32_create(&handle, hipDeviceForBlocks(), taps.data(), (int)taps.size(), interp,
                                                             decim, dRe, dIm, STREAM_BUFFER_SIZE);
         if (rc != 0) { handle = nullptr; hipBlockFail("VFO::init", rc); }
+        {
+            std::lock_guard<std::mutex> lk(member->designMtx);
+            member->taps = taps;
+            member->interp = interp;
+            member->decim = decim;
+            member->dRe = dRe;
+            member->dIm = dIm;
+            member->out = &out;
+            member->handle = handle;
+        }
+        if (handle) { _in->bankMember = member; }     // (a Splitter upstream may run identical VFOs as one batched launch: vfo_bank.h)
         base::registerInput(_in);
         base::registerOutput(&out);
         _in->claimConsumer(handle != nullptr, true);
@@ -59,9 +63,12 @@ public:
     void configure(const std::vector<float>& taps, int interp, int decim) {
         std::lock_guard<std::mutex> lck(base::ctrlMtx);
         base::tempStop();
-        member->taps = taps;
-        member->interp = interp;
-        member->decim = decim;
+        {
+            std::lock_guard<std::mutex> lk(member->designMtx);
+            member->taps = taps;
+            member->interp = interp;
+            member->decim = decim;
+        }
         if (auto ctl = std::atomic_load(&member->ctl)) { ctl->broken.store(true); }   // a bank built for the old design is taken down by its Splitter
         if (handle) {
             const int rc = qdsp_hip_xlate_fir_decim_cf32_configure(handle, taps.data(), (int)taps.size(), interp, decim);
@@ -72,8 +79,11 @@ public:
 
     void setPhaseInc(float dRe, float dIm) {
         if (handle) { qdsp_hip_xlate_fir_decim_cf32_set_phase_inc(handle, dRe, dIm); }
-        member->dRe = dRe;
-        member->dIm = dIm;
+        {
+            std::lock_guard<std::mutex> lk(member->designMtx);
+            member->dRe = dRe;
+            member->dIm = dIm;
+        }
         if (auto ctl = std::atomic_load(&member->ctl)) {
             std::lock_guard<std::mutex> lk(ctl->m);
             if (ctl->bank) { qdsp_hip_chan_cf32_set_phase_inc(ctl->bank, member->index, dRe, dIm); }

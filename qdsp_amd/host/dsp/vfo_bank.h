@@ -29,11 +29,14 @@ struct vfo_bank_ctl {
 };
 
 struct vfo_bank_member {
-    // the design the core runs (written by the core under its ctrlMtx with its worker stopped)
+    // the design the core runs: written by the core (init / configure / retune, any thread), read by the Splitter's
+    // worker when it builds a bank -- both under designMtx
+    std::mutex designMtx;
     std::vector<float> taps;
     int interp = 1, decim = 1;
     float dRe = 1.0f, dIm = 0.0f;
     stream<complex_t>* out = nullptr;   // the core's output stream
+    void* handle = nullptr;             // the core's own xlate_fir_decim_cf32 handle: idle while banked, takes the channel's state back afterwards
     std::atomic<bool> alive{true};
     // while banked
     std::shared_ptr<vfo_bank_ctl> ctl;  // nullptr = not banked: the core runs its own kernel

@@ -24,6 +24,10 @@
 //                      prints input Msamples/s and microseconds per block
 //   graph_check split  <in.cf32> <out_prefix> <block> <n> <inSR> <outSR> <bw>
 //                      source -> Splitter -> n x VFO(offset_i = (i - (n-1)/2) * inSR/n) -> sinks
+//   graph_check splitretune <in.cf32> <out_prefix> <block> <n> <inSR> <outSR> <bw> <K> <newOffset> [reconf]
+//                      as split, but before block K is fed (and after every sink has blocks 0..K-1) VFO 1 is retuned to
+//                      newOffset (setOffset, vfo.h:78-82: the bank's channel follows); with `reconf` VFO 0 is given a new
+//                      bandwidth instead (setBandwidth: the bank is taken down, every VFO runs its own kernel again)
 //   graph_check mulsplit <in.cf32> <out_prefix> <block> <n> <inSR> <outSR> <bw>
 //                      source -> Splitter (host-fed) -> Multiply(x, x) -> Splitter -> n x VFO -> sinks: the second
 //                      Splitter's input comes from a producer OUTSIDE the library's pipelined stream, so its
@@ -494,6 +498,83 @@ int main(int argc, char** argv) {
             o.write(reinterpret_cast<const char*>(cols[i]->data.data()), (std::streamsize)(cols[i]->data.size() * sizeof(complex_t)));
         }
         printf("split ok: %d channels, %zu in, %zu out each\n", n, feed.data.size(), cols[0]->data.size());
+        for (auto* s : sinks) { delete s; }
+        for (auto* v : vfos) { delete v; }
+        for (auto* l : links) { delete l; }
+        for (auto* c : cols) { delete c; }
+        return 0;
+    }
+    if (mode == "splitretune" && argc >= 11) {
+        const int n = atoi(argv[5]);
+        const float inSR = (float)atof(argv[6]), outSR = (float)atof(argv[7]), bw = (float)atof(argv[8]);
+        const long K = atol(argv[9]);
+        const float newOff = (float)atof(argv[10]);
+        const bool reconf = argc >= 12 && std::string(argv[11]) == "reconf";
+        struct Gate {
+            Feed<complex_t> feed;
+            std::vector<Collect<complex_t>*>* cols = nullptr;
+            std::vector<VFO*>* vfos = nullptr;
+            long K = 0, fed = 0;
+            float newOff = 0, bw2 = 0;
+            bool reconf = false;
+            static int pull(complex_t* dst, void* ctx) {
+                Gate* g = static_cast<Gate*>(ctx);
+                if (g->fed == g->K) {
+                    // every block fed so far has come out of every sink: the graph is idle, the change lands exactly here
+                    for (auto* c : *g->cols) {
+                        while (c->blocks.load() < g->K) { std::this_thread::sleep_for(std::chrono::microseconds(200)); }
+                    }
+                    if (g->reconf) { (*g->vfos)[0]->setBandwidth(g->bw2); }
+                    else { (*g->vfos)[1]->setOffset(g->newOff); }
+                }
+                g->fed++;
+                return Feed<complex_t>::pull(dst, &g->feed);
+            }
+        };
+        Gate gate;
+        gate.feed.data = readAll<complex_t>(in);
+        gate.feed.block = block;
+        gate.K = K;
+        gate.newOff = newOff;
+        gate.bw2 = bw * 0.5f;
+        gate.reconf = reconf;
+        const long nblocks = (long)((gate.feed.data.size() + block - 1) / block);
+        HandlerSource<complex_t> src(Gate::pull, &gate);
+        Splitter<complex_t> split(&src.out);
+        std::vector<stream<complex_t>*> links;
+        std::vector<VFO*> vfos;
+        std::vector<Collect<complex_t>*> cols;
+        std::vector<HandlerSink<complex_t>*> sinks;
+        for (int i = 0; i < n; i++) {
+            links.push_back(new stream<complex_t>());
+            const float off = ((float)i - (float)(n - 1) / 2.0f) * inSR / (float)n;
+            vfos.push_back(new VFO(links[i], off, inSR, outSR, bw));
+            split.bindStream(links[i]);
+            cols.push_back(new Collect<complex_t>());
+            sinks.push_back(new HandlerSink<complex_t>(vfos[i]->out, Collect<complex_t>::push, cols[i]));
+        }
+        gate.cols = &cols;
+        gate.vfos = &vfos;
+        for (auto* s : sinks) { s->start(); }
+        for (auto* v : vfos) { v->start(); }
+        split.start();
+        src.start();
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < n; i++) {
+            while (cols[i]->blocks.load() < nblocks) {
+                std::this_thread::sleep_for(std::chrono::milliseconds(1));
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) { fprintf(stderr, "splitretune graph timed out\n"); return 3; }
+            }
+        }
+        src.stop();
+        split.stop();
+        for (auto* v : vfos) { v->stop(); }
+        for (auto* s : sinks) { s->stop(); }
+        for (int i = 0; i < n; i++) {
+            std::ofstream o(std::string(out) + "." + std::to_string(i) + ".cf32", std::ios::binary);
+            o.write(reinterpret_cast<const char*>(cols[i]->data.data()), (std::streamsize)(cols[i]->data.size() * sizeof(complex_t)));
+        }
+        printf("splitretune ok: %d channels, %zu in, %zu out each\n", n, gate.feed.data.size(), cols[0]->data.size());
         for (auto* s : sinks) { delete s; }
         for (auto* v : vfos) { delete v; }
         for (auto* l : links) { delete l; }

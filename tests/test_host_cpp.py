@@ -237,6 +237,42 @@ def test_graph_splitter_to_vfos(harness, data):
 
 
 @gpu
+def test_graph_bank_retune_and_reconfigure(harness, data):
+    """Splitter -> 4 x VFO runs as a bank (one batched launch per block, dsp/vfo_bank.h).  (1) setOffset on one VFO while
+    the graph is live reaches the bank's channel: phase continuous, increment changed from block K on -- exact against the
+    oracle.  (2) setBandwidth on one VFO takes the bank down: every VFO gets its channel's NCO phase and filter history back
+    (qdsp_hip_chan_cf32_move_channel_state) and runs its own kernel again: the untouched channels stay exact against the
+    oracle across the hand-back, the re-designed one up to the change."""
+    d, x = data
+    b, n, K = 20_000, 4, 3
+    offs = [np.float32((np.float32(i) - np.float32(n - 1) / np.float32(2.0)) * np.float32(2.4e6) / np.float32(n)) for i in range(n)]
+    nblk = (len(x) + b - 1) // b
+    assert nblk > K + 2
+    new_off = 123456.0
+    run([harness, "splitretune", str(d / "x.cf32"), str(d / "yrt"), str(b), str(n), "2400000", "240000", "200000", str(K), str(new_off)])
+    for i in range(n):
+        y = np.fromfile(str(d / "yrt") + f".{i}.cf32", dtype=np.complex64)
+        v = O.Vfo(float(offs[i]), 2.4e6, 240e3, 200e3, exact_nco=True, volk_gain=True)
+        want = []
+        for k, j in enumerate(range(0, len(x), b)):
+            if i == 1 and k == K:
+                v.xl.delta[:] = O.Xlator(2.4e6, -new_off).delta      # VFO: xlator(-offset), vfo.h:28
+            want.append(v.process(x[j:j + b]))
+        want = np.concatenate(want)
+        assert len(y) == len(want) and rel_rms(y, want) < 3e-6, i
+    run([harness, "splitretune", str(d / "x.cf32"), str(d / "yrc"), str(b), str(n), "2400000", "240000", "200000", str(K), "0", "reconf"])
+    per = b // 10
+    for i in range(n):
+        y = np.fromfile(str(d / "yrc") + f".{i}.cf32", dtype=np.complex64)
+        v = O.Vfo(float(offs[i]), 2.4e6, 240e3, 200e3, exact_nco=True, volk_gain=True)
+        want = np.concatenate([v.process(x[j:j + b]) for j in range(0, len(x), b)])
+        assert len(y) == len(want)
+        assert rel_rms(y[:K * per], want[:K * per]) < 3e-6, i          # banked blocks
+        if i != 0:                                                     # own kernel from block K on, state handed back: no glitch
+            assert rel_rms(y, want) < 3e-6, i
+
+
+@gpu
 def test_graph_multiply_into_splitter_to_vfos(harness, data):
     """source -> Splitter -> Multiply(x, x) -> Splitter -> 8 x VFO -> sinks.  The second Splitter's input is a
     device-resident block from a producer that does not launch into the library's pipelined stream (the math block has
