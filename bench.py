@@ -400,6 +400,10 @@ def run_workload(name: str, args, ctx) -> dict:
         # MACs (512), radix-16 (~200), twiddles (~90), radix-4 across the quad (~220), per-channel
         # rotation (~320): ~1350 FLOP x 64 lanes / 1024 input samples
         flops = 84.0 * (64 // w["decim"])
+    elif kinfo["name"] == "decim_mfma_kernel":
+        # FP32 MFMA: per tile of 16 rows (16 * decim samples) 4 * ceil(decim / 8) v_mfma_f32_16x16x4_f32 of 2048 FLOP (the
+        # A operand carries 16 tap rows whatever the tap count), one tile in 17 read twice; + ~14 VALU FLOP per sample (NCO)
+        flops = 2048.0 * 4 * ((w["decim"] + 7) // 8) / (16 * w["decim"]) * 17 / 16 + (14.0 if w["rot"] else 0.0)
     achieved_tf = flops * n / (kms * 1e-3) / 1e12
     res = {
         "value": round(value, 1),
@@ -427,7 +431,7 @@ def run_workload(name: str, args, ctx) -> dict:
             "launch": {"grid": kinfo["grid"], "block": kinfo["block"], "lds_bytes": kinfo["lds_bytes"]},
         },
         "roofline_fp32": {
-            "bound": "valu",
+            "bound": "mfma" if kinfo["name"] == "decim_mfma_kernel" else "valu",
             "achieved": round(achieved_tf, 2),
             "peak": FP32_PEAK_TFLOPS,
             "unit": "TFLOP/s",

@@ -1,0 +1,207 @@
+// mf_dec.hip -- MFMA decimator for large integer decimations (design notes: mf_dec.hip.h).
+#include "mf_dec.hip.h"
+#include "kernels.hip.h"
+
+namespace qk {
+
+namespace {
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// value of `src` in the lane the DPP control pairs this one with; lanes whose source is outside the row read 0, lanes
+// in rows outside ROWMASK keep `old`
+template <int CTRL, int ROWMASK = 0xf> __device__ __forceinline__ float dpp(float old, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL, ROWMASK, 0xf, true));
+}
+constexpr int kShl = 0x100, kShr = 0x110;      // row_shl:n -- lane i reads lane i + n;  row_shr:n -- lane i reads lane i - n
+
+// Diagonal sums of a 16 x 16 result tile.  d[v] = Z[4g + v][rho] on lane 16 g + rho.  cur[rho] collects the terms
+// Z[q][rho + q] with rho + q < 16 (output rho of THIS tile), prev[rho] the terms with rho + q >= 16, i.e. Z[q][rho + q - 16]
+// (output rho of the PREVIOUS tile); both still spread over the four lane groups.
+__device__ __forceinline__ void diag_sum(const f32x4 d, float& cur, float& prev) {
+    // within a group: shift by the register index
+    float i_ = d[0] + dpp<kShl + 1>(0.0f, d[1]);
+    i_ += dpp<kShl + 2>(0.0f, d[2]);
+    i_ += dpp<kShl + 3>(0.0f, d[3]);                           // I[e] = sum_v Z[4g+v][e + v], e + v < 16
+    float r_ = dpp<kShr + 15>(0.0f, d[1]);
+    r_ += dpp<kShr + 14>(0.0f, d[2]);
+    r_ += dpp<kShr + 13>(0.0f, d[3]);                          // R[e + 16] = the same for e = -3..-1
+    // per group: shift by 4 g
+    float c = i_;
+    c = dpp<kShl + 4, 0x2>(c, i_);
+    c = dpp<kShl + 8, 0x4>(c, i_);
+    c = dpp<kShl + 12, 0x8>(c, i_);
+    float p = r_;
+    p = dpp<kShl + 4, 0x2>(p, r_);
+    p = dpp<kShl + 8, 0x4>(p, r_);
+    p = dpp<kShl + 12, 0x8>(p, r_);
+    float w = dpp<kShr + 12, 0x2>(0.0f, i_);
+    w = dpp<kShr + 8, 0x4>(w, i_);
+    w = dpp<kShr + 4, 0x8>(w, i_);
+    cur = c;
+    prev = p + w;
+}
+}  // namespace
+
+template <int KJ, bool ROT, int DEPTH>
+__global__ __launch_bounds__(256, KJ * DEPTH <= 8 ? 4 : (KJ * DEPTH <= 12 ? 3 : 2)) void decim_mfma_kernel(const MfArgs a) {
+    constexpr int K = 8 * KJ, PITCH = K + 2, NI = 2 * KJ;
+    const int t = threadIdx.x, l = t & 63;
+    const int P = a.P, M = a.M;
+    if ((int)blockIdx.x == (a.ntasks + 3) / 4) {
+        // history hand-over (resampling.h:129): last P samples of hist ++ in, rotated for the fused VFO
+        for (int i = t; i < P; i += 256) {
+            const long long g = a.count - P + i;
+            float2 v;
+            if (g < 0) v = a.hist[g + P];
+            else {
+                v = a.in[g];
+                if (ROT) v = rotate(v, phasor_fx(a.phase0 + (unsigned long long)g * a.dphase), g, a.gm1);
+            }
+            a.hist_next[i] = v;
+        }
+        return;
+    }
+    __shared__ __attribute__((aligned(16))) float2 tile_all[4][16 * PITCH + 64];      // + a spare slot per lane
+    float2* tile = tile_all[t >> 6];
+    const int task = (int)blockIdx.x * 4 + (t >> 6);
+    if (task >= a.ntasks) return;
+    const long long n0 = (long long)task * a.T;
+    long long n1 = n0 + a.T;
+    if (n1 > a.nout) n1 = a.nout;
+    const int ntiles = (int)((n1 - n0 + 15) >> 4) + 1;        // + 1: the rows the last outputs reach into
+    const int E = 16 * M;                                     // samples per tile
+
+    // columns M..K-1 of the rows are never written: they meet zero taps, but must hold finite values
+    for (int i = l; i < 16 * PITCH; i += 64) tile[i] = make_float2(0.0f, 0.0f);
+
+    float ta[KJ][2];
+#pragma unroll
+    for (int jj = 0; jj < KJ; jj++) {
+        ta[jj][0] = a.tapk[(2 * jj) * 64 + l];
+        ta[jj][1] = a.tapk[(2 * jj + 1) * 64 + l];
+    }
+    // element i of a tile for this lane: sample 64 i + l of its 16 M, LDS slot [row][col]; the elements past the tile's end
+    // (only the last two loads can reach there) re-read its last sample and park it in the lane's spare slot
+    int woff[NI];
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+        const int idx = 64 * i + l;
+        const int row = idx / M;
+        woff[i] = idx < E ? row * PITCH + (idx - row * M) : 16 * PITCH + l;
+    }
+    const int e1 = min(64 * (NI - 2) + l, E - 1), e2 = min(64 * (NI - 1) + l, E - 1);
+    // B operand of this lane: row l % 16, columns 8 jj + 2 (l / 16) + {0, 1}
+    const float4* brd = reinterpret_cast<const float4*>(tile + (l & 15) * PITCH + 2 * (l >> 4));
+
+    const long long gbase = (long long)M * n0 - P;            // sample index (relative to in[0]) of tile 0's element 0
+    double2 pd;
+    if (ROT) pd = phasor_fx(a.phase0 + (unsigned long long)(gbase + l) * a.dphase);
+
+    // DEPTH tiles are in flight in registers ahead of the one being multiplied
+    float2 xb[DEPTH][NI];
+    bool plainb[DEPTH];
+    const bool tail = 64 * (NI - 1) < E;                      // wave-uniform: the last load holds samples of the tile at all
+    auto tile_plain = [&](int tt) {                           // wave-uniform: the whole tile is plain input
+        const long long g0 = gbase + (long long)E * tt;
+        return tt < ntiles && g0 >= 0 && g0 + E <= a.count;
+    };
+    auto load_tile = [&](int tt, float2 (&xn)[NI]) {
+        const float2* __restrict__ p = a.in + (gbase + (long long)E * tt);
+#pragma unroll
+        for (int i = 0; i < NI - 2; i++) xn[i] = p[64 * i + l];
+        xn[NI - 2] = p[e1];
+        if (tail) xn[NI - 1] = p[e2];
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) {
+        plainb[d] = tile_plain(d);
+        if (plainb[d]) load_tile(d, xb[d]);
+    }
+    float carry_re = 0.0f, carry_im = 0.0f;
+    auto do_tile = [&](int tt, float2 (&xn)[NI], bool& plain) {
+        const long long g0 = gbase + (long long)E * tt;
+        float2 pf;
+        int m0;
+        if (ROT) {
+            pf = make_float2((float)pd.x, (float)pd.y);
+            m0 = (int)((g0 + l) & 511);
+        }
+        auto spin = [&](float2 v, int i) {                     // NCO: lane phasor of the tile x table inside it
+            const float2 w = a.rot_k[i];
+            const float gain = fmaf((float)((m0 + 64 * i) & 511), a.gm1, 1.0f);   // VOLK's magnitude sawtooth (rotate(), kernels.hip.h)
+            const float pr = fmaf(pf.x, w.x, -pf.y * w.y) * gain, pi = fmaf(pf.x, w.y, pf.y * w.x) * gain;
+            return rot_apply(v, pr, pi);
+        };
+        if (plain) {
+#pragma unroll
+            for (int i = 0; i < NI; i++)
+                if (i < NI - 1 || tail) tile[woff[i]] = ROT ? spin(xn[i], i) : xn[i];
+        } else {
+            // a tile that touches the history or the end of the call (the first and the last of a call): rolled, guarded
+#pragma unroll 1
+            for (int i = 0; i < NI; i++) {
+                const int idx = 64 * i + l;
+                if (idx < E) {
+                    const long long g = g0 + idx;
+                    float2 v = make_float2(0.0f, 0.0f);
+                    if (g < 0) { if (g + P >= 0) v = a.hist[g + P]; }               // (history is already rotated)
+                    else if (g < a.count) {
+                        v = a.in[g];
+                        if (ROT) v = spin(v, i);
+                    }
+                    const int row = idx / M;
+                    tile[row * PITCH + (idx - row * M)] = v;
+                }
+            }
+        }
+        if (ROT) pd = cmul(pd, a.rot_step);
+        plain = tile_plain(tt + DEPTH);
+        if (plain) load_tile(tt + DEPTH, xn);
+
+        f32x4 zr = {0.0f, 0.0f, 0.0f, 0.0f}, zi = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int jj = 0; jj < KJ; jj++) {
+            const float4 b = brd[4 * jj];                                        // 8 samples = 64 B further per step
+            zr = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[jj][0], b.x, zr, 0, 0, 0);
+            zi = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[jj][0], b.y, zi, 0, 0, 0);
+            zr = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[jj][1], b.z, zr, 0, 0, 0);
+            zi = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[jj][1], b.w, zi, 0, 0, 0);
+        }
+        float cur_re, prev_re, cur_im, prev_im;
+        diag_sum(zr, cur_re, prev_re);
+        diag_sum(zi, cur_im, prev_im);
+        float o_re = carry_re + prev_re, o_im = carry_im + prev_im;              // outputs of the previous tile, complete
+        carry_re = cur_re;
+        carry_im = cur_im;
+        o_re += __shfl_xor(o_re, 16);
+        o_im += __shfl_xor(o_im, 16);
+        o_re += __shfl_xor(o_re, 32);
+        o_im += __shfl_xor(o_im, 32);
+        const long long n = n0 + 16LL * (tt - 1) + l;
+        if (tt > 0 && l < 16 && n < n1) a.out[n] = make_float2(o_re, o_im);
+    };
+    for (int tt = 0; tt < ntiles; tt += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++)
+            if (tt + d < ntiles) do_tile(tt + d, xb[d], plainb[d]);
+    }
+}
+
+int launch_mf_dec(const MfArgs& a, int KJ, bool rot, int depth, hipStream_t stream) {
+    const dim3 grid((a.ntasks + 3) / 4 + 1), block(256);
+#define QK_MF(k)                                                                                           \
+    if (KJ == k) {                                                                                         \
+        if (rot && depth == 2) hipLaunchKernelGGL((decim_mfma_kernel<k, true, 2>), grid, block, 0, stream, a);          \
+        else if (rot) hipLaunchKernelGGL((decim_mfma_kernel<k, true, 1>), grid, block, 0, stream, a);      \
+        else if (depth == 2) hipLaunchKernelGGL((decim_mfma_kernel<k, false, 2>), grid, block, 0, stream, a);           \
+        else hipLaunchKernelGGL((decim_mfma_kernel<k, false, 1>), grid, block, 0, stream, a);              \
+        const hipError_t e = hipGetLastError();                                                            \
+        return e == hipSuccess ? 0 : -(int)e;                                                              \
+    }
+    QK_MF(2) QK_MF(3) QK_MF(4) QK_MF(5) QK_MF(6) QK_MF(7) QK_MF(8)
+    QK_MF(9) QK_MF(10) QK_MF(11) QK_MF(12) QK_MF(13) QK_MF(14) QK_MF(15) QK_MF(16)
+#undef QK_MF
+    return -1;
+}
+
+}  // namespace qk

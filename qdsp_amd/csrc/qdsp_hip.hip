@@ -6,6 +6,7 @@
 #include "fft_fir.hip.h"
 #include "chan.hip.h"
 #include "pfb_dec.hip.h"
+#include "mf_dec.hip.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -88,6 +89,8 @@ struct Engine {
     float2* d_fft_TB = nullptr;
     int fft_ntaps = -1;         // tap count d_fft_H was built for (-1: not built)
     unsigned long long fft_dphase = 0;   // NCO increment d_fft_H was built for (fused VFO), 0 otherwise
+    float* d_taps_mf = nullptr;    // MFMA decimator (mf_dec.hip.h): [2 KJ][64] A operands, built with the taps
+    int mf_KJ = 0;
     // polyphase overlap-save decimate-by-8 (pfb_dec.hip.h): column spectra + twiddles, built for (pfb_ntaps, pfb_dphase)
     float2* d_pfb = nullptr;
     int pfb_ntaps = -1;
@@ -231,6 +234,22 @@ bool use_lm(const Engine* e) {
     return e->M >= 1 && e->M <= 8 && env_int("QDSP_HIP_NO_LM", 0) == 0;
 }
 
+// Shapes the MFMA decimator (mf_dec.hip.h) serves: complex data, interp 1, at most 16 taps per polyphase column (the 16
+// rows of the A operand), decimation up to 128 (a tile of 16 rows is prefetched in registers).  Its time hardly depends
+// on the tap count (0.21-0.25 ms per 2^27 samples from decimation 14 up, profiles/r02_tune_mf.md); below decimation 14
+// the tiles get small and it only wins over the strided-window / general kernels from ~12 taps per unit of decimation,
+// and the strided-window kernel keeps the short filters at decimation 16.
+bool mf_plan(const Engine* e, int* KJ) {
+    if (e->ch != 2 || e->L != 1 || !e->has_filter || e->kind == KIND_FIR) return false;
+    const int M = e->M, P = e->P;
+    if (M < env_int("QDSP_HIP_MF_MIN_DECIM", 9) || M > 8 * qk::kMfMaxKJ) return false;
+    if ((P + M - 1) / M > qk::kMfMaxQ) return false;
+    if (M < 14 && P < 12 * M) return false;
+    if (use_win(e) && P < 6 * M) return false;
+    *KJ = (M + 7) / 8;
+    return true;
+}
+
 int upload_taps(Engine* e, const float* taps, int ntaps) {
     // FIR: h[k] pairs with s[n - (ntaps-1) + k]  -> core with M=1, Q=ntaps, H=ntaps-1
     // resampler L==1: tapPhases[0][t] = taps[t]   -> core with M, Q=ceil(P/M), H=P
@@ -279,6 +298,24 @@ int upload_taps(Engine* e, const float* taps, int ntaps) {
         e->taps_lm_t_off = M == 1 ? n1 : 0;
         HIPCHK(hipMalloc(&e->d_taps_lm, lm.size() * sizeof(float)));
         HIPCHK(hipMemcpy(e->d_taps_lm, lm.data(), lm.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    // MFMA decimator (mf_dec.hip.h): A operand of step (jj, a), lane l = tap row q = l % 16, column 8 jj + 2 (l / 16) + a
+    if (e->d_taps_mf) { HIPCHK(hipFree(e->d_taps_mf)); e->d_taps_mf = nullptr; }
+    e->mf_KJ = 0;
+    {
+        int KJ = 0;
+        if (mf_plan(e, &KJ)) {
+            std::vector<float> tk((size_t)2 * KJ * 64, 0.0f);
+            for (int jj = 0; jj < KJ; jj++)
+                for (int a = 0; a < 2; a++)
+                    for (int l = 0; l < 64; l++) {
+                        const int q = l % 16, col = 8 * jj + 2 * (l / 16) + a, k = e->M * q + col;
+                        if (col < e->M && k < e->P) tk[(size_t)(2 * jj + a) * 64 + l] = taps[k];
+                    }
+            HIPCHK(hipMalloc(&e->d_taps_mf, tk.size() * sizeof(float)));
+            HIPCHK(hipMemcpy(e->d_taps_mf, tk.data(), tk.size() * sizeof(float), hipMemcpyHostToDevice));
+            e->mf_KJ = KJ;
+        }
     }
     return 0;
 }
@@ -405,6 +442,7 @@ void destroy(Engine* e) {
     if (e->d_fft_TA) (void)hipFree(e->d_fft_TA);
     if (e->d_fft_TB) (void)hipFree(e->d_fft_TB);
     if (e->d_pfb) (void)hipFree(e->d_pfb);
+    if (e->d_taps_mf) (void)hipFree(e->d_taps_mf);
     for (int i = 0; i < 2; i++)
         if (e->d_hist[i]) (void)hipFree(e->d_hist[i]);
     if (e->d_in) (void)hipFree(e->d_in);
@@ -877,6 +915,8 @@ bool pfb_eligible(const Engine* e, int64_t count) {
     // measured crossover (scripts/tune_pfb_threshold.py, 256 taps): a lone segment takes a wave ~7 us (15 us per call
     // with the table load) where fir_fft_kernel<8> needs 8 us, so the per-segment kernels keep the reference-sized
     // calls; from 2^23 samples (decimator) / 2^24 (fused VFO) on this form is ahead, 1.2x at 2^27
+    // (never below one segment: the kernel's prefetch reads whole 4096-sample segments from a clamped in-range start)
+    if (count < qk::kPfbSeg) return false;
     return count >= (int64_t)env_int("QDSP_HIP_PFB_MIN_COUNT", e->rotate ? 1 << 24 : 1 << 23);
 }
 
@@ -1149,6 +1189,47 @@ int launch_xlate_inc(Engine* e, const void* d_in, int64_t count, void* d_out, un
     return 0;
 }
 
+int launch_mf(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d_out, hipStream_t s) {
+    qk::MfArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = static_cast<const float2*>(d_in);
+    a.out = static_cast<float2*>(d_out);
+    a.hist = reinterpret_cast<const float2*>(e->d_hist[e->cur]);
+    a.hist_next = reinterpret_cast<float2*>(e->d_hist[e->cur ^ 1]);
+    a.tapk = e->d_taps_mf;
+    a.count = count;
+    a.nout = nout;
+    a.P = e->P;
+    a.M = e->M;
+    // outputs per wave task: a task reads one tile of 16 rows beyond its own (T = 256: 6 %); small calls take shorter
+    // tasks so that a reference-sized block still spreads over the chip (1e6 samples at decimation 50: 20 000 outputs)
+    long long T = nout / env_int("QDSP_HIP_MF_TASKS", 8192);
+    T = (T + 15) / 16 * 16;
+    const long long tmax = env_int("QDSP_HIP_MF_TASK_MAX", e->rotate ? 256 : 128);
+    if (T > tmax) T = tmax;
+    if (T < 16) T = 16;
+    a.T = (int)T;
+    a.ntasks = (int)((nout + T - 1) / T);
+    if (e->rotate) {
+        a.phase0 = e->phase;
+        a.dphase = e->dphase;
+        a.gm1 = e->volk_gain ? e->gm1 : 0.0f;
+        unit_of_fx(e->dphase, 16.0L * (long double)e->M, &a.rot_step.x, &a.rot_step.y);
+        for (int k = 0; k < 2 * e->mf_KJ; k++) {
+            double c, sn;
+            unit_of_fx(e->dphase, 64.0L * (long double)k, &c, &sn);
+            a.rot_k[k] = make_float2((float)c, (float)sn);
+        }
+    }
+    const int rc = qk::launch_mf_dec(a, e->mf_KJ, e->rotate, env_int("QDSP_HIP_MF_DEPTH", e->mf_KJ <= 8 ? 2 : 1), s);
+    if (rc) return rc < 0 && rc != -1 ? rc : QDSP_HIP_EINVAL;
+    e->last.name = "decim_mfma_kernel";
+    e->last.grid = (a.ntasks + 3) / 4 + 1;
+    e->last.block = 256;
+    e->last.lds = 4 * 16 * (8 * e->mf_KJ + 2) * (int)sizeof(float2);
+    return 0;
+}
+
 // One run() worth of work on device pointers.  Returns the output count.
 int64_t process_dev(Engine* e, const void* d_in, int64_t count, void* d_out, void* stream) {
     if (count < 0 || (count > 0 && ((!d_in && e->kind != KIND_SINE) || !d_out))) return QDSP_HIP_EINVAL;
@@ -1160,6 +1241,10 @@ int64_t process_dev(Engine* e, const void* d_in, int64_t count, void* d_out, voi
     bool took_fft = false;
     if (!e->has_filter) {
         rc = launch_xlate(e, d_in, count, d_out, s);
+    } else if (e->d_taps_mf && mode_of(e) == 0 && nout > 0 && !env_int("QDSP_HIP_NO_MF", 0)) {
+        // large integer decimations (the VFO's usual job) as an FP32 matrix product on the MFMA units (mf_dec.hip.h)
+        rc = launch_mf(e, d_in, count, nout, d_out, s);
+        if (rc == 0) e->cur ^= 1;
     } else if (fft_eligible(e, count) && !(mode_of(e) == 0 && use_win(e) && e->d_taps_lm)) {
         rc = launch_fft(e, d_in, count, nout, d_out, s);
         if (rc == 0) e->cur ^= 1;

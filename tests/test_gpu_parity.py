@@ -284,14 +284,14 @@ def test_polyphase_overlap_save_decimator_vs_oracle(ops, monkeypatch, ntaps, rot
     monkeypatch.setenv("QDSP_HIP_PFB_MIN_COUNT", "0")
     taps = O.lowpass_taps_f64(ntaps, 1 / 16).astype(np.float32) if ntaps > 8 else np.arange(1, ntaps + 1, dtype=np.float32)
     x = O.synth_iq(0, 500_000, seed=800 + ntaps)
-    cuts = [0, 8 * 13001, 8 * 13001 + 8 * 9, 8 * 30000 + 3, 8 * 30000 + 4096 + 3, 500_000]
+    cuts = [0, 8 * 13001, 8 * 13001 + 8 * 9, 8 * 30000 + 3, 8 * 30000 + 4096 + 3, 500_000]      # (the 72-sample call is below one segment: 4096-point kernel)
     inc = ops.phase_delta(1.0, 0.1234)
     op = ops.Vfo(taps, 1, 8, inc, max_block=0) if rot else ops.Resampler(taps, 1, 8, max_block=0)
     op.set_mode(op.FFT)
     ys = []
     for a, b in zip(cuts, cuts[1:]):
         ys.append(op.process(dev(x[a:b])).cpu().numpy())
-        assert op.last_kernel()["name"] == "pfb_dec8_kernel"
+        assert (op.last_kernel()["name"] == "pfb_dec8_kernel") == (b - a >= 4096)
     torch.cuda.synchronize()
     y = np.concatenate(ys)
     rs = O.Resampler(taps, 1, 8, acc=O.ACC_F64)
@@ -1043,36 +1043,75 @@ def test_vfo_retune_mid_stream(ops, gold, M, ntaps):
 
 @pytest.mark.parametrize("M,ntaps", [(9, 63), (20, 127), (32, 255), (40, 321), (50, 401), (64, 513), (100, 801), (128, 255),
                                       (147, 1177), (192, 1537), (250, 2001), (1000, 2049), (2500, 1999)])
-def test_large_decimation_direct_kernel(ops, M, ntaps):
-    """The VFO's usual job (2.4 Msps -> 48 kHz is M = 50) with the reference's ~8 taps per unit of decimation: AUTO
-    takes the general direct kernel (padded LDS layout when M is a multiple of 4; 4-16 lanes per output from tiles of
-    64 outputs down), as decimator and as fused VFO, over blocks that end inside tiles.  The tap split adds partial
-    sums in a different order than the k-ordered chain, so the bar is the FP64 oracle, not bit equality."""
+def test_large_decimation_direct_kernel(ops, M, ntaps, monkeypatch):
+    """The VFO's usual job (2.4 Msps -> 48 kHz is M = 50) with the reference's ~8 taps per unit of decimation, as
+    decimator and as fused VFO, over blocks that end inside tiles.  AUTO takes the MFMA decimator (decimation 14-128,
+    at most 16 taps per column: mf_dec.hip.h) and the general direct kernel beyond (padded LDS layout when M is a
+    multiple of 4; 4-16 lanes per output from tiles of 64 outputs down); the general kernel is run on every shape
+    (QDSP_HIP_NO_MF).  Neither adds its partial sums in the order of the k-ordered chain, so the bar is the FP64
+    oracle, not bit equality."""
     taps = O.lowpass_taps_f64(ntaps, 0.4 / M).astype(np.float32)
     sizes = [M * 4096 + 17, 5, M * 1500] if M < 1000 else [M * 300 + 17, 5, M * 100]
     x = O.synth_iq(0, sum(sizes), seed=M)
     cuts = np.cumsum([0] + sizes)
     blocks = [x[a:b] for a, b in zip(cuts, cuts[1:])]
+    mf = 14 <= M <= 128 and -(-ntaps // M) <= 16
     for vfo in (False, True):
         if vfo:
-            op = ops.Vfo(taps, 1, M, ops.phase_delta(1.0, 0.2345), max_block=0)
             xl, rs = O.Xlator(1.0, 0.2345, exact=True, volk_gain=True), O.Resampler(taps, 1, M, acc=O.ACC_F64)
             want = np.concatenate([rs.process(xl.process(b)) for b in blocks])
         else:
-            op = ops.Resampler(taps, 1, M, max_block=0)
             rs = O.Resampler(taps, 1, M, acc=O.ACC_F64)
             want = np.concatenate([rs.process(b) for b in blocks])
-        if M >= 1000:
-            op.set_mode(op.DIRECT)      # (AUTO: overlap-save; here the tap split at 1-8 outputs per tile is under test)
-        got = np.concatenate([op.process(dev(b)).cpu().numpy() for b in blocks])
-        assert op.last_kernel()["name"] == "resamp_any_kernel", (M, ntaps, vfo, op.last_kernel())
-        assert got.shape == want.shape and rel_rms(got, want) < 2e-6, (M, ntaps, vfo)
+        mk = (lambda: ops.Vfo(taps, 1, M, ops.phase_delta(1.0, 0.2345), max_block=0)) if vfo else (lambda: ops.Resampler(taps, 1, M, max_block=0))
+        for no_mf in ((False, True) if mf else (True,)):
+            monkeypatch.setenv("QDSP_HIP_NO_MF", "1" if no_mf else "0")
+            op = mk()
+            if M >= 1000:
+                op.set_mode(op.DIRECT)      # (AUTO: overlap-save; here the tap split at 1-8 outputs per tile is under test)
+            got = np.concatenate([op.process(dev(b)).cpu().numpy() for b in blocks])
+            assert op.last_kernel()["name"] == ("resamp_any_kernel" if no_mf else "decim_mfma_kernel"), (M, ntaps, vfo, op.last_kernel())
+            assert got.shape == want.shape and rel_rms(got, want) < 2e-6, (M, ntaps, vfo, no_mf)
         # the overlap-save form of the same plan agrees
-        ref = ops.Vfo(taps, 1, M, ops.phase_delta(1.0, 0.2345), max_block=0) if vfo else ops.Resampler(taps, 1, M, max_block=0)
+        ref = mk()
         ref.set_mode(ref.FFT)
         alt = np.concatenate([ref.process(dev(b)).cpu().numpy() for b in blocks])
         assert ref.last_kernel()["name"] == "fir_fft_kernel"
         assert rel_rms(got, alt) < 3e-6, (M, ntaps, vfo)
+
+
+@pytest.mark.parametrize("M,ntaps", [(9, 143), (13, 208), (14, 14), (16, 96), (16, 256), (17, 100), (24, 384), (31, 249), (33, 265), (50, 160),
+                                      (56, 449), (57, 449), (64, 1024), (65, 521), (72, 575), (73, 580), (96, 1500), (127, 2032), (128, 2048)])
+def test_mfma_decimator_shapes(ops, M, ntaps):
+    """decim_mfma_kernel over its whole shape range: every K / 8 instantiation boundary (decimation 8 j and 8 j + 1), 1 to
+    16 taps per column (16 = all rows of the A operand), tiles whose last 64-sample load is partly or wholly past the
+    tile (decimation 50: 800 samples = 12.5 loads), ragged blocks -- shorter than a tile of 16 rows, shorter than the
+    decimation (no output), ending inside a tile -- so that every call starts and ends in the guarded tile path, and a
+    retune between calls.  Decimator and fused VFO against the FP64 oracle."""
+    taps = O.lowpass_taps_f64(ntaps, 0.4 / M).astype(np.float32)
+    sizes = [M * 3000 + 17, 5, M * 700, M - 1, 3 * M + 1, M * 40, 16 * M, 16 * M + 1, M * 515]
+    x = O.synth_iq(0, sum(sizes), seed=M)
+    cuts = np.cumsum([0] + sizes)
+    blocks = [x[a:b] for a, b in zip(cuts, cuts[1:])]
+    r = ops.Resampler(taps, 1, M, max_block=0)
+    got = np.concatenate([r.process(dev(b)).cpu().numpy() for b in blocks])
+    assert r.last_kernel()["name"] == "decim_mfma_kernel", r.last_kernel()
+    rs = O.Resampler(taps, 1, M, acc=O.ACC_F64)
+    want = np.concatenate([rs.process(b) for b in blocks])
+    assert got.shape == want.shape and rel_rms(got, want) < 1e-6, (M, ntaps)
+    assert np.array_equal(r.get_history(), x[len(x) - ntaps:])
+    v = ops.Vfo(taps, 1, M, ops.phase_delta(1.0, 0.2345), max_block=0)
+    xl, rs = O.Xlator(1.0, 0.2345, exact=True, volk_gain=True), O.Resampler(taps, 1, M, acc=O.ACC_F64)
+    gv, wv = [], []
+    for i, b in enumerate(blocks):
+        if i == 4:
+            v.set_phase_inc(*ops.phase_delta(1.0, -0.111))
+            O.lib().oracle_xlator_phase_delta(1.0, -0.111, O._fp(xl.delta))
+        gv.append(v.process(dev(b)).cpu().numpy())
+        wv.append(rs.process(xl.process(b)))
+    assert v.last_kernel()["name"] == "decim_mfma_kernel"
+    gv, wv = np.concatenate(gv), np.concatenate(wv)
+    assert gv.shape == wv.shape and rel_rms(gv, wv) < 1e-6, (M, ntaps)
 
 
 @pytest.mark.parametrize("seed", range(24))
@@ -1233,7 +1272,7 @@ def test_calls_beyond_2_31_samples(ops, gold):
         ("fir256", 1, 256, lambda: ops.Fir(gold["taps256"], max_block=0), "fir_fft_kernel"),
         # (the big call takes the polyphase one-wave-per-segment kernel, the 66 000-sample reference slices the 4096-point one)
         ("vfo8", 8, 256, lambda: ops.Vfo(gold["taps256"], 1, 8, inc, max_block=0), "pfb_dec8_kernel"),
-        ("vfo50", 50, 401, lambda: ops.Vfo(t401, 1, 50, inc, max_block=0), "resamp_any_kernel"),
+        ("vfo50", 50, 401, lambda: ops.Vfo(t401, 1, 50, inc, max_block=0), "decim_mfma_kernel"),
     ]
     for name, M, ntaps, mk, kernel in plans:
         op = mk()

@@ -84,7 +84,7 @@ def test_ranks_on_one_gpu_match_unsharded_oracle(tmp_path, case, world):
 
 
 def test_large_decimation_vfo_on_two_ranks(tmp_path):
-    """The VFO's everyday shape (401 taps, decimate by 50: resamp_any_kernel) sharded over two ranks; chunks are
+    """The VFO's everyday shape (401 taps, decimate by 50: decim_mfma_kernel) sharded over two ranks; chunks are
     multiples of lcm(50, 512) = 12800 samples (per-call phase restart and the VOLK gain cadence both line up)."""
     from qdsp_amd.sharding import chunk_alignment
 
@@ -98,7 +98,7 @@ def test_large_decimation_vfo_on_two_ranks(tmp_path):
     per = len(want) // (steps * world)
     for c in range(1, steps * world):
         assert rel_rms(y[c * per:c * per + 8], want[c * per:c * per + 8]) < 1e-5, c
-    assert open(os.path.join(tmp_path, f"{case}_kernel_0.txt")).read() == "resamp_any_kernel"
+    assert open(os.path.join(tmp_path, f"{case}_kernel_0.txt")).read() == "decim_mfma_kernel"
     with pytest.raises(AssertionError):
         _run_ranks(case, "gloo", world, tmp_path, steps, 1 << 17)     # 2^17 % 12800 != 0: RingStream refuses, the ranks exit non-zero
 
