@@ -12,6 +12,21 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 template <int CTRL, int ROWMASK = 0xf> __device__ __forceinline__ float dpp(float old, float src) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL, ROWMASK, 0xf, true));
 }
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+// complex product on the packed FP32 pipe: two instructions (the operand swizzle and the sign ride on op_sel / neg_lo;
+// written out in C the compiler spends six on it).  _s: the second factor is wave-uniform (SGPR pair).
+__device__ __forceinline__ f32x2 cmul_pk(f32x2 x, f32x2 p) {
+    f32x2 t, o;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(x), "v"(p));                                    // (xr pr, xr pi)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(o) : "v"(x), "v"(p), "v"(t));   // (-xi pi, xi pr) + t
+    return o;
+}
+__device__ __forceinline__ f32x2 cmul_pk_s(f32x2 x, f32x2 p) {
+    f32x2 t, o;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(x), "s"(p));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(o) : "v"(x), "s"(p), "v"(t));
+    return o;
+}
 constexpr int kShl = 0x100, kShr = 0x110;      // row_shl:n -- lane i reads lane i + n;  row_shr:n -- lane i reads lane i - n
 
 // Diagonal sums of a 16 x 16 result tile.  d[v] = Z[4g + v][rho] on lane 16 g + rho.  cur[rho] collects the terms
@@ -42,8 +57,8 @@ __device__ __forceinline__ void diag_sum(const f32x4 d, float& cur, float& prev)
 }
 }  // namespace
 
-template <int KJ, bool ROT, int DEPTH>
-__global__ __launch_bounds__(256, KJ * DEPTH <= 8 ? 4 : (KJ * DEPTH <= 12 ? 3 : 2)) void decim_mfma_kernel(const MfArgs a) {
+// rot_k: the NCO table exp(j 64 i dphase) -- the kernel arguments' (one channel) or the channel's row of the device table
+template <int KJ, bool ROT, int DEPTH> __device__ __forceinline__ void decim_mfma_body(const MfArgs& a, const float2* __restrict__ rot_k) {
     constexpr int K = 8 * KJ, PITCH = K + 2, NI = 2 * KJ;
     const int t = threadIdx.x, l = t & 63;
     const int P = a.P, M = a.M;
@@ -72,7 +87,10 @@ __global__ __launch_bounds__(256, KJ * DEPTH <= 8 ? 4 : (KJ * DEPTH <= 12 ? 3 : 
     const int E = 16 * M;                                     // samples per tile
 
     // columns M..K-1 of the rows are never written: they meet zero taps, but must hold finite values
-    for (int i = l; i < 16 * PITCH; i += 64) tile[i] = make_float2(0.0f, 0.0f);
+    for (int i = l; i < 16 * (K - M); i += 64) {
+        const int row = i / (K - M);
+        tile[row * PITCH + M + (i - row * (K - M))] = make_float2(0.0f, 0.0f);
+    }
 
     float ta[KJ][2];
 #pragma unroll
@@ -86,7 +104,7 @@ __global__ __launch_bounds__(256, KJ * DEPTH <= 8 ? 4 : (KJ * DEPTH <= 12 ? 3 : 
 #pragma unroll
     for (int i = 0; i < NI; i++) {
         const int idx = 64 * i + l;
-        const int row = idx / M;
+        const int row = (int)__umulhi((unsigned)idx, a.minv);          // idx / M (exact: idx < 2^11, M <= 128)
         woff[i] = idx < E ? row * PITCH + (idx - row * M) : 16 * PITCH + l;
     }
     const int e1 = min(64 * (NI - 2) + l, E - 1), e2 = min(64 * (NI - 1) + l, E - 1);
@@ -120,17 +138,20 @@ __global__ __launch_bounds__(256, KJ * DEPTH <= 8 ? 4 : (KJ * DEPTH <= 12 ? 3 : 
     float carry_re = 0.0f, carry_im = 0.0f;
     auto do_tile = [&](int tt, float2 (&xn)[NI], bool& plain) {
         const long long g0 = gbase + (long long)E * tt;
-        float2 pf;
-        int m0;
+        // NCO: lane phasor of the tile (FP64 recurrence, rounded once) x the FP32 table exp(j 64 i dphase) inside it,
+        // x VOLK's magnitude sawtooth 1 + (g mod 512) gm1 (rotate(), kernels.hip.h): g advances by 64 per load, so the
+        // sawtooth takes 8 values per lane and tile, folded into 8 copies of the lane phasor
+        f32x2 pg[8];
         if (ROT) {
-            pf = make_float2((float)pd.x, (float)pd.y);
-            m0 = (int)((g0 + l) & 511);
+            const f32x2 pf = {(float)pd.x, (float)pd.y};
+            const int m0 = (int)((g0 + l) & 511);
+#pragma unroll
+            for (int k = 0; k < 8; k++) pg[k] = pf * fmaf((float)((m0 + 64 * k) & 511), a.gm1, 1.0f);
         }
-        auto spin = [&](float2 v, int i) {                     // NCO: lane phasor of the tile x table inside it
-            const float2 w = a.rot_k[i];
-            const float gain = fmaf((float)((m0 + 64 * i) & 511), a.gm1, 1.0f);   // VOLK's magnitude sawtooth (rotate(), kernels.hip.h)
-            const float pr = fmaf(pf.x, w.x, -pf.y * w.y) * gain, pi = fmaf(pf.x, w.y, pf.y * w.x) * gain;
-            return rot_apply(v, pr, pi);
+        auto spin = [&](float2 v, int i) {
+            const f32x2 w = {rot_k[i].x, rot_k[i].y};
+            const f32x2 o = cmul_pk(f32x2{v.x, v.y}, cmul_pk_s(pg[i & 7], w));
+            return make_float2(o.x, o.y);
         };
         if (plain) {
 #pragma unroll
@@ -147,9 +168,9 @@ __global__ __launch_bounds__(256, KJ * DEPTH <= 8 ? 4 : (KJ * DEPTH <= 12 ? 3 : 
                     if (g < 0) { if (g + P >= 0) v = a.hist[g + P]; }               // (history is already rotated)
                     else if (g < a.count) {
                         v = a.in[g];
-                        if (ROT) v = spin(v, i);
+                        if (ROT) v = rotate_f(v, make_float2((float)pd.x, (float)pd.y), rot_k[i], g, a.gm1);
                     }
-                    const int row = idx / M;
+                    const int row = (int)__umulhi((unsigned)idx, a.minv);
                     tile[row * PITCH + (idx - row * M)] = v;
                 }
             }
@@ -185,6 +206,41 @@ __global__ __launch_bounds__(256, KJ * DEPTH <= 8 ? 4 : (KJ * DEPTH <= 12 ? 3 : 
         for (int d = 0; d < DEPTH; d++)
             if (tt + d < ntiles) do_tile(tt + d, xb[d], plainb[d]);
     }
+}
+
+template <int KJ, bool ROT, int DEPTH>
+__global__ __launch_bounds__(256, KJ * DEPTH <= 8 ? 4 : (KJ * DEPTH <= 12 ? 3 : 2)) void decim_mfma_kernel(const MfArgs a) {
+    decim_mfma_body<KJ, ROT, DEPTH>(a, a.rot_k);
+}
+
+template <int KJ, int DEPTH>
+__global__ __launch_bounds__(256, KJ * DEPTH <= 8 ? 4 : (KJ * DEPTH <= 12 ? 3 : 2)) void decim_mfma_batch_kernel(const MfBatchArgs b) {
+    const int ch = blockIdx.y;
+    MfArgs a = b.a;
+    const MfChanConst& c = b.tab[ch];
+    a.hist = c.hist[b.cur];
+    a.hist_next = const_cast<float2*>(c.hist[b.cur ^ 1]);
+    a.out = b.use_ptrs ? static_cast<float2*>(b.outs[ch]) : b.a.out + (long long)ch * b.out_stride;
+    a.phase0 = b.phase0[ch];
+    a.dphase = c.dphase;
+    a.rot_step = c.rot_step;
+    a.gm1 = c.gm1;
+    decim_mfma_body<KJ, true, DEPTH>(a, c.rot_k);
+}
+
+int launch_mf_dec_batch(const MfBatchArgs& b, int nchan, int KJ, int depth, hipStream_t stream) {
+    const dim3 grid((b.a.ntasks + 3) / 4 + 1, nchan), block(256);
+#define QK_MFB(k)                                                                                          \
+    if (KJ == k) {                                                                                         \
+        if (depth == 2) hipLaunchKernelGGL((decim_mfma_batch_kernel<k, 2>), grid, block, 0, stream, b);    \
+        else hipLaunchKernelGGL((decim_mfma_batch_kernel<k, 1>), grid, block, 0, stream, b);               \
+        const hipError_t e = hipGetLastError();                                                            \
+        return e == hipSuccess ? 0 : -(int)e;                                                              \
+    }
+    QK_MFB(2) QK_MFB(3) QK_MFB(4) QK_MFB(5) QK_MFB(6) QK_MFB(7) QK_MFB(8)
+    QK_MFB(9) QK_MFB(10) QK_MFB(11) QK_MFB(12) QK_MFB(13) QK_MFB(14) QK_MFB(15) QK_MFB(16)
+#undef QK_MFB
+    return -1;
 }
 
 int launch_mf_dec(const MfArgs& a, int KJ, bool rot, int depth, hipStream_t stream) {

@@ -38,6 +38,7 @@ struct MfArgs {
     const float* tapk;            // [2 KJ][64] A operands: tapk[2 jj + a][l] = h[M (l % 16) + 8 jj + 2 (l / 16) + a], 0 outside
     long long count, nout;
     int P, M;
+    unsigned minv;                // ceil(2^32 / M): idx / M == umulhi(idx, minv) for the tile-relative indices (< 2^11)
     int T;                        // outputs per wave task (multiple of 16)
     int ntasks;                   // wave tasks (grid = ceil(ntasks / 4) + 1: the last workgroup hands over the history)
     unsigned long long phase0, dphase;
@@ -46,7 +47,30 @@ struct MfArgs {
     float gm1;
 };
 
+// N channels of one filter design in one launch (blockIdx.y = channel): the non-uniform channelizer and the
+// Splitter -> N x VFO bank (routing.h:47-57 + vfo.h:19-36).  Per-channel constants sit in a device table, what changes
+// every call (NCO phase at the first sample, output pointer) rides in the kernel arguments -- as resamp_any_batch_kernel.
+constexpr int kMfBatchMax = 128;
+struct MfChanConst {
+    const float2* hist[2];        // the channel's two history buffers; `cur` selects the one to read
+    unsigned long long dphase;
+    double2 rot_step;
+    float2 rot_k[2 * kMfMaxKJ];
+    float gm1;
+    int pad_;
+};
+struct MfBatchArgs {
+    MfArgs a;                     // shared part (in, taps, geometry); per-channel fields are patched in
+    const MfChanConst* tab;       // [nchan]
+    long long out_stride;         // complex samples between the channels' output rows
+    int cur;                      // history parity of this call (all channels flip together)
+    int use_ptrs;                 // 1: channel c writes to outs[c]
+    unsigned long long phase0[kMfBatchMax];
+    void* outs[kMfBatchMax];
+};
+
 // KJ = ceil(M / 8) in 2..16; returns -1 for other shapes
+int launch_mf_dec_batch(const MfBatchArgs& b, int nchan, int KJ, int depth, hipStream_t stream);
 int launch_mf_dec(const MfArgs& a, int KJ, bool rot, int depth, hipStream_t stream);
 
 }  // namespace qk

@@ -1189,6 +1189,28 @@ int launch_xlate_inc(Engine* e, const void* d_in, int64_t count, void* d_out, un
     return 0;
 }
 
+// outputs per wave task: a task reads one tile of 16 rows beyond its own (T = 256: 6 %); small calls take shorter
+// tasks so that a reference-sized block still spreads over the chip (1e6 samples at decimation 50: 20 000 outputs)
+void mf_tasks(qk::MfArgs& a, int64_t nout, int nchan, bool rot) {
+    long long T = nout * nchan / env_int("QDSP_HIP_MF_TASKS", 8192);
+    T = (T + 15) / 16 * 16;
+    const long long tmax = env_int("QDSP_HIP_MF_TASK_MAX", rot ? 256 : 128);
+    if (T > tmax) T = tmax;
+    if (T < 16) T = 16;
+    a.T = (int)T;
+    a.ntasks = (int)((nout + T - 1) / T);
+    a.minv = (unsigned)(((1ull << 32) + a.M - 1) / a.M);
+}
+// NCO tables: one tile (16 M samples) further in FP64, load i of a tile (64 i samples) in FP32
+void mf_rot_tables(unsigned long long dphase, int M, int KJ, double2* step, float2* rot_k) {
+    unit_of_fx(dphase, 16.0L * (long double)M, &step->x, &step->y);
+    for (int k = 0; k < 2 * KJ; k++) {
+        double c, sn;
+        unit_of_fx(dphase, 64.0L * (long double)k, &c, &sn);
+        rot_k[k] = make_float2((float)c, (float)sn);
+    }
+}
+
 int launch_mf(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d_out, hipStream_t s) {
     qk::MfArgs a;
     memset(&a, 0, sizeof(a));
@@ -1201,32 +1223,19 @@ int launch_mf(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d_
     a.nout = nout;
     a.P = e->P;
     a.M = e->M;
-    // outputs per wave task: a task reads one tile of 16 rows beyond its own (T = 256: 6 %); small calls take shorter
-    // tasks so that a reference-sized block still spreads over the chip (1e6 samples at decimation 50: 20 000 outputs)
-    long long T = nout / env_int("QDSP_HIP_MF_TASKS", 8192);
-    T = (T + 15) / 16 * 16;
-    const long long tmax = env_int("QDSP_HIP_MF_TASK_MAX", e->rotate ? 256 : 128);
-    if (T > tmax) T = tmax;
-    if (T < 16) T = 16;
-    a.T = (int)T;
-    a.ntasks = (int)((nout + T - 1) / T);
+    mf_tasks(a, nout, 1, e->rotate);
     if (e->rotate) {
         a.phase0 = e->phase;
         a.dphase = e->dphase;
         a.gm1 = e->volk_gain ? e->gm1 : 0.0f;
-        unit_of_fx(e->dphase, 16.0L * (long double)e->M, &a.rot_step.x, &a.rot_step.y);
-        for (int k = 0; k < 2 * e->mf_KJ; k++) {
-            double c, sn;
-            unit_of_fx(e->dphase, 64.0L * (long double)k, &c, &sn);
-            a.rot_k[k] = make_float2((float)c, (float)sn);
-        }
+        mf_rot_tables(e->dphase, e->M, e->mf_KJ, &a.rot_step, a.rot_k);
     }
     const int rc = qk::launch_mf_dec(a, e->mf_KJ, e->rotate, env_int("QDSP_HIP_MF_DEPTH", e->mf_KJ <= 8 ? 2 : 1), s);
     if (rc) return rc < 0 && rc != -1 ? rc : QDSP_HIP_EINVAL;
     e->last.name = "decim_mfma_kernel";
     e->last.grid = (a.ntasks + 3) / 4 + 1;
     e->last.block = 256;
-    e->last.lds = 4 * 16 * (8 * e->mf_KJ + 2) * (int)sizeof(float2);
+    e->last.lds = 4 * (16 * (8 * e->mf_KJ + 2) + 64) * (int)sizeof(float2);
     return 0;
 }
 
@@ -1503,6 +1512,9 @@ struct Chan {
     float* d_phases = nullptr;
     qk::AnyChanConst* d_batch = nullptr;
     std::vector<qk::AnyChanConst> batch_key;
+    // the same for the MFMA decimator (decim_mfma_batch_kernel: large integer decimations)
+    qk::MfChanConst* d_batch_mf = nullptr;
+    std::vector<qk::MfChanConst> batch_mf_key;
     Launch last;
 };
 Chan* as_chan(void* h) {
@@ -1518,6 +1530,7 @@ void chan_destroy(Chan* c) {
     if (c->d_tw64) (void)hipFree(c->d_tw64);
     if (c->d_phases) (void)hipFree(c->d_phases);
     if (c->d_batch) (void)hipFree(c->d_batch);
+    if (c->d_batch_mf) (void)hipFree(c->d_batch_mf);
     for (int i = 0; i < 2; i++)
         if (c->d_hist[i]) (void)hipFree(c->d_hist[i]);
     if (c->d_in) (void)hipFree(c->d_in);
@@ -1622,10 +1635,84 @@ int chan_launch_uniform(Chan* c, const void* d_in, int64_t count, int64_t nout, 
     return 0;
 }
 
+// Non-uniform plans whose design the MFMA decimator serves (large integer decimations: the VFO bank's usual shape):
+// ALL channels in one launch of decim_mfma_batch_kernel.  Returns 1 if it does not apply.
+int chan_launch_batch_mf(Chan* c, const void* d_in, int64_t count, int64_t nout, void* d_out, int64_t out_stride, hipStream_t s,
+                         void* const* out_ptrs) {
+    Engine* e0 = c->vfo[0];
+    if (!e0->d_taps_mf || nout <= 0 || env_int("QDSP_HIP_NO_MF", 0) || env_int("QDSP_HIP_NO_MF_BATCH", 0)) return 1;
+    // per wave: taps, slot table and an FP64 sincos before the first tile -- small launches are quicker on the general
+    // direct kernel (profiles/r02_tune_chan_batch.txt: even at 4 channels x 1e6 samples, 16 x 1e6: 36 against 55 us)
+    if (count * c->nchan < (int64_t)env_int("QDSP_HIP_MF_BATCH_MIN_WORK", 1 << 22)) return 1;
+    for (Engine* e : c->vfo)
+        if (e->cur != e0->cur || !e->rotate || e->ch != 2 || !e->d_taps_mf || e->mf_KJ != e0->mf_KJ) return 1;
+    std::vector<qk::MfChanConst> key((size_t)c->nchan);
+    for (int i = 0; i < c->nchan; i++) {
+        Engine* e = c->vfo[i];
+        qk::MfChanConst& k = key[i];
+        memset(&k, 0, sizeof(k));
+        k.hist[0] = reinterpret_cast<const float2*>(e->d_hist[0]);
+        k.hist[1] = reinterpret_cast<const float2*>(e->d_hist[1]);
+        k.dphase = e->dphase;
+        k.gm1 = e->volk_gain ? e->gm1 : 0.0f;
+    }
+    bool dirty = !c->d_batch_mf || c->batch_mf_key.size() != key.size();
+    for (size_t i = 0; !dirty && i < key.size(); i++)
+        dirty = key[i].hist[0] != c->batch_mf_key[i].hist[0] || key[i].hist[1] != c->batch_mf_key[i].hist[1] ||
+                key[i].dphase != c->batch_mf_key[i].dphase || key[i].gm1 != c->batch_mf_key[i].gm1;
+    if (dirty) {
+        for (size_t i = 0; i < key.size(); i++) mf_rot_tables(key[i].dphase, e0->M, e0->mf_KJ, &key[i].rot_step, key[i].rot_k);
+        HIPCHK(hipDeviceSynchronize());     // (rare -- a retune: nothing in flight may still read the old table)
+        if (c->d_batch_mf && c->batch_mf_key.size() != key.size()) { HIPCHK(hipFree(c->d_batch_mf)); c->d_batch_mf = nullptr; }
+        if (!c->d_batch_mf) HIPCHK(hipMalloc(&c->d_batch_mf, key.size() * sizeof(qk::MfChanConst)));
+        HIPCHK(hipMemcpy(c->d_batch_mf, key.data(), key.size() * sizeof(qk::MfChanConst), hipMemcpyHostToDevice));
+        c->batch_mf_key = key;
+    }
+    qk::MfBatchArgs b;
+    memset(&b, 0, sizeof(b));
+    qk::MfArgs& a = b.a;
+    a.in = static_cast<const float2*>(d_in);
+    a.tapk = e0->d_taps_mf;
+    a.count = count;
+    a.nout = nout;
+    a.P = e0->P;
+    a.M = e0->M;
+    mf_tasks(a, nout, c->nchan, true);
+    b.out_stride = out_stride;
+    b.cur = e0->cur;
+    const int depth = env_int("QDSP_HIP_MF_DEPTH", e0->mf_KJ <= 8 ? 2 : 1);
+    for (int base = 0; base < c->nchan; base += qk::kMfBatchMax) {
+        const int nb = (c->nchan - base < qk::kMfBatchMax) ? c->nchan - base : qk::kMfBatchMax;
+        b.tab = c->d_batch_mf + base;
+        a.out = out_ptrs ? nullptr : static_cast<float2*>(d_out) + (size_t)base * out_stride;
+        b.use_ptrs = out_ptrs ? 1 : 0;
+        for (int i = 0; i < nb; i++) {
+            b.phase0[i] = c->vfo[base + i]->phase;
+            b.outs[i] = out_ptrs ? out_ptrs[base + i] : nullptr;
+        }
+        const int rc = qk::launch_mf_dec_batch(b, nb, e0->mf_KJ, depth, s);
+        if (rc) return rc < 0 && rc != -1 ? rc : QDSP_HIP_EINVAL;
+    }
+    for (Engine* e : c->vfo) {
+        e->cur ^= 1;
+        e->phase += (unsigned long long)count * e->dphase;
+        e->raw_valid = false;
+    }
+    c->last.name = "decim_mfma_batch_kernel";
+    c->last.grid = ((a.ntasks + 3) / 4 + 1) * c->nchan;
+    c->last.block = 256;
+    c->last.lds = 4 * (16 * (8 * e0->mf_KJ + 2) + 64) * (int)sizeof(float2);
+    return 0;
+}
+
 // Non-uniform plans (arbitrary offsets, any channel count): ALL channels in one launch of resamp_any_batch_kernel
 // (blockIdx.y = channel).  Returns 1 if the batched form does not apply (the caller then loops over the channels).
 int chan_launch_batch(Chan* c, const void* d_in, int64_t count, int64_t nout, void* d_out, int64_t out_stride, hipStream_t s,
                       void* const* out_ptrs = nullptr) {
+    {
+        const int rc = chan_launch_batch_mf(c, d_in, count, nout, d_out, out_stride, s, out_ptrs);
+        if (rc <= 0) return rc;
+    }
     constexpr int NT = 256;
     Engine* e0 = c->vfo[0];
     for (Engine* e : c->vfo)
@@ -1731,6 +1818,7 @@ bool chan_batch_wins(const Chan* c, int64_t count) {
     if (c->nchan < 2 || env_int("QDSP_HIP_NO_CHAN_BATCH", 0)) return false;
     const Engine* e = c->vfo[0];
     if (count <= (int64_t)env_int("QDSP_HIP_CHAN_BATCH_MAX_COUNT", 1 << 22)) return true;
+    if (e->d_taps_mf && !env_int("QDSP_HIP_NO_MF", 0) && !env_int("QDSP_HIP_NO_MF_BATCH", 0)) return true;   // what each channel would run anyway
     const bool dedicated = (fft_eligible(e, count) || use_win(e) || use_core(e) || use_lm(e));
     return !dedicated;
 }

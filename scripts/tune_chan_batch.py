@@ -1,5 +1,6 @@
 """Non-uniform channel plans (Splitter -> N x VFO at arbitrary offsets) per reference-sized block: one batched launch
-(resamp_any_batch_kernel) against one fused kernel per channel."""
+(decim_mfma_batch_kernel where the design allows, resamp_any_batch_kernel otherwise and with QDSP_HIP_NO_MF_BATCH)
+against one fused kernel per channel."""
 import os
 import sys
 
@@ -17,13 +18,14 @@ for (M, ntaps, nch) in ((50, 401, 4), (50, 401, 16), (50, 401, 64), (10, 97, 16)
         x = ops.synth_iq(n, seed=1, device=0)
         out = torch.empty((nch, n // M), dtype=torch.complex64, device="cuda")
         row = [f"M {M:3d} taps {ntaps:4d} ch {nch:3d} n {n:8d}"]
-        for batch in (1, 0):
+        for batch in (2, 1, 0):
             os.environ["QDSP_HIP_NO_CHAN_BATCH"] = "0" if batch else "1"
+            os.environ["QDSP_HIP_NO_MF_BATCH"] = "0" if batch == 2 else "1"
             ch = ops.Channelizer(taps, 1, M, incs, max_block=0)
             for _ in range(10):
                 ch.process(x, out)
             torch.cuda.synchronize()
             us = min(ch.time_dev(x, out, 30) for _ in range(3)) * 1e3
-            row.append(f"{ch.last_kernel()['name'][:18]:18s} {us:8.1f} us")
+            row.append(f"{ch.last_kernel()['name'][:23]:23s} {us:8.1f} us")
             ch.close()
         print("  ".join(row), flush=True)

@@ -672,10 +672,13 @@ def test_channelizer_guard_bands_and_odd_strides(ops, gold, dec):
         assert np.array_equal(host[:, :no], want), (dec, n, stride, off)
 
 
-def test_channelizer_non_uniform_plan_one_batched_launch(ops, gold):
-    """Arbitrary offsets (Splitter -> N x VFO, routing.h:47-57 + vfo.h:19-36): ALL channels in ONE launch of
-    resamp_any_batch_kernel (blockIdx.y = channel; per-channel NCO / history from a device table), each channel
+@pytest.mark.parametrize("kernel", ["decim_mfma_batch_kernel", "resamp_any_batch_kernel"])
+def test_channelizer_non_uniform_plan_one_batched_launch(ops, gold, kernel, monkeypatch):
+    """Arbitrary offsets (Splitter -> N x VFO, routing.h:47-57 + vfo.h:19-36): ALL channels in ONE launch
+    (blockIdx.y = channel; per-channel NCO / history from a device table) of the MFMA decimator, or of the general
+    direct kernel (what designs outside the former's range get; forced here with QDSP_HIP_NO_MF_BATCH), each channel
     against the FP64 oracle of its own xlator -> resampler chain."""
+    monkeypatch.setenv("QDSP_HIP_NO_MF_BATCH" if kernel == "resamp_any_batch_kernel" else "QDSP_HIP_MF_BATCH_MIN_WORK", "1" if kernel == "resamp_any_batch_kernel" else "0")
     taps = gold["taps256"]
     n = 65_536
     x = O.synth_iq(0, n, seed=9)
@@ -684,7 +687,7 @@ def test_channelizer_non_uniform_plan_one_batched_launch(ops, gold):
     ch = ops.Channelizer(taps, 1, 64, incs, max_block=n)
     y = np.array(ch.process(x))
     k = ch.last_kernel()
-    assert k["name"] == "resamp_any_batch_kernel" and y.shape == (4, n // 64)
+    assert k["name"] == kernel and y.shape == (4, n // 64)
     assert k["grid"] % 4 == 0                       # grid = (tiles + hand-over) x 4 channels: one launch
     for c, f in enumerate(freqs):
         want = O.Resampler(taps, 1, 64, acc=O.ACC_F64).process(O.Xlator(1.0, f, exact=True, volk_gain=True).process(x))
@@ -693,24 +696,33 @@ def test_channelizer_non_uniform_plan_one_batched_launch(ops, gold):
     ch2 = ops.Channelizer(taps, 1, 64, incs, max_block=n)
     ch2.set_mode(ch2.DIRECT)
     y2 = np.array(ch2.process(x))
-    assert ch2.last_kernel()["name"] != "resamp_any_batch_kernel"
+    assert "batch" not in ch2.last_kernel()["name"]
     for c in range(4):
         assert rel_rms(y[c], y2[c]) < 2e-6
 
 
-@pytest.mark.parametrize("plan", ["vfo50x16", "dec8x5", "r3_2x3", "dec10x130"])
-def test_channelizer_batched_stream_of_blocks(ops, plan):
-    """The batched per-channel kernel over a STREAM of reference-sized and ragged blocks (history and every channel's NCO
+@pytest.mark.parametrize("plan", ["vfo50x16", "vfo50x16_any", "dec8x5", "r3_2x3", "dec10x130", "dec20x130"])
+def test_channelizer_batched_stream_of_blocks(ops, plan, monkeypatch):
+    """The batched per-channel kernels over a STREAM of reference-sized and ragged blocks (history and every channel's NCO
     phase carried from call to call, a zero-length block in between, a retune of one channel mid-stream that
-    rewrites the device table), for the VFO's everyday shape (401 taps, decimate by 50, 16 channels), a short
-    decimate-by-8, a rational 3/2 plan and 130 channels (two launches of <= 128 channels)."""
+    rewrites the device table), for the VFO's everyday shape (401 taps, decimate by 50, 16 channels: MFMA form, and the
+    general direct form with QDSP_HIP_NO_MF_BATCH), a short decimate-by-8, a rational 3/2 plan and 130 channels (two
+    launches of <= 128 channels) in both forms."""
     import torch
 
-    L, M, ntaps, nch = {"vfo50x16": (1, 50, 401, 16), "dec8x5": (1, 8, 63, 5), "r3_2x3": (3, 2, 95, 3), "dec10x130": (1, 10, 97, 130)}[plan]
+    if plan.endswith("_any"):
+        monkeypatch.setenv("QDSP_HIP_NO_MF_BATCH", "1")
+    if plan == "dec20x130":
+        monkeypatch.setenv("QDSP_HIP_MF_BATCH_MIN_WORK", "0")
+    # (vfo50x16 runs under the default policy: the MFMA form from 2^22 channel-samples per call, the general direct
+    # form below -- the stream switches forms from block to block, on one history and one NCO state)
+    mf_plan = plan in ("vfo50x16", "dec20x130")
+    L, M, ntaps, nch = {"vfo50x16": (1, 50, 401, 16), "vfo50x16_any": (1, 50, 401, 16), "dec8x5": (1, 8, 63, 5), "r3_2x3": (3, 2, 95, 3),
+                        "dec10x130": (1, 10, 97, 130), "dec20x130": (1, 20, 161, 130)}[plan]
     taps = (O.lowpass_taps_f64(ntaps, 0.4 / max(L, M)) * L).astype(np.float32)
     freqs = [(-0.45 + 0.9 * (i + 0.37) / nch) for i in range(nch)]
     incs = [ops.phase_delta(1.0, f) for f in freqs]
-    sizes = [50 * 2000, 50 * 7, 0, 50 * 400 + 50, 50 * 1311] if M == 50 else [20_000, 80, 0, 4000 + 2 * M, 30_000]
+    sizes = [50 * 2000, 50 * 6000, 50 * 7, 0, 50 * 400 + 50, 50 * 5300 + 7, 50 * 1311] if M == 50 else [20_000, 80, 0, 4000 + 2 * M, 30_000]
     x = O.synth_iq(0, sum(sizes), seed=444)
     ch = ops.Channelizer(taps, L, M, incs, max_block=0)
     ys, pos = [], 0
@@ -724,7 +736,8 @@ def test_channelizer_batched_stream_of_blocks(ops, plan):
         pos += m
         ys.append(ch.process(blk).cpu().numpy())
         if m:
-            assert ch.last_kernel()["name"] == "resamp_any_batch_kernel", plan
+            mf = mf_plan and (plan == "dec20x130" or nch * m >= 1 << 22)
+            assert ch.last_kernel()["name"] == ("decim_mfma_batch_kernel" if mf else "resamp_any_batch_kernel"), (plan, m)
     torch.cuda.synchronize()
     y = np.concatenate(ys, axis=1)
     check = range(nch) if nch <= 16 else (0, 1, 2, 64, 127, 128, 129)
