@@ -7,6 +7,7 @@
 #include "chan.hip.h"
 #include "pfb_dec.hip.h"
 #include "mf_dec.hip.h"
+#include "rm_resamp.hip.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -89,6 +90,8 @@ struct Engine {
     float2* d_fft_TB = nullptr;
     int fft_ntaps = -1;         // tap count d_fft_H was built for (-1: not built)
     unsigned long long fft_dphase = 0;   // NCO increment d_fft_H was built for (fused VFO), 0 otherwise
+    float* d_taps_rm = nullptr;    // rational MFMA resampler (rm_resamp.hip.h): A operands + first columns, built with the taps
+    int rm_ngrp = 0, rm_KB = 0, rm_ext = 0, rm_pitch = 0, rm_G = 0, rm_J = 1, rm_qpb = 1;
     float* d_taps_mf = nullptr;    // MFMA decimator (mf_dec.hip.h): [2 KJ][64] A operands, built with the taps
     int mf_KJ = 0;
     // polyphase overlap-save decimate-by-8 (pfb_dec.hip.h): column spectra + twiddles, built for (pfb_ntaps, pfb_dphase)
@@ -317,6 +320,74 @@ int upload_taps(Engine* e, const float* taps, int ntaps) {
             e->mf_KJ = KJ;
         }
     }
+    // rational MFMA resampler (rm_resamp.hip.h): the banded period matrix W[i][c] = phases[(i M) % L][c - (i M) / L], cut
+    // into blocks of 4 rows (16 blocks per MFMA step) with one band per block, in the lane order of the A operand.
+    // Periods too short to hold their band in one row are merged J at a time (L' = J L, M' = J M: the same operator).
+    if (e->d_taps_rm) { HIPCHK(hipFree(e->d_taps_rm)); e->d_taps_rm = nullptr; }
+    e->rm_ngrp = 0;
+    // Where it pays (profiles/r02_tune_rm.md): periods of at least 9 blocks (interp >= 33: 48 kHz <-> 44.1 kHz runs 1.25-1.5x
+    // faster than through the general direct kernel) and pure interpolators; shorter periods share a step between period
+    // quads and run within +-15 % of the general kernel, which keeps them (QDSP_HIP_RM_MIN_INTERP lowers the bar).
+    const bool rm_wanted = e->L >= env_int("QDSP_HIP_RM_MIN_INTERP", 33) || (e->M == 1 && e->L >= 6 && !use_lm(e));
+    if (e->ch == 2 && rm_wanted && e->has_filter && e->kind != KIND_FIR && !use_core(e) && e->M < (1 << 16)) {
+        const int L0 = e->L, M0 = e->M, P = e->P;
+        for (int J = 1; J <= 64 && !e->rm_ngrp; J++) {
+            const int L = J * L0, M = J * M0, nblk = (L + 3) / 4;
+            if (nblk > 16 * qk::kRmMaxGrp || 4 * M > 64 * qk::kRmNE) break;
+            const int qpb = nblk <= 8 ? 16 / nblk : 1, ngrp = (nblk + 15) / 16;
+            std::vector<int> c0((size_t)nblk);
+            int KB = 1, reach = 0;
+            for (int b = 0; b < nblk; b++) {
+                const int i0 = 4 * b, i1 = (i0 + 3 < L - 1) ? i0 + 3 : L - 1;
+                c0[b] = (int)(((long long)i0 * M0) / L0);
+                const int need = (int)(((long long)i1 * M0) / L0) + P - c0[b];
+                if (need > KB) KB = need;
+            }
+            if (KB > qk::kRmMaxKB) break;
+            for (int b = 0; b < nblk; b++)
+                if (c0[b] + KB > reach) reach = c0[b] + KB;
+            const int ext = reach > M ? reach - M : 0;
+            if (ext > M) continue;                     // a row must hold its band with one neighbour's head: merge more periods
+            // used fraction of the 16 blocks of a step: below ~0.6 the general direct kernel is the faster one
+            const double used = (double)(nblk * qpb) / (16.0 * ngrp);
+            if (used < 0.6) continue;                  // (more merged periods may fill the steps better)
+            int pitch = M + ext;
+            pitch += (pitch & 1) ^ 1;                  // odd: the four periods of a quad start on different banks
+            // period quads per tile: as many as the register prefetch (kRmNE samples per lane) holds, a multiple of qpb
+            int G = (64 * qk::kRmNE - ext) / (4 * M);
+            if (G > 16) G = 16;
+            G -= G % qpb;
+            if (G < 1 || qk::rm_lds_bytes(ngrp, KB, G, pitch) > 64 * 1024) continue;
+            std::vector<float> tab((size_t)ngrp * KB * 64 + (size_t)2 * ngrp * 64, 0.0f);
+            int* cbl = reinterpret_cast<int*>(tab.data() + (size_t)ngrp * KB * 64);
+            int* meta = cbl + (size_t)ngrp * 64;
+            for (int g = 0; g < ngrp; g++)
+                for (int l = 0; l < 64; l++) {
+                    const int slot = l / 4;            // block slot of the step
+                    const int b = ngrp > 1 || qpb == 1 ? 16 * g + slot : slot % nblk;
+                    const int pq = ngrp > 1 || qpb == 1 ? 0 : slot / nblk;
+                    const bool live = b < nblk && pq < qpb;
+                    cbl[g * 64 + l] = live ? c0[b] : 0;
+                    meta[g * 64 + l] = live ? ((pq << 16) | b) : 0xffff;
+                    const int i = 4 * b + l % 4;
+                    if (!live || i >= L) continue;
+                    const int off = (int)(((long long)i * M0) / L0), ph = (int)(((long long)i * M0) % L0);
+                    for (int k = 0; k < KB; k++) {
+                        const int col = c0[b] + k;
+                        if (col >= off && col < off + P) tab[((size_t)g * KB + k) * 64 + l] = host[(size_t)ph * P + (col - off)];
+                    }
+                }
+            HIPCHK(hipMalloc(&e->d_taps_rm, tab.size() * sizeof(float)));
+            HIPCHK(hipMemcpy(e->d_taps_rm, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+            e->rm_ngrp = ngrp;
+            e->rm_KB = KB;
+            e->rm_ext = ext;
+            e->rm_pitch = pitch;
+            e->rm_G = G;
+            e->rm_J = J;
+            e->rm_qpb = qpb;
+        }
+    }
     return 0;
 }
 
@@ -443,6 +514,7 @@ void destroy(Engine* e) {
     if (e->d_fft_TB) (void)hipFree(e->d_fft_TB);
     if (e->d_pfb) (void)hipFree(e->d_pfb);
     if (e->d_taps_mf) (void)hipFree(e->d_taps_mf);
+    if (e->d_taps_rm) (void)hipFree(e->d_taps_rm);
     for (int i = 0; i < 2; i++)
         if (e->d_hist[i]) (void)hipFree(e->d_hist[i]);
     if (e->d_in) (void)hipFree(e->d_in);
@@ -1211,6 +1283,53 @@ void mf_rot_tables(unsigned long long dphase, int M, int KJ, double2* step, floa
     }
 }
 
+int launch_rm(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d_out, hipStream_t s) {
+    qk::RmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = static_cast<const float2*>(d_in);
+    a.out = static_cast<float2*>(d_out);
+    a.hist = reinterpret_cast<const float2*>(e->d_hist[e->cur]);
+    a.hist_next = reinterpret_cast<float2*>(e->d_hist[e->cur ^ 1]);
+    a.atab = e->d_taps_rm;
+    a.count = count;
+    a.nout = nout;
+    a.L = e->rm_J * e->L;          // (J merged periods)
+    a.M = e->rm_J * e->M;
+    a.P = e->P;
+    a.minv = (unsigned)(((1ull << 32) + a.M - 1) / a.M);
+    a.qpb = e->rm_qpb;
+    a.ngrp = e->rm_ngrp;
+    a.KB = e->rm_KB;
+    a.ext = e->rm_ext;
+    a.pitch = e->rm_pitch;
+    a.G = e->rm_G;
+    a.total = 4 * a.G * a.M + a.ext;
+    const long long nper = (nout + a.L - 1) / a.L;
+    a.ntiles = (int)((nper + 4 * a.G - 1) / (4 * a.G));
+    int nwaves = 1024 * env_int("QDSP_HIP_RM_WAVES_PER_SIMD", 3);
+    if (nwaves > a.ntiles) nwaves = a.ntiles;
+    if (nwaves < 1) nwaves = 1;
+    a.nwaves = nwaves;
+    if (e->rotate) {
+        a.phase0 = e->phase;
+        a.dphase = e->dphase;
+        a.gm1 = e->volk_gain ? e->gm1 : 0.0f;
+        unit_of_fx(e->dphase, (long double)nwaves * 4.0L * (long double)a.G * (long double)a.M, &a.rot_step.x, &a.rot_step.y);
+        for (int k = 0; k < qk::kRmNE; k++) {
+            double c, sn;
+            unit_of_fx(e->dphase, 64.0L * (long double)k, &c, &sn);
+            a.rot_k[k] = make_float2((float)c, (float)sn);
+        }
+    }
+    const int rc = qk::launch_rm_resamp(a, e->rotate, s);
+    if (rc) return rc;
+    e->last.name = "resamp_mfma_kernel";
+    e->last.grid = (nwaves + 3) / 4 + 1;
+    e->last.block = 256;
+    e->last.lds = (int)qk::rm_lds_bytes(a.ngrp, a.KB, a.G, a.pitch);
+    return 0;
+}
+
 int launch_mf(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d_out, hipStream_t s) {
     qk::MfArgs a;
     memset(&a, 0, sizeof(a));
@@ -1282,6 +1401,10 @@ int64_t process_dev(Engine* e, const void* d_in, int64_t count, void* d_out, voi
         a.gm1 = e->volk_gain ? e->gm1 : 0.0f;
         if (e->ch == 2) rc = e->rotate ? launch_core<2, true>(e, a, s) : launch_core<2, false>(e, a, s);
         else rc = launch_core<1, false>(e, a, s);
+        if (rc == 0) e->cur ^= 1;
+    } else if (e->d_taps_rm && e->rm_ngrp && mode_of(e) == 0 && nout > 0 && !env_int("QDSP_HIP_NO_RM", 0)) {
+        // rational ratios with interp >= 6 (48 kHz <-> 44.1 kHz is 147 / 160) on the MFMA units (rm_resamp.hip.h)
+        rc = launch_rm(e, d_in, count, nout, d_out, s);
         if (rc == 0) e->cur ^= 1;
     } else if (use_lm(e) && e->d_taps_lm) {
         if (e->ch == 2) rc = e->rotate ? launch_lm<2, true>(e, d_in, count, nout, d_out, s) : launch_lm<2, false>(e, d_in, count, nout, d_out, s);

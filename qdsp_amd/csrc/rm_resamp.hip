@@ -1,0 +1,175 @@
+// rm_resamp.hip -- rational polyphase resampler on the MFMA units (design notes: rm_resamp.hip.h).
+#include "rm_resamp.hip.h"
+#include "kernels.hip.h"
+
+namespace qk {
+
+namespace {
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+}
+
+template <bool ROT> __global__ __launch_bounds__(256, 3) void resamp_mfma_kernel(const RmArgs a) {
+    constexpr int NE = kRmNE, GM = kRmMaxGrp, KM = kRmMaxKB;
+    const int t = threadIdx.x, l = t & 63;
+    const int P = a.P, M = a.M, L = a.L;
+    if ((int)blockIdx.x == (a.nwaves + 3) / 4) {
+        // history hand-over (resampling.h:129): last P samples of hist ++ in, rotated for the fused VFO
+        for (int i = t; i < P; i += 256) {
+            const long long g = a.count - P + i;
+            float2 v;
+            if (g < 0) v = a.hist[g + P];
+            else {
+                v = a.in[g];
+                if (ROT) v = rotate(v, phasor_fx(a.phase0 + (unsigned long long)g * a.dphase), g, a.gm1);
+            }
+            a.hist_next[i] = v;
+        }
+        return;
+    }
+    extern __shared__ __attribute__((aligned(16))) unsigned char rm_smem[];
+    const int rows = 4 * a.G;                                   // periods per tile
+    // A operands for the whole workgroup: atab[g][k][lane] = W[4 (16 g + lane / 4) + lane % 4][cb + k], cb = first band
+    // column of the lane's block (in registers they cost 72 VGPRs and the third wave per SIMD)
+    float* atab = reinterpret_cast<float*>(rm_smem);
+    const int na = a.ngrp * a.KB * 64;
+    for (int i = t; i < na; i += 256) atab[i] = a.atab[i];
+    __syncthreads();
+    float2* tile = reinterpret_cast<float2*>(atab + ((na + 3) & ~3)) + (size_t)(t >> 6) * (rows * a.pitch + 64);
+    const int wave = (int)blockIdx.x * 4 + (t >> 6);
+    if (wave >= a.nwaves) return;
+    int cb[GM], meta[GM];
+#pragma unroll
+    for (int g = 0; g < GM; g++) {
+        cb[g] = g < a.ngrp ? reinterpret_cast<const int*>(a.atab + na)[g * 64 + l] : 0;
+        meta[g] = g < a.ngrp ? reinterpret_cast<const int*>(a.atab + na)[(a.ngrp + g) * 64 + l] : 0xffff;
+    }
+    // sample e of a tile for this lane: tile-relative index u = 64 e + l, period row u / M, column u % M; a column below
+    // ext is also the tail of the previous row; what has no slot goes to the lane's spare one.  (Recomputed per tile:
+    // as register tables the slots cost 24 VGPRs and spills.)
+    const int spare = rows * a.pitch + l;
+    const long long tstep = (long long)rows * M;                // input samples per tile
+    float2 xn[NE];
+    auto tile_plain = [&](int T) {                              // wave-uniform: the whole tile is plain input
+        const long long g0 = tstep * T - P;                     // sample index (relative to in[0]) of the tile's element 0
+        return T < a.ntiles && g0 >= 0 && g0 + a.total <= a.count;
+    };
+    auto load_tile = [&](int T) {
+        const float2* __restrict__ p = a.in + (tstep * T - P);
+#pragma unroll
+        for (int e = 0; e < NE; e++)
+            if (64 * e < a.total) xn[e] = p[min(64 * e + l, a.total - 1)];         // (past the tile: its last sample again, not stored)
+    };
+    auto put = [&](int u, float2 v) {
+        const int b = (int)__umulhi((unsigned)u, a.minv), c = u - b * M;
+        tile[(u < a.total && b < rows) ? b * a.pitch + c : spare] = v;
+        tile[(u < a.total && b >= 1 && c < a.ext) ? (b - 1) * a.pitch + M + c : spare] = v;
+    };
+    int T = wave;
+    double2 pd;
+    if (ROT) pd = phasor_fx(a.phase0 + (unsigned long long)(tstep * T - P + l) * a.dphase);
+    bool plain = tile_plain(T);
+    if (plain) load_tile(T);
+    // B operand of this lane: period l % 4 of a quad, columns from the block's band start
+    const int brow = (l & 3) * a.pitch;
+    for (; T < a.ntiles; T += a.nwaves) {
+        const long long g0 = tstep * T - P;
+        // ---- stage: registers -> (NCO) -> LDS rows ------------------------------------------------------------------
+        {
+            float2 pf;
+            int m0;
+            if (ROT) {
+                pf = make_float2((float)pd.x, (float)pd.y);
+                pd = cmul(pd, a.rot_step);
+                m0 = (int)((g0 + l) & 511);
+            }
+            if (plain) {
+#pragma unroll
+                for (int e = 0; e < NE; e++) {
+                    if (64 * e < a.total) {                     // wave-uniform
+                        float2 v = xn[e];
+                        if (ROT) {
+                            const float2 wk = a.rot_k[e];
+                            const float gain = fmaf((float)((m0 + 64 * e) & 511), a.gm1, 1.0f);   // VOLK's magnitude sawtooth (rotate(), kernels.hip.h)
+                            const float pr = fmaf(pf.x, wk.x, -pf.y * wk.y) * gain, pi = fmaf(pf.x, wk.y, pf.y * wk.x) * gain;
+                            v = rot_apply(v, pr, pi);
+                        }
+                        put(64 * e + l, v);
+                    }
+                }
+            } else {
+                // a tile that touches the history or the end of the call (the first and the last of a call): rolled, guarded
+#pragma unroll 1
+                for (int e = 0; 64 * e < a.total; e++) {
+                    const int u = 64 * e + l;
+                    const long long g = g0 + u;
+                    float2 v = make_float2(0.0f, 0.0f);
+                    if (u < a.total) {
+                        if (g < 0) { if (g + P >= 0) v = a.hist[g + P]; }           // (history is already rotated)
+                        else if (g < a.count) {
+                            v = a.in[g];
+                            if (ROT) v = rotate_f(v, pf, a.rot_k[e], g, a.gm1);
+                        }
+                    }
+                    put(u, v);
+                }
+            }
+        }
+        plain = tile_plain(T + a.nwaves);
+        if (plain) load_tile(T + a.nwaves);
+        // ---- matrix product per quad of periods and group of 16 blocks ------------------------------------------------
+        const long long per0 = (long long)rows * T;             // first period of the tile
+        for (int qd = 0; qd < a.G; qd += a.qpb) {
+#pragma unroll
+            for (int g = 0; g < GM; g++) {
+                if (g < a.ngrp) {
+                    const int lq = qd + (meta[g] >> 16);        // the lane's period quad
+                    const float2* bp = tile + 4 * lq * a.pitch + brow + cb[g];
+                    const float* ap = atab + g * a.KB * 64 + l;
+                    f32x4 zr = {0.0f, 0.0f, 0.0f, 0.0f}, zi = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int k = 0; k < KM; k++) {
+                        if (k < a.KB) {
+                            const float2 bv = bp[k];
+                            zr = __builtin_amdgcn_mfma_f32_4x4x1f32(ap[k * 64], bv.x, zr, 0, 0, 0);
+                            zi = __builtin_amdgcn_mfma_f32_4x4x1f32(ap[k * 64], bv.y, zi, 0, 0, 0);
+                        }
+                        if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);      // reads run at most 8 steps ahead (16 VGPRs)
+                    }
+                    // lane = (block l / 4, period l % 4 of the quad): outputs o .. o + 3 of that period, 32 bytes
+                    const int o = 4 * (meta[g] & 0xffff);
+                    const long long n = (per0 + 4 * lq + (l & 3)) * L + o;
+                    if (o < L && n < a.nout) {
+                        float2* dst = a.out + n;
+                        if (o + 3 < L && n + 3 < a.nout) {
+                            dst[0] = make_float2(zr[0], zi[0]);
+                            dst[1] = make_float2(zr[1], zi[1]);
+                            dst[2] = make_float2(zr[2], zi[2]);
+                            dst[3] = make_float2(zr[3], zi[3]);
+                        } else {
+#pragma unroll
+                            for (int v = 0; v < 4; v++)
+                                if (o + v < L && n + v < a.nout) dst[v] = make_float2(zr[v], zi[v]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+int launch_rm_resamp(const RmArgs& a, bool rot, hipStream_t stream) {
+    static bool attr_done = false;
+    const size_t lds = rm_lds_bytes(a.ngrp, a.KB, a.G, a.pitch);
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resamp_mfma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resamp_mfma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        attr_done = true;
+    }
+    const dim3 grid((a.nwaves + 3) / 4 + 1), block(256);
+    if (rot) hipLaunchKernelGGL((resamp_mfma_kernel<true>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((resamp_mfma_kernel<false>), grid, block, lds, stream, a);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
+}  // namespace qk

@@ -1127,6 +1127,52 @@ def test_mfma_decimator_shapes(ops, M, ntaps):
     assert gv.shape == wv.shape and rel_rms(gv, wv) < 1e-6, (M, ntaps)
 
 
+@pytest.mark.parametrize("L,M,tpp,forced", [(147, 160, 16, False), (160, 147, 16, False), (48, 50, 20, False), (192, 175, 9, False), (40, 39, 28, False),
+                                            (6, 1, 10, False), (64, 63, 1, False),
+                                            # periods of <= 8 blocks share an MFMA step between period quads; periods shorter than their
+                                            # band are merged (L' = J L, M' = J M): the general kernel keeps these by default
+                                            (7, 5, 24, True), (25, 24, 8, True), (16, 15, 16, True), (17, 16, 3, True), (12, 1, 6, True)])
+def test_rational_mfma_resampler(ops, L, M, tpp, forced, monkeypatch):
+    """resamp_mfma_kernel (rational ratios as banded 4 x 4 block products on the MFMA units): 48 kHz <-> 44.1 kHz, ratios
+    near one, a pure interpolator, bands of 1 to 31 columns, periods that fill one to three groups of 16 blocks or share a
+    step between period quads, ragged blocks -- shorter than a period, no output at all, ending inside a tile -- so that
+    every call starts and ends in the guarded tile path; resampler and fused VFO (with a retune between calls)
+    against the FP64 oracle."""
+    if forced:
+        monkeypatch.setenv("QDSP_HIP_RM_MIN_INTERP", "6")
+    ntaps = L * tpp - 3 if tpp > 1 else L - 3
+    taps = (O.lowpass_taps_f64(ntaps, 0.4 / max(L, M)) * L).astype(np.float32)
+    sizes = [M * 700 + 17, 5, M * 300, max(M - 1, 1), 3 * M + 1, 16 * M, 16 * M + 1, M * 515 + 3]
+    if M == 1:
+        sizes = [s * 40 for s in sizes]
+    x = O.synth_iq(0, sum(sizes), seed=L + M)
+    cuts = np.cumsum([0] + sizes)
+    blocks = [x[a:b] for a, b in zip(cuts, cuts[1:])]
+    r = ops.Resampler(taps, L, M, max_block=0)
+    got = np.concatenate([r.process(dev(b)).cpu().numpy() for b in blocks])
+    assert r.last_kernel()["name"] == "resamp_mfma_kernel", r.last_kernel()
+    rs = O.Resampler(taps, L, M, acc=O.ACC_F64)
+    want = np.concatenate([rs.process(b) for b in blocks])
+    assert got.shape == want.shape and rel_rms(got, want) < 1e-6, (L, M)
+    v = ops.Vfo(taps, L, M, ops.phase_delta(1.0, 0.2345), max_block=0)
+    xl, rs = O.Xlator(1.0, 0.2345, exact=True, volk_gain=True), O.Resampler(taps, L, M, acc=O.ACC_F64)
+    gv, wv = [], []
+    for i, b in enumerate(blocks):
+        if i == 4:
+            v.set_phase_inc(*ops.phase_delta(1.0, -0.111))
+            O.lib().oracle_xlator_phase_delta(1.0, -0.111, O._fp(xl.delta))
+        gv.append(v.process(dev(b)).cpu().numpy())
+        wv.append(rs.process(xl.process(b)))
+    assert v.last_kernel()["name"] == "resamp_mfma_kernel"
+    gv, wv = np.concatenate(gv), np.concatenate(wv)
+    assert gv.shape == wv.shape and rel_rms(gv, wv) < 1e-6, (L, M)
+    # the general direct kernel on the same plan agrees
+    monkeypatch.setenv("QDSP_HIP_NO_RM", "1")
+    r2 = ops.Resampler(taps, L, M, max_block=0)
+    alt = np.concatenate([r2.process(dev(b)).cpu().numpy() for b in blocks])
+    assert r2.last_kernel()["name"] != "resamp_mfma_kernel" and rel_rms(got, alt) < 1e-6
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_random_plans_every_dispatch_path(ops, seed):
     """Seeded sweep over (interp, decim, tap count, data type, NCO, block sizes, kernel mode): whichever kernel the
