@@ -158,13 +158,7 @@ template <bool ROT> __global__ __launch_bounds__(256, 3) void resamp_mfma_kernel
 }
 
 int launch_rm_resamp(const RmArgs& a, bool rot, hipStream_t stream) {
-    static bool attr_done = false;
-    const size_t lds = rm_lds_bytes(a.ngrp, a.KB, a.G, a.pitch);
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resamp_mfma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resamp_mfma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        attr_done = true;
-    }
+    const size_t lds = rm_lds_bytes(a.ngrp, a.KB, a.G, a.pitch);      // <= 64 KB (checked where the plan is made)
     const dim3 grid((a.nwaves + 3) / 4 + 1), block(256);
     if (rot) hipLaunchKernelGGL((resamp_mfma_kernel<true>), grid, block, lds, stream, a);
     else hipLaunchKernelGGL((resamp_mfma_kernel<false>), grid, block, lds, stream, a);
