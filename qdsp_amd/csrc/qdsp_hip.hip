@@ -326,9 +326,13 @@ int upload_taps(Engine* e, const float* taps, int ntaps) {
     if (e->d_taps_rm) { HIPCHK(hipFree(e->d_taps_rm)); e->d_taps_rm = nullptr; }
     e->rm_ngrp = 0;
     // Where it pays (profiles/r02_tune_rm.md): periods of at least 9 blocks (interp >= 33: 48 kHz <-> 44.1 kHz runs 1.25-1.5x
-    // faster than through the general direct kernel) and pure interpolators; shorter periods share a step between period
-    // quads and run within +-15 % of the general kernel, which keeps them (QDSP_HIP_RM_MIN_INTERP lowers the bar).
-    const bool rm_wanted = e->L >= env_int("QDSP_HIP_RM_MIN_INTERP", 33) || (e->M == 1 && e->L >= 6 && !use_lm(e));
+    // faster than through the general direct kernel), pure interpolators, and the decimating side of the small ratios
+    // resamp_lm_kernel serves (decim >= 5, and 10/3: 1.2-2.2x at up to ~24 taps per phase).  Other short periods share a step
+    // between period quads and run within +-15 % of the general kernel, which keeps them (QDSP_HIP_RM_MIN_INTERP lowers
+    // the bar).
+    bool rm_wanted = e->L >= env_int("QDSP_HIP_RM_MIN_INTERP", 33) || (e->M == 1 && e->L >= 6 && !use_lm(e));
+    if (use_lm(e) && e->L >= 2 && !env_int("QDSP_HIP_NO_RM_SMALL", 0))
+        rm_wanted = rm_wanted || (e->M >= 5 && e->P <= (e->L == 10 ? 36 : 24)) || (e->L == 10 && e->M >= 3 && e->P <= 24);
     if (e->ch == 2 && rm_wanted && e->has_filter && e->kind != KIND_FIR && !use_core(e) && e->M < (1 << 16)) {
         const int L0 = e->L, M0 = e->M, P = e->P;
         for (int J = 1; J <= 64 && !e->rm_ngrp; J++) {

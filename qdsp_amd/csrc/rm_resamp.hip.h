@@ -32,7 +32,7 @@ namespace qk {
 
 constexpr int kRmNE = 12;         // samples per lane and tile held in registers: 4 G M + ext <= 768
 constexpr int kRmMaxGrp = 3;      // groups of 16 blocks = 64 outputs per period: L <= 192
-constexpr int kRmMaxKB = 32;      // band columns per block
+constexpr int kRmMaxKB = 40;      // band columns per block
 
 struct RmArgs {
     const float2* in;

@@ -9,7 +9,8 @@ from qdsp_amd import ops
 def dev(a): return torch.from_numpy(a).cuda()
 def rel_rms(a, b): return float(np.sqrt(np.mean(np.abs(a - b) ** 2) / max(np.mean(np.abs(b) ** 2), 1e-30)))
 
-PLANS = [(147, 160, 16), (160, 147, 16), (7, 5, 24), (24, 125, 12), (25, 24, 8), (6, 1, 10), (16, 15, 16), (17, 16, 3), (10, 3, 32), (441, 480, 8), (48, 50, 20), (8, 25, 40)]
+PLANS = [(10, 7, 8), (10, 7, 32), (10, 3, 16), (5, 6, 20), (5, 7, 20), (5, 8, 20), (4, 7, 20), (4, 5, 32), (3, 8, 20), (3, 5, 20), (2, 5, 20), (2, 7, 20), (5, 2, 20), (3, 4, 20), (3, 2, 32),
+         (147, 160, 16), (160, 147, 16), (7, 5, 24), (24, 125, 12), (25, 24, 8), (6, 1, 10), (16, 15, 16), (17, 16, 3), (10, 3, 32), (441, 480, 8), (48, 50, 20), (8, 25, 40)]
 
 def parity():
     bad = 0
@@ -50,6 +51,7 @@ def timing():
             row = []
             for norm in ("0", "1"):
                 os.environ["QDSP_HIP_NO_RM"] = norm
+                os.environ["QDSP_HIP_NO_LM"] = "0" if norm == "1" else "1"      # (column 1: resamp_mfma_kernel also where resamp_lm_kernel would be picked)
                 op = ops.Vfo(taps, L, M, ops.phase_delta(1.0, 0.2345), max_block=0) if vfo else ops.Resampler(taps, L, M, max_block=0)
                 nout = nin * L // M
                 out = torch.empty(nout + 8, dtype=torch.complex64, device="cuda")
@@ -65,7 +67,7 @@ def timing():
         del x
 
 if __name__ == "__main__":
-    os.environ.setdefault("QDSP_HIP_RM_MIN_INTERP", "6")     # (the default policy leaves interp < 33 to the general kernel)
+    os.environ.setdefault("QDSP_HIP_RM_MIN_INTERP", "2")     # (the default policy leaves interp < 33 to the general kernel)
     bad = 0
     if "--time-only" not in sys.argv: bad = parity()
     if not bad: timing()
