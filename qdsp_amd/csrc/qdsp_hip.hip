@@ -1268,7 +1268,7 @@ int launch_xlate_inc(Engine* e, const void* d_in, int64_t count, void* d_out, un
 // outputs per wave task: a task reads one tile of 16 rows beyond its own (T = 256: 6 %); small calls take shorter
 // tasks so that a reference-sized block still spreads over the chip (1e6 samples at decimation 50: 20 000 outputs)
 void mf_tasks(qk::MfArgs& a, int64_t nout, int nchan, bool rot) {
-    long long T = nout * nchan / env_int("QDSP_HIP_MF_TASKS", 8192);
+    long long T = nout * nchan / env_int("QDSP_HIP_MF_TASKS", 2048);      // (one round of the chip: 3072 wave slots; 8192 left a 4M-sample call at T = 16 -- half of every task's reads its neighbour's -- and 18 us instead of 14)
     T = (T + 15) / 16 * 16;
     const long long tmax = env_int("QDSP_HIP_MF_TASK_MAX", rot ? 256 : 128);
     if (T > tmax) T = tmax;
