@@ -8,6 +8,7 @@
 #include "pfb_dec.hip.h"
 #include "mf_dec.hip.h"
 #include "rm_resamp.hip.h"
+#include "fir_lat.hip.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -1287,6 +1288,38 @@ void mf_rot_tables(unsigned long long dphase, int M, int KJ, double2* step, floa
     }
 }
 
+// FIR<complex_t> on reference-sized calls: the direct form arranged for latency (fir_lat.hip.h), bit-identical to
+// fir_core_kernel.  Per call at 256 taps the overlap-save kernel takes 9.0-9.3 us at 16 384-262 144 samples and
+// fir_core_kernel 11.3+ (profiles/r02_tune_call_size.txt).
+bool fir_lat_eligible(const Engine* e, int64_t count) {
+    if (e->kind != KIND_FIR || e->ch != 2 || !e->has_filter || e->L != 1 || e->M != 1) return false;
+    if (e->ntaps > 1024 || env_int("QDSP_HIP_NO_FIR_LAT", 0)) return false;
+    // measured: 2.5 us + 1.7e-7 us per tap and sample (63 / 127 / 256 taps at 65 536 samples: 2.9 / 3.6 / 5.3 us); what it
+    // competes with is the overlap-save kernel (~9 us up to 262 144 samples) from 96 taps on, fir_core_kernel (5.7-6.1 us) below
+    const int64_t limit = env_int("QDSP_HIP_FIR_LAT_MAX_WORK", e->ntaps >= 96 ? 1 << 25 : 1 << 24);
+    return count > 0 && count * (int64_t)e->ntaps <= limit;
+}
+int launch_fir_lat(Engine* e, const void* d_in, int64_t count, void* d_out, hipStream_t s) {
+    qk::FirLatArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = static_cast<const float2*>(d_in);
+    a.out = static_cast<float2*>(d_out);
+    a.hist = reinterpret_cast<const float2*>(e->d_hist[e->cur]);
+    a.hist_next = reinterpret_cast<float2*>(e->d_hist[e->cur ^ 1]);
+    a.taps = e->d_taps;
+    a.count = count;
+    a.N = e->ntaps;
+    a.Np = (e->ntaps + 7) & ~7;
+    a.nwaves = (int)((count + 63) / 64);
+    const int rc = qk::launch_fir_lat(a, s);
+    if (rc) return rc;
+    e->last.name = "fir_lat_kernel";
+    e->last.grid = (a.nwaves + 3) / 4 + 1;
+    e->last.block = 256;
+    e->last.lds = (int)qk::fir_lat_lds_bytes(a.Np);
+    return 0;
+}
+
 int launch_rm(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d_out, hipStream_t s) {
     qk::RmArgs a;
     memset(&a, 0, sizeof(a));
@@ -1373,6 +1406,9 @@ int64_t process_dev(Engine* e, const void* d_in, int64_t count, void* d_out, voi
     bool took_fft = false;
     if (!e->has_filter) {
         rc = launch_xlate(e, d_in, count, d_out, s);
+    } else if (mode_of(e) == 0 && fir_lat_eligible(e, count)) {
+        rc = launch_fir_lat(e, d_in, count, d_out, s);
+        if (rc == 0) e->cur ^= 1;
     } else if (e->d_taps_mf && mode_of(e) == 0 && nout > 0 && !env_int("QDSP_HIP_NO_MF", 0)) {
         // large integer decimations (the VFO's usual job) as an FP32 matrix product on the MFMA units (mf_dec.hip.h)
         rc = launch_mf(e, d_in, count, nout, d_out, s);

@@ -208,9 +208,9 @@ def test_fft_fir_golden_and_auto_mode(ops, gold):
     assert f.last_kernel()["name"] == "fir_fft_kernel"
     want = O.Fir(taps).process(x)
     assert rel_rms(y.cpu().numpy(), want) < TOL_FFT
-    # small calls stay on the direct form (bit-exact) and share the same history
+    # small calls stay on the direct form (bit-exact; the latency arrangement of it) and share the same history
     y2 = f.process(dev(x[:1000]))
-    assert f.last_kernel()["name"] == "fir_core_kernel"
+    assert f.last_kernel()["name"] == "fir_lat_kernel"
     o = O.Fir(taps, acc=O.ACC_FMA)
     o.process(x)
     assert np.array_equal(y2.cpu().numpy(), o.process(x[:1000]))

@@ -68,7 +68,7 @@ def _collect(case, outdir, world, steps):
 @pytest.mark.parametrize("case", ["fir256", "xlate_fir_decim8", "decim8"])
 def test_ranks_on_one_gpu_match_unsharded_oracle(tmp_path, case, world):
     """configs[3] shape (256-tap FIR, chunk-sharded, 255-sample halo) and configs[2] sharded the same way."""
-    steps, n = 2, 1 << 17
+    steps, n = 2, 1 << 18           # (256 taps x 2^18 samples per chunk: past the small-call direct kernel)
     _run_ranks(case, "gloo", world, tmp_path, steps, n)
     y = np.concatenate(_collect(case, tmp_path, world, steps))
     x = O.synth_iq(0, steps * world * n, seed=4321)
