@@ -62,6 +62,8 @@ WORKLOADS = {
     "xlate_fir_decim8_t63": dict(ntaps=63, decim=8, rot=True, bytes=9.0, flops=37.5),
     # the reference VFO's usual shape (vfo.h: 2.4 Msps -> 48 kHz, ~8 taps per unit of decimation): 8 + 8/50 B
     "vfo50": dict(ntaps=401, decim=50, rot=True, bytes=8.16, flops=38.1, fc=0.4 / 50),
+    # 48 kHz -> 44.1 kHz, 16 taps per phase: 8 B in + 8 * 147/160 B out, 4 * 16 * 147/160 FLOP per input sample
+    "resamp147_160": dict(ntaps=147 * 16 - 3, decim=160, interp=147, rot=False, bytes=8.0 + 8.0 * 147 / 160, flops=4 * 16 * 147 / 160, fc=0.4 / 160),
     # BASELINE configs[4]: 64 channels at (c - 31.5) fs/64, 256 taps, decimate 64: 8 B in + 64*8/64 B out
     "chan64": dict(ntaps=256, decim=64, rot=True, bytes=16.0, flops=1408.0, nchan=64),
     # its oversampled variant (SURVEY 8d config 5 "and M = 8"): 8 B in + 64*8/8 B out per input sample
@@ -96,10 +98,13 @@ def make_op(ops, name: str, device: int):
         # BlackmanWindow(cutoff=0.1 fs, transWidth=4 fs/63) of SURVEY 8d config 1, as designed by
         # the C++ host mirror; for the bench any fixed 63 taps do: use the FP64 design.
         taps = lowpass_taps(63, 0.1)
+    L = w.get("interp", 1)
+    if L > 1:
+        taps = (taps * L).astype(taps.dtype)       # unit pass-band gain after the zero-stuffing
     if w["rot"]:
-        return ops.Vfo(taps, 1, w["decim"], ops.phase_delta(1.0, 0.1234), device=device, max_block=0)
-    if w["decim"] > 1:
-        return ops.Resampler(taps, 1, w["decim"], device=device, max_block=0)
+        return ops.Vfo(taps, L, w["decim"], ops.phase_delta(1.0, 0.1234), device=device, max_block=0)
+    if w["decim"] > 1 or L > 1:
+        return ops.Resampler(taps, L, w["decim"], device=device, max_block=0)
     return ops.Fir(taps, device=device, max_block=0)
 
 
@@ -230,6 +235,7 @@ WORKLOAD_TEXT = {
     "decim8_t63": "63-tap polyphase decimate-by-8",
     "xlate_fir_decim8_t63": "fused NCO + 63-tap FIR + decimate-by-8",
     "vfo50": "fused NCO + 401-tap FIR + decimate-by-50 (the reference VFO's 2.4 Msps -> 48 kHz shape)",
+    "resamp147_160": "rational resampler 147/160 (48 kHz -> 44.1 kHz), 16 taps per phase",
     "chan64": "64-channel polyphase channelizer, 256 taps, decimate 64 (BASELINE configs[4])",
     "chan64m8": "64-channel polyphase channelizer oversampled by 8: 256 taps, decimate 8 (BASELINE configs[4], M = 8 variant)",
 }
@@ -292,8 +298,10 @@ def run_workload(name: str, args, ctx) -> dict:
     n = 1 << args.log2n
     # chunk starts must be multiples of lcm(decim, 512) once the stream is cut over ranks (per-call phase restart of the
     # resampler, VOLK gain cadence: qdsp_amd/sharding.py); a single rank runs one continuous stream and needs none
-    align = chunk_alignment(w["decim"], 1, 512 if w["rot"] else 0) if (world > 1 or self_ring) else 1
+    align = chunk_alignment(w["decim"], w.get("interp", 1), 512 if w["rot"] else 0) if (world > 1 or self_ring) else 1
     n -= n % align
+    if w.get("interp", 1) > 1:
+        n -= n % w["decim"]
     op = make_op(ops, name, local_rank)
     is_chan = name in ("chan64", "chan64m8")
     has_hist = name != "xlate"
@@ -304,7 +312,7 @@ def run_workload(name: str, args, ctx) -> dict:
     # [(s*world + r)*n, +n).  The synthetic block content repeats every step (same buffer), the halo hand-off is
     # the real one: every step each rank's tail goes to its ring successor over RCCL, prefetched under the kernel.
     x = ops.synth_iq(n, first_sample=rank * n, seed=1234, device=local_rank)
-    nout = n // w["decim"]
+    nout = n // w["decim"] * w.get("interp", 1)
     out = torch.empty((w["nchan"], nout) if is_chan else nout, dtype=torch.complex64, device=dev)
     ring = RingStream(op, n, rank, world, transport="host" if rehearse else "device", align=align,
                       exchange=(world > 1 or self_ring),
@@ -400,6 +408,10 @@ def run_workload(name: str, args, ctx) -> dict:
         # MACs (512), radix-16 (~200), twiddles (~90), radix-4 across the quad (~220), per-channel
         # rotation (~320): ~1350 FLOP x 64 lanes / 1024 input samples
         flops = 84.0 * (64 // w["decim"])
+    elif kinfo["name"] == "resamp_mfma_kernel":
+        # 16 blocks x 4 x 4 MACs x 2 components per step; per 4 periods (4 * decim inputs): groups * band columns steps
+        L, M = w.get("interp", 1), w["decim"]
+        flops = 2.0 * 512 * ((L + 63) // 64) * (3 * M // L + (w["ntaps"] + L - 1) // L + 1) / (4.0 * M)
     elif kinfo["name"] == "decim_mfma_kernel":
         # FP32 MFMA: per tile of 16 rows (16 * decim samples) 4 * ceil(decim / 8) v_mfma_f32_16x16x4_f32 of 2048 FLOP (the
         # A operand carries 16 tap rows whatever the tap count), one tile in 17 read twice; + ~14 VALU FLOP per sample (NCO)
@@ -431,7 +443,7 @@ def run_workload(name: str, args, ctx) -> dict:
             "launch": {"grid": kinfo["grid"], "block": kinfo["block"], "lds_bytes": kinfo["lds_bytes"]},
         },
         "roofline_fp32": {
-            "bound": "mfma" if kinfo["name"] == "decim_mfma_kernel" else "valu",
+            "bound": "mfma" if kinfo["name"] in ("decim_mfma_kernel", "resamp_mfma_kernel") else "valu",
             "achieved": round(achieved_tf, 2),
             "peak": FP32_PEAK_TFLOPS,
             "unit": "TFLOP/s",
