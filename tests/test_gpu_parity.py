@@ -1360,6 +1360,58 @@ def test_calls_beyond_2_31_samples(ops, gold):
         torch.cuda.empty_cache()
 
 
+def test_bench_size_mfma_kernels(ops, monkeypatch):
+    """The MFMA kernels at the bench's size (2^27 input samples = 1 GiB: byte offsets past 2^31, > 10^4 wave tasks):
+    the VFO's everyday shape through decim_mfma_kernel and 48 kHz -> 44.1 kHz through resamp_mfma_kernel against
+    oracle windows (start, middle past the 2^31-byte mark, end) and against the general direct kernel over the
+    whole output."""
+    import torch
+
+    n = 1 << 27
+    x = ops.synth_iq(n, seed=4242)
+    t401 = O.lowpass_taps_f64(401, 0.4 / 50).astype(np.float32)
+    v = ops.Vfo(t401, 1, 50, ops.phase_delta(1.0, 0.1234), max_block=0)
+    yv = v.process(x)
+    assert v.last_kernel()["name"] == "decim_mfma_kernel" and yv.numel() == n // 50
+    step = 12800                                                     # lcm(50, 512): polyphase counter and VOLK gain cadence restart together
+    for start in (0, ((1 << 26) + 777_000) // step * step, (n - 400_000) // step * step):
+        lo = max(start - step, 0)                                    # one aligned stretch of history in front
+        xh = O.synth_iq(lo, min(200_000, n - start) + (start - lo), seed=4242)
+        xlo = O.Xlator(1.0, 0.1234, exact=True, volk_gain=True)
+        dt = np.arctan2(float(xlo.delta[1]), float(xlo.delta[0])) / (2 * np.pi)
+        xlo.turns.value = (lo * dt) % 1.0
+        want = O.Resampler(t401, 1, 50, acc=O.ACC_F64).process(xlo.process(xh))[(start - lo) // 50:]
+        got = yv[start // 50:start // 50 + len(want)].cpu().numpy()
+        sl = slice(10 if start == 0 and lo == 0 else 0, None)
+        assert rel_rms(got[sl], want[sl]) < 2e-6, start
+    monkeypatch.setenv("QDSP_HIP_NO_MF", "1")
+    v2 = ops.Vfo(t401, 1, 50, ops.phase_delta(1.0, 0.1234), max_block=0)
+    y2 = v2.process(x)
+    assert v2.last_kernel()["name"] == "resamp_any_kernel"
+    monkeypatch.delenv("QDSP_HIP_NO_MF")
+    assert (yv - y2).abs().max().item() < 2e-5 * y2.abs().max().item()
+    del yv, y2, v, v2
+    L, M = 147, 160
+    taps = (O.lowpass_taps_f64(L * 16 - 3, 0.4 / M) * L).astype(np.float32)
+    nr = n // M * M
+    r = ops.Resampler(taps, L, M, max_block=0)
+    yr = r.process(x[:nr])
+    assert r.last_kernel()["name"] == "resamp_mfma_kernel" and yr.numel() == nr // M * L
+    for start in (0, ((1 << 26) + 555_555) // M * M, nr - 300 * M):
+        lo = max(start - 4 * M, 0)
+        xh = O.synth_iq(lo, min(120_000 // M * M, nr - start) + (start - lo), seed=4242)
+        want = O.Resampler(taps, L, M, acc=O.ACC_F64).process(xh)[(start - lo) // M * L:]
+        got = yr[start // M * L:start // M * L + len(want)].cpu().numpy()
+        sl = slice(40 if start == 0 else 0, None)
+        assert rel_rms(got[sl], want[sl]) < 2e-6, start
+    monkeypatch.setenv("QDSP_HIP_NO_RM", "1")
+    r2 = ops.Resampler(taps, L, M, max_block=0)
+    y2 = r2.process(x[:nr])
+    assert r2.last_kernel()["name"] == "resamp_any_kernel"
+    assert (yr - y2).abs().max().item() < 2e-5 * y2.abs().max().item()
+    torch.cuda.synchronize()
+
+
 def test_bench_size_cross_checks(ops, gold, monkeypatch):
     """The bench's size (2^27 samples per call = 1 GiB in: byte offsets past 2^31): independent kernels must agree.
     Overlap-save FIR vs direct form; fused polyphase overlap-save VFO (pfb_dec8_kernel) vs NCO kernel -> 4096-point
