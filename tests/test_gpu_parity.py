@@ -1360,6 +1360,28 @@ def test_calls_beyond_2_31_samples(ops, gold):
         torch.cuda.empty_cache()
 
 
+def test_resampler_reconfigure_across_kernel_families(ops, gold):
+    """PolyphaseResampler::setInSamplerate / setOutSamplerate / updateWindow (resampling.h:45-97) on a live handle:
+    every operand table the kernels keep (branch-major taps, MFMA A operands, band matrices, spectra) is rebuilt for the
+    new plan.  After each reconfiguration the outputs past the filter's transient equal a fresh oracle's."""
+    x = O.synth_iq(0, 400_000, seed=99)
+    plans = [(1, 50, 401, "decim_mfma_kernel"), (1, 8, 256, "fir_fft_kernel"), (147, 160, 147 * 16 - 3, "resamp_mfma_kernel"),
+             (1, 25, 100, "decim_mfma_kernel"), (3, 2, 95, "resamp_lm_kernel"), (10, 7, 77, "resamp_mfma_kernel"), (1, 50, 160, "decim_mfma_kernel")]
+    r = None
+    for L, M, ntaps, kernel in plans:
+        taps = (O.lowpass_taps_f64(ntaps, 0.4 / max(L, M)) * L).astype(np.float32)
+        if r is None:
+            r = ops.Resampler(taps, L, M, max_block=0)
+        else:
+            r.configure(taps, L, M)
+        n = len(x) // M * M
+        y = r.process(dev(x[:n])).cpu().numpy()
+        assert r.last_kernel()["name"] == kernel, (L, M, ntaps, r.last_kernel())
+        want = O.Resampler(taps, L, M, acc=O.ACC_F64).process(x[:n])
+        skip = (-(-ntaps // L) * L) // M + L + 2          # outputs whose window reaches into what came before the call
+        assert y.shape == want.shape and rel_rms(y[skip:], want[skip:]) < 1e-6, (L, M, ntaps)
+
+
 def test_bench_size_mfma_kernels(ops, monkeypatch):
     """The MFMA kernels at the bench's size (2^27 input samples = 1 GiB: byte offsets past 2^31, > 10^4 wave tasks):
     the VFO's everyday shape through decim_mfma_kernel and 48 kHz -> 44.1 kHz through resamp_mfma_kernel against
