@@ -58,7 +58,7 @@ __device__ __forceinline__ void diag_sum(const f32x4 d, float& cur, float& prev)
 }  // namespace
 
 // rot_k: the NCO table exp(j 64 i dphase) -- the kernel arguments' (one channel) or the channel's row of the device table
-template <int KJ, bool ROT, int DEPTH> __device__ __forceinline__ void decim_mfma_body(const MfArgs& a, const float2* __restrict__ rot_k) {
+template <int KJ, bool ROT, int DEPTH, int QS> __device__ __forceinline__ void decim_mfma_body(const MfArgs& a, const float2* __restrict__ rot_k) {
     constexpr int K = 8 * KJ, PITCH = K + 2, NI = 2 * KJ;
     const int t = threadIdx.x, l = t & 63;
     const int P = a.P, M = a.M;
@@ -83,7 +83,7 @@ template <int KJ, bool ROT, int DEPTH> __device__ __forceinline__ void decim_mfm
     const long long n0 = (long long)task * a.T;
     long long n1 = n0 + a.T;
     if (n1 > a.nout) n1 = a.nout;
-    const int ntiles = (int)((n1 - n0 + 15) >> 4) + 1;        // + 1: the rows the last outputs reach into
+    const int ntiles = (int)((n1 - n0 + 15) >> 4) + QS;       // + QS: the rows the last outputs reach into (16 per tap set)
     const int E = 16 * M;                                     // samples per tile
 
     // columns M..K-1 of the rows are never written: they meet zero taps, but must hold finite values
@@ -92,12 +92,15 @@ template <int KJ, bool ROT, int DEPTH> __device__ __forceinline__ void decim_mfm
         tile[row * PITCH + M + (i - row * (K - M))] = make_float2(0.0f, 0.0f);
     }
 
-    float ta[KJ][2];
+    // tap set s = tap rows 16 s .. 16 s + 15 (QS = 2: up to 32 taps per column)
+    float ta[QS][KJ][2];
 #pragma unroll
-    for (int jj = 0; jj < KJ; jj++) {
-        ta[jj][0] = a.tapk[(2 * jj) * 64 + l];
-        ta[jj][1] = a.tapk[(2 * jj + 1) * 64 + l];
-    }
+    for (int s = 0; s < QS; s++)
+#pragma unroll
+        for (int jj = 0; jj < KJ; jj++) {
+            ta[s][jj][0] = a.tapk[((s * KJ + jj) * 2) * 64 + l];
+            ta[s][jj][1] = a.tapk[((s * KJ + jj) * 2 + 1) * 64 + l];
+        }
     // element i of a tile for this lane: sample 64 i + l of its 16 M, LDS slot [row][col]; the elements past the tile's end
     // (only the last two loads can reach there) re-read its last sample and park it in the lane's spare slot
     int woff[NI];
@@ -135,7 +138,7 @@ template <int KJ, bool ROT, int DEPTH> __device__ __forceinline__ void decim_mfm
         plainb[d] = tile_plain(d);
         if (plainb[d]) load_tile(d, xb[d]);
     }
-    float carry_re = 0.0f, carry_im = 0.0f;
+    float carry_re = 0.0f, carry_im = 0.0f, carry2_re = 0.0f, carry2_im = 0.0f;
     auto do_tile = [&](int tt, float2 (&xn)[NI], bool& plain) {
         const long long g0 = gbase + (long long)E * tt;
         // NCO: lane phasor of the tile (FP64 recurrence, rounded once) x the FP32 table exp(j 64 i dphase) inside it,
@@ -179,27 +182,55 @@ template <int KJ, bool ROT, int DEPTH> __device__ __forceinline__ void decim_mfm
         plain = tile_plain(tt + DEPTH);
         if (plain) load_tile(tt + DEPTH, xn);
 
-        f32x4 zr = {0.0f, 0.0f, 0.0f, 0.0f}, zi = {0.0f, 0.0f, 0.0f, 0.0f};
+        f32x4 zr[QS], zi[QS];
+#pragma unroll
+        for (int s = 0; s < QS; s++) {
+            zr[s] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            zi[s] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
 #pragma unroll
         for (int jj = 0; jj < KJ; jj++) {
             const float4 b = brd[4 * jj];                                        // 8 samples = 64 B further per step
-            zr = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[jj][0], b.x, zr, 0, 0, 0);
-            zi = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[jj][0], b.y, zi, 0, 0, 0);
-            zr = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[jj][1], b.z, zr, 0, 0, 0);
-            zi = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[jj][1], b.w, zi, 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < QS; s++) {
+                zr[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[s][jj][0], b.x, zr[s], 0, 0, 0);
+                zi[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[s][jj][0], b.y, zi[s], 0, 0, 0);
+                zr[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[s][jj][1], b.z, zr[s], 0, 0, 0);
+                zi[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[s][jj][1], b.w, zi[s], 0, 0, 0);
+            }
         }
         float cur_re, prev_re, cur_im, prev_im;
-        diag_sum(zr, cur_re, prev_re);
-        diag_sum(zi, cur_im, prev_im);
-        float o_re = carry_re + prev_re, o_im = carry_im + prev_im;              // outputs of the previous tile, complete
-        carry_re = cur_re;
-        carry_im = cur_im;
+        diag_sum(zr[0], cur_re, prev_re);
+        diag_sum(zi[0], cur_im, prev_im);
+        float o_re, o_im;
+        if (QS == 1) {
+            o_re = carry_re + prev_re;                                           // outputs of the previous tile, complete
+            o_im = carry_im + prev_im;
+            carry_re = cur_re;
+            carry_im = cur_im;
+        } else {
+            // the second tap set reaches 16 rows further back: its in-tile part belongs to the previous tile's outputs, its
+            // carried part to the tile before that, which this tile completes
+            float c1_re, p1_re, c1_im, p1_im;
+            diag_sum(zr[QS - 1], c1_re, p1_re);
+            diag_sum(zi[QS - 1], c1_im, p1_im);
+            o_re = carry2_re + p1_re;
+            o_im = carry2_im + p1_im;
+            carry2_re = carry_re + prev_re + c1_re;
+            carry2_im = carry_im + prev_im + c1_im;
+            carry_re = cur_re;
+            carry_im = cur_im;
+        }
         o_re += __shfl_xor(o_re, 16);
         o_im += __shfl_xor(o_im, 16);
         o_re += __shfl_xor(o_re, 32);
         o_im += __shfl_xor(o_im, 32);
-        const long long n = n0 + 16LL * (tt - 1) + l;
-        if (tt > 0 && l < 16 && n < n1) a.out[n] = make_float2(o_re, o_im);
+        const long long n = n0 + 16LL * (tt - QS) + l;
+        if (tt >= QS && l < 16 && n < n1) {
+            // keep2: the kernel runs at half the decimation (rows of M / 2 samples: decimations 130-256) and every other output is the call's
+            if (!a.keep2) a.out[n] = make_float2(o_re, o_im);
+            else if (!(n & 1)) a.out[n >> 1] = make_float2(o_re, o_im);
+        }
     };
     for (int tt = 0; tt < ntiles; tt += DEPTH) {
 #pragma unroll
@@ -208,9 +239,9 @@ template <int KJ, bool ROT, int DEPTH> __device__ __forceinline__ void decim_mfm
     }
 }
 
-template <int KJ, bool ROT, int DEPTH>
-__global__ __launch_bounds__(256, KJ * DEPTH <= 8 ? 4 : (KJ * DEPTH <= 12 ? 3 : 2)) void decim_mfma_kernel(const MfArgs a) {
-    decim_mfma_body<KJ, ROT, DEPTH>(a, a.rot_k);
+template <int KJ, bool ROT, int DEPTH, int QS>
+__global__ __launch_bounds__(256, KJ * DEPTH * QS <= 8 ? 4 : (KJ * DEPTH * QS <= 12 ? 3 : 2)) void decim_mfma_kernel(const MfArgs a) {
+    decim_mfma_body<KJ, ROT, DEPTH, QS>(a, a.rot_k);
 }
 
 template <int KJ, int DEPTH>
@@ -225,7 +256,7 @@ __global__ __launch_bounds__(256, KJ * DEPTH <= 8 ? 4 : (KJ * DEPTH <= 12 ? 3 : 
     a.dphase = c.dphase;
     a.rot_step = c.rot_step;
     a.gm1 = c.gm1;
-    decim_mfma_body<KJ, true, DEPTH>(a, c.rot_k);
+    decim_mfma_body<KJ, true, DEPTH, 1>(a, c.rot_k);
 }
 
 int launch_mf_dec_batch(const MfBatchArgs& b, int nchan, int KJ, int depth, hipStream_t stream) {
@@ -243,16 +274,18 @@ int launch_mf_dec_batch(const MfBatchArgs& b, int nchan, int KJ, int depth, hipS
     return -1;
 }
 
-int launch_mf_dec(const MfArgs& a, int KJ, bool rot, int depth, hipStream_t stream) {
+int launch_mf_dec(const MfArgs& a, int KJ, bool rot, int depth, int qs, hipStream_t stream) {
     const dim3 grid((a.ntasks + 3) / 4 + 1), block(256);
-#define QK_MF(k)                                                                                           \
-    if (KJ == k) {                                                                                         \
-        if (rot && depth == 2) hipLaunchKernelGGL((decim_mfma_kernel<k, true, 2>), grid, block, 0, stream, a);          \
-        else if (rot) hipLaunchKernelGGL((decim_mfma_kernel<k, true, 1>), grid, block, 0, stream, a);      \
-        else if (depth == 2) hipLaunchKernelGGL((decim_mfma_kernel<k, false, 2>), grid, block, 0, stream, a);           \
-        else hipLaunchKernelGGL((decim_mfma_kernel<k, false, 1>), grid, block, 0, stream, a);              \
-        const hipError_t e = hipGetLastError();                                                            \
-        return e == hipSuccess ? 0 : -(int)e;                                                              \
+#define QK_MF(k)                                                                                                    \
+    if (KJ == k) {                                                                                                  \
+        if (qs == 2 && rot) hipLaunchKernelGGL((decim_mfma_kernel<k, true, 1, 2>), grid, block, 0, stream, a);     \
+        else if (qs == 2) hipLaunchKernelGGL((decim_mfma_kernel<k, false, 1, 2>), grid, block, 0, stream, a);       \
+        else if (rot && depth == 2) hipLaunchKernelGGL((decim_mfma_kernel<k, true, 2, 1>), grid, block, 0, stream, a);   \
+        else if (rot) hipLaunchKernelGGL((decim_mfma_kernel<k, true, 1, 1>), grid, block, 0, stream, a);           \
+        else if (depth == 2) hipLaunchKernelGGL((decim_mfma_kernel<k, false, 2, 1>), grid, block, 0, stream, a);    \
+        else hipLaunchKernelGGL((decim_mfma_kernel<k, false, 1, 1>), grid, block, 0, stream, a);                   \
+        const hipError_t e = hipGetLastError();                                                                     \
+        return e == hipSuccess ? 0 : -(int)e;                                                                       \
     }
     QK_MF(2) QK_MF(3) QK_MF(4) QK_MF(5) QK_MF(6) QK_MF(7) QK_MF(8)
     QK_MF(9) QK_MF(10) QK_MF(11) QK_MF(12) QK_MF(13) QK_MF(14) QK_MF(15) QK_MF(16)

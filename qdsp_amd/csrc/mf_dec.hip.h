@@ -28,17 +28,18 @@
 namespace qk {
 
 constexpr int kMfMaxKJ = 16;      // K / 8: decimations up to 128
-constexpr int kMfMaxQ = 16;       // taps per column (rows of the A operand)
+constexpr int kMfMaxQ = 32;       // taps per column: two sets of 16 rows of the A operand
 
 struct MfArgs {
     const float2* in;
     float2* out;
     const float2* hist;           // P samples preceding in[0] (fused VFO: rotated, as every direct-form kernel keeps them)
     float2* hist_next;
-    const float* tapk;            // [2 KJ][64] A operands: tapk[2 jj + a][l] = h[M (l % 16) + 8 jj + 2 (l / 16) + a], 0 outside
+    const float* tapk;            // [QS][2 KJ][64] A operands: tapk[s][2 jj + a][l] = h[M (16 s + l % 16) + 8 jj + 2 (l / 16) + a], 0 outside
     long long count, nout;
     int P, M;
     unsigned minv;                // ceil(2^32 / M): idx / M == umulhi(idx, minv) for the tile-relative indices (< 2^11)
+    int keep2;                    // 1: M is half the call's decimation; every other output is stored (at n / 2)
     int T;                        // outputs per wave task (multiple of 16)
     int ntasks;                   // wave tasks (grid = ceil(ntasks / 4) + 1: the last workgroup hands over the history)
     unsigned long long phase0, dphase;
@@ -71,6 +72,7 @@ struct MfBatchArgs {
 
 // KJ = ceil(M / 8) in 2..16; returns -1 for other shapes
 int launch_mf_dec_batch(const MfBatchArgs& b, int nchan, int KJ, int depth, hipStream_t stream);
-int launch_mf_dec(const MfArgs& a, int KJ, bool rot, int depth, hipStream_t stream);
+// qs: tap sets of 16 rows (1, or 2 for 17-32 taps per column: one tile in flight)
+int launch_mf_dec(const MfArgs& a, int KJ, bool rot, int depth, int qs, hipStream_t stream);
 
 }  // namespace qk

@@ -94,7 +94,7 @@ struct Engine {
     float* d_taps_rm = nullptr;    // rational MFMA resampler (rm_resamp.hip.h): A operands + first columns, built with the taps
     int rm_ngrp = 0, rm_KB = 0, rm_ext = 0, rm_pitch = 0, rm_G = 0, rm_J = 1, rm_qpb = 1;
     float* d_taps_mf = nullptr;    // MFMA decimator (mf_dec.hip.h): [2 KJ][64] A operands, built with the taps
-    int mf_KJ = 0;
+    int mf_KJ = 0, mf_QS = 1, mf_keep2 = 0;
     // polyphase overlap-save decimate-by-8 (pfb_dec.hip.h): column spectra + twiddles, built for (pfb_ntaps, pfb_dphase)
     float2* d_pfb = nullptr;
     int pfb_ntaps = -1;
@@ -243,14 +243,22 @@ bool use_lm(const Engine* e) {
 // on the tap count (0.21-0.25 ms per 2^27 samples from decimation 14 up, profiles/r02_tune_mf.md); below decimation 14
 // the tiles get small and it only wins over the strided-window / general kernels from ~12 taps per unit of decimation,
 // and the strided-window kernel keeps the short filters at decimation 16.
-bool mf_plan(const Engine* e, int* KJ) {
+bool mf_plan(const Engine* e, int* KJ, int* QS, int* keep2) {
     if (e->ch != 2 || e->L != 1 || !e->has_filter || e->kind == KIND_FIR) return false;
     const int M = e->M, P = e->P;
-    if (M < env_int("QDSP_HIP_MF_MIN_DECIM", 9) || M > 8 * qk::kMfMaxKJ) return false;
-    if ((P + M - 1) / M > qk::kMfMaxQ) return false;
+    if (M < env_int("QDSP_HIP_MF_MIN_DECIM", 9)) return false;
+    // decimations 130-256 (even): the kernel runs rows of M / 2 samples -- the decimator by M / 2 with the same taps -- and
+    // keeps every other output; twice the matrix work for the outputs that count, on a unit that has the room
+    const int k2 = (M > 8 * qk::kMfMaxKJ && M <= 16 * qk::kMfMaxKJ && M % 2 == 0 && !env_int("QDSP_HIP_MF_NO_KEEP2", 0)) ? 1 : 0;
+    const int Mk = k2 ? M / 2 : M;
+    if (Mk > 8 * qk::kMfMaxKJ) return false;
+    const int Q = (P + Mk - 1) / Mk;                  // taps per column: one set of 16 rows of the A operand, or two
+    if (Q > qk::kMfMaxQ || (Q > 16 && env_int("QDSP_HIP_MF_NO_QS2", 0))) return false;
     if (M < 14 && P < 12 * M) return false;
     if (use_win(e) && P < 6 * M) return false;
-    *KJ = (M + 7) / 8;
+    *KJ = (Mk + 7) / 8;
+    *QS = Q > 16 ? 2 : 1;
+    *keep2 = k2;
     return true;
 }
 
@@ -303,22 +311,26 @@ int upload_taps(Engine* e, const float* taps, int ntaps) {
         HIPCHK(hipMalloc(&e->d_taps_lm, lm.size() * sizeof(float)));
         HIPCHK(hipMemcpy(e->d_taps_lm, lm.data(), lm.size() * sizeof(float), hipMemcpyHostToDevice));
     }
-    // MFMA decimator (mf_dec.hip.h): A operand of step (jj, a), lane l = tap row q = l % 16, column 8 jj + 2 (l / 16) + a
+    // MFMA decimator (mf_dec.hip.h): A operand of set s, step (jj, a), lane l = tap row q = 16 s + l % 16, column 8 jj + 2 (l / 16) + a
     if (e->d_taps_mf) { HIPCHK(hipFree(e->d_taps_mf)); e->d_taps_mf = nullptr; }
     e->mf_KJ = 0;
     {
-        int KJ = 0;
-        if (mf_plan(e, &KJ)) {
-            std::vector<float> tk((size_t)2 * KJ * 64, 0.0f);
-            for (int jj = 0; jj < KJ; jj++)
-                for (int a = 0; a < 2; a++)
-                    for (int l = 0; l < 64; l++) {
-                        const int q = l % 16, col = 8 * jj + 2 * (l / 16) + a, k = e->M * q + col;
-                        if (col < e->M && k < e->P) tk[(size_t)(2 * jj + a) * 64 + l] = taps[k];
-                    }
+        int KJ = 0, QS = 1, keep2 = 0;
+        if (mf_plan(e, &KJ, &QS, &keep2)) {
+            const int Mk = keep2 ? e->M / 2 : e->M;
+            std::vector<float> tk((size_t)QS * 2 * KJ * 64, 0.0f);
+            for (int sset = 0; sset < QS; sset++)
+                for (int jj = 0; jj < KJ; jj++)
+                    for (int a = 0; a < 2; a++)
+                        for (int l = 0; l < 64; l++) {
+                            const int q = 16 * sset + l % 16, col = 8 * jj + 2 * (l / 16) + a, k = Mk * q + col;
+                            if (col < Mk && k < e->P) tk[((size_t)(sset * KJ + jj) * 2 + a) * 64 + l] = taps[k];
+                        }
             HIPCHK(hipMalloc(&e->d_taps_mf, tk.size() * sizeof(float)));
             HIPCHK(hipMemcpy(e->d_taps_mf, tk.data(), tk.size() * sizeof(float), hipMemcpyHostToDevice));
             e->mf_KJ = KJ;
+            e->mf_QS = QS;
+            e->mf_keep2 = keep2;
         }
     }
     // rational MFMA resampler (rm_resamp.hip.h): the banded period matrix W[i][c] = phases[(i M) % L][c - (i M) / L], cut
@@ -1378,15 +1390,17 @@ int launch_mf(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d_
     a.count = count;
     a.nout = nout;
     a.P = e->P;
-    a.M = e->M;
-    mf_tasks(a, nout, 1, e->rotate);
+    a.M = e->mf_keep2 ? e->M / 2 : e->M;
+    a.keep2 = e->mf_keep2;
+    if (e->mf_keep2) a.nout = 2 * nout - 1;      // (in the kernel's units: outputs of the decimator by M / 2)
+    mf_tasks(a, a.nout, 1, e->rotate);
     if (e->rotate) {
         a.phase0 = e->phase;
         a.dphase = e->dphase;
         a.gm1 = e->volk_gain ? e->gm1 : 0.0f;
-        mf_rot_tables(e->dphase, e->M, e->mf_KJ, &a.rot_step, a.rot_k);
+        mf_rot_tables(e->dphase, a.M, e->mf_KJ, &a.rot_step, a.rot_k);
     }
-    const int rc = qk::launch_mf_dec(a, e->mf_KJ, e->rotate, env_int("QDSP_HIP_MF_DEPTH", e->mf_KJ <= 8 ? 2 : 1), s);
+    const int rc = qk::launch_mf_dec(a, e->mf_KJ, e->rotate, env_int("QDSP_HIP_MF_DEPTH", e->mf_KJ <= 8 ? 2 : 1), e->mf_QS, s);
     if (rc) return rc < 0 && rc != -1 ? rc : QDSP_HIP_EINVAL;
     e->last.name = "decim_mfma_kernel";
     e->last.grid = (a.ntasks + 3) / 4 + 1;
@@ -1808,7 +1822,7 @@ int chan_launch_batch_mf(Chan* c, const void* d_in, int64_t count, int64_t nout,
     // direct kernel (profiles/r02_tune_chan_batch.txt: even at 4 channels x 1e6 samples, 16 x 1e6: 36 against 55 us)
     if (count * c->nchan < (int64_t)env_int("QDSP_HIP_MF_BATCH_MIN_WORK", 1 << 22)) return 1;
     for (Engine* e : c->vfo)
-        if (e->cur != e0->cur || !e->rotate || e->ch != 2 || !e->d_taps_mf || e->mf_KJ != e0->mf_KJ) return 1;
+        if (e->cur != e0->cur || !e->rotate || e->ch != 2 || !e->d_taps_mf || e->mf_KJ != e0->mf_KJ || e->mf_QS != 1 || e->mf_keep2) return 1;
     std::vector<qk::MfChanConst> key((size_t)c->nchan);
     for (int i = 0; i < c->nchan; i++) {
         Engine* e = c->vfo[i];

@@ -1058,8 +1058,8 @@ def test_vfo_retune_mid_stream(ops, gold, M, ntaps):
                                       (147, 1177), (192, 1537), (250, 2001), (1000, 2049), (2500, 1999)])
 def test_large_decimation_direct_kernel(ops, M, ntaps, monkeypatch):
     """The VFO's usual job (2.4 Msps -> 48 kHz is M = 50) with the reference's ~8 taps per unit of decimation, as
-    decimator and as fused VFO, over blocks that end inside tiles.  AUTO takes the MFMA decimator (decimation 14-128,
-    at most 16 taps per column: mf_dec.hip.h) and the general direct kernel beyond (padded LDS layout when M is a
+    decimator and as fused VFO, over blocks that end inside tiles.  AUTO takes the MFMA decimator (decimation 14-128, even
+    decimations up to 256, at most 32 taps per column: mf_dec.hip.h) and the general direct kernel beyond (padded LDS layout when M is a
     multiple of 4; 4-16 lanes per output from tiles of 64 outputs down); the general kernel is run on every shape
     (QDSP_HIP_NO_MF).  Neither adds its partial sums in the order of the k-ordered chain, so the bar is the FP64
     oracle, not bit equality."""
@@ -1068,7 +1068,8 @@ def test_large_decimation_direct_kernel(ops, M, ntaps, monkeypatch):
     x = O.synth_iq(0, sum(sizes), seed=M)
     cuts = np.cumsum([0] + sizes)
     blocks = [x[a:b] for a, b in zip(cuts, cuts[1:])]
-    mf = 14 <= M <= 128 and -(-ntaps // M) <= 16
+    Mk = M // 2 if (128 < M <= 256 and M % 2 == 0) else M           # (decimations 130-256: rows of M / 2 samples, every other output kept)
+    mf = 14 <= M and Mk <= 128 and -(-ntaps // Mk) <= 32
     for vfo in (False, True):
         if vfo:
             xl, rs = O.Xlator(1.0, 0.2345, exact=True, volk_gain=True), O.Resampler(taps, 1, M, acc=O.ACC_F64)
@@ -1094,10 +1095,13 @@ def test_large_decimation_direct_kernel(ops, M, ntaps, monkeypatch):
 
 
 @pytest.mark.parametrize("M,ntaps", [(9, 143), (13, 208), (14, 14), (16, 96), (16, 256), (17, 100), (24, 384), (31, 249), (33, 265), (50, 160),
-                                      (56, 449), (57, 449), (64, 1024), (65, 521), (72, 575), (73, 580), (96, 1500), (127, 2032), (128, 2048)])
+                                      (56, 449), (57, 449), (64, 1024), (65, 521), (72, 575), (73, 580), (96, 1500), (127, 2032), (128, 2048),
+                                      # two tap sets (17-32 taps per column) and decimations 130-256 (rows of M / 2 samples, every other output kept)
+                                      (16, 511), (17, 289), (50, 1201), (64, 2048), (100, 3200), (130, 1041), (200, 1601), (254, 2033), (256, 4096)])
 def test_mfma_decimator_shapes(ops, M, ntaps):
     """decim_mfma_kernel over its whole shape range: every K / 8 instantiation boundary (decimation 8 j and 8 j + 1), 1 to
-    16 taps per column (16 = all rows of the A operand), tiles whose last 64-sample load is partly or wholly past the
+    16 taps per column (16 = all rows of the A operand) and 17 to 32 (a second tap set, partial sums carried over two
+    tiles), decimations past 128 at half the row length, tiles whose last 64-sample load is partly or wholly past the
     tile (decimation 50: 800 samples = 12.5 loads), ragged blocks -- shorter than a tile of 16 rows, shorter than the
     decimation (no output), ending inside a tile -- so that every call starts and ends in the guarded tile path, and a
     retune between calls.  Decimator and fused VFO against the FP64 oracle."""
