@@ -510,7 +510,14 @@ int create(void** h, Kind kind, int device, int ch, bool rotate, bool has_filter
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (err == hipSuccess) err = hipEventCreate(&e->ev0);
     if (err == hipSuccess) err = hipEventCreate(&e->ev1);
-    if (err != hipSuccess) { delete e; return -(int)err; }
+    if (err != hipSuccess) {
+        // nothing created so far may outlive the failed handle
+        if (e->ev1) (void)hipEventDestroy(e->ev1);
+        if (e->ev0) (void)hipEventDestroy(e->ev0);
+        if (e->stream) (void)hipStreamDestroy(e->stream);
+        delete e;
+        return -(int)err;
+    }
     e->max_block = 0;
     (void)max_block;
     *h = e;
