@@ -9,8 +9,8 @@
 // v_mfma_f32_16x16x4_f32 per component (A = taps, 16 rows q of which Q <= 16 are used; B = data, one of the 16 rows per
 // lane column; K = M rounded up to 8).  The FP32 MFMA is bit-for-bit an fmaf chain (one rounding per product), so the
 // numerics are those of the direct kernels.  What the matrix unit buys: no per-tap LDS reads (resamp_any_kernel: every
-// sample read back Q times, LDS 74 % busy) and no cross-lane reduction per output (decim_col_kernel: twelve DPP adds
-// per output) -- a sample is written to LDS once and read once, as a B operand.
+// sample read back Q times, LDS 74 % busy) and no cross-lane reduction per output (a lane-per-column VALU kernel, built first and
+// not kept, spent twelve DPP adds per output) -- a sample is written to LDS once and read once, as a B operand.
 //
 // Execution model: a wave owns a run of T outputs and never meets another wave (no workgroup barrier).  Per tile it
 //   - takes the tile's 16 M samples from registers (loaded one tile AHEAD, linearly: 64 consecutive samples per
