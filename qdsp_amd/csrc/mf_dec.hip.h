@@ -22,6 +22,10 @@
 //     the row index on its 16 lanes, so the shift by q is a DPP row shift by the register index plus a per-group shift
 //     by 4g (row-masked DPP), then one sum over the four lane groups.  Partial sums that reach into the previous tile's
 //     outputs are carried in a register.
+//
+// 17-32 taps per column: a second tap set (tap rows 16-31; its diagonal sums belong one tile further back, so a tile
+// completes the outputs two tiles behind it).  Decimations 130-256 (even): the same kernel at M / 2 -- the decimator
+// by M / 2 with the same taps -- storing every other output (keep2).
 #pragma once
 #include <hip/hip_runtime.h>
 
