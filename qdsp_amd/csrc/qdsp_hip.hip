@@ -1416,6 +1416,25 @@ int launch_mf(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d_
     return 0;
 }
 
+// Smallest call the MFMA kernels take (profiles/r02_tune_call_size_mfma.txt).  Their waves set up operand tables, slot
+// maps and an FP64 phasor before the first tile and then walk their tiles one after the other, so on a reference-sized
+// block (<= 1e6 samples, src/dsp/stream.h:7) the general direct kernel is 1-3 us quicker wherever a wave's tile is large
+// (decimations past 32, periods of >= 33 outputs); the crossover sits at 2-5e6 samples -- 1.4e7 for the decimations
+// run at half the row length -- and from there on the MFMA kernels are 1.3-2x faster.  Short rows (decimation <= 32)
+// and the small rational ratios are quicker at every size.
+int64_t mf_min_count(const Engine* e) {
+    const int v = env_int("QDSP_HIP_MF_MIN_COUNT", -1);
+    if (v >= 0) return v;
+    if (e->mf_keep2) return 1 << 24;
+    if (e->mf_QS == 2 || e->mf_KJ > 4) return 3 << 20;
+    return 0;
+}
+int64_t rm_min_count(const Engine* e) {
+    const int v = env_int("QDSP_HIP_RM_MIN_COUNT", -1);
+    if (v >= 0) return v;
+    return e->L >= 33 ? 6 << 20 : 0;
+}
+
 // One run() worth of work on device pointers.  Returns the output count.
 int64_t process_dev(Engine* e, const void* d_in, int64_t count, void* d_out, void* stream) {
     if (count < 0 || (count > 0 && ((!d_in && e->kind != KIND_SINE) || !d_out))) return QDSP_HIP_EINVAL;
@@ -1430,7 +1449,7 @@ int64_t process_dev(Engine* e, const void* d_in, int64_t count, void* d_out, voi
     } else if (mode_of(e) == 0 && fir_lat_eligible(e, count)) {
         rc = launch_fir_lat(e, d_in, count, d_out, s);
         if (rc == 0) e->cur ^= 1;
-    } else if (e->d_taps_mf && mode_of(e) == 0 && nout > 0 && !env_int("QDSP_HIP_NO_MF", 0)) {
+    } else if (e->d_taps_mf && mode_of(e) == 0 && nout > 0 && count >= mf_min_count(e) && !env_int("QDSP_HIP_NO_MF", 0)) {
         // large integer decimations (the VFO's usual job) as an FP32 matrix product on the MFMA units (mf_dec.hip.h)
         rc = launch_mf(e, d_in, count, nout, d_out, s);
         if (rc == 0) e->cur ^= 1;
@@ -1463,7 +1482,7 @@ int64_t process_dev(Engine* e, const void* d_in, int64_t count, void* d_out, voi
         if (e->ch == 2) rc = e->rotate ? launch_core<2, true>(e, a, s) : launch_core<2, false>(e, a, s);
         else rc = launch_core<1, false>(e, a, s);
         if (rc == 0) e->cur ^= 1;
-    } else if (e->d_taps_rm && e->rm_ngrp && mode_of(e) == 0 && nout > 0 && !env_int("QDSP_HIP_NO_RM", 0)) {
+    } else if (e->d_taps_rm && e->rm_ngrp && mode_of(e) == 0 && nout > 0 && count >= rm_min_count(e) && !env_int("QDSP_HIP_NO_RM", 0)) {
         // rational ratios with interp >= 6 (48 kHz <-> 44.1 kHz is 147 / 160) on the MFMA units (rm_resamp.hip.h)
         rc = launch_rm(e, d_in, count, nout, d_out, s);
         if (rc == 0) e->cur ^= 1;

@@ -1386,6 +1386,50 @@ def test_resampler_reconfigure_across_kernel_families(ops, gold):
         assert y.shape == want.shape and rel_rms(y[skip:], want[skip:]) < 1e-6, (L, M, ntaps)
 
 
+@pytest.mark.default_dispatch
+def test_default_size_thresholds_of_the_mfma_kernels(ops):
+    """Under the library's own thresholds a reference-sized block of the VFO's everyday shape (401 taps, decimate by 50)
+    and of 48 kHz -> 44.1 kHz runs the general direct kernel (1-3 us quicker there), a call of several million samples the
+    MFMA kernels; short rows (decimate by 16) and the small ratios take the MFMA kernels at any size.  The stream
+    switches kernels from call to call on one history and NCO state."""
+    t401 = O.lowpass_taps_f64(401, 0.4 / 50).astype(np.float32)
+    sizes = [50 * 20_000, 50 * 70_000 + 13, 50 * 1_000 + 7, 50 * 65_000]
+    x = O.synth_iq(0, sum(sizes), seed=31)
+    cuts = np.cumsum([0] + sizes)
+    v = ops.Vfo(t401, 1, 50, ops.phase_delta(1.0, 0.2345), max_block=0)
+    xl, rs = O.Xlator(1.0, 0.2345, exact=True, volk_gain=True), O.Resampler(t401, 1, 50, acc=O.ACC_F64)
+    got, want, names = [], [], []
+    for a, b in zip(cuts, cuts[1:]):
+        got.append(v.process(dev(x[a:b])).cpu().numpy())
+        names.append(v.last_kernel()["name"])
+        want.append(rs.process(xl.process(x[a:b])))
+    assert names == ["resamp_any_kernel", "decim_mfma_kernel", "resamp_any_kernel", "decim_mfma_kernel"], names
+    got, want = np.concatenate(got), np.concatenate(want)
+    assert got.shape == want.shape and rel_rms(got, want) < 2e-6
+    L, M = 147, 160
+    taps = (O.lowpass_taps_f64(L * 16 - 3, 0.4 / M) * L).astype(np.float32)
+    sizes = [M * 6_000, M * 40_000 + 77, M * 500]
+    x = O.synth_iq(0, sum(sizes), seed=32)
+    cuts = np.cumsum([0] + sizes)
+    r = ops.Resampler(taps, L, M, max_block=0)
+    rs = O.Resampler(taps, L, M, acc=O.ACC_F64)
+    got, want, names = [], [], []
+    for a, b in zip(cuts, cuts[1:]):
+        got.append(r.process(dev(x[a:b])).cpu().numpy())
+        names.append(r.last_kernel()["name"])
+        want.append(rs.process(x[a:b]))
+    assert names == ["resamp_any_kernel", "resamp_mfma_kernel", "resamp_any_kernel"], names
+    got, want = np.concatenate(got), np.concatenate(want)
+    assert got.shape == want.shape and rel_rms(got, want) < 1e-6
+    for taps_, L_, M_, kernel in ((O.lowpass_taps_f64(129, 0.4 / 16).astype(np.float32), 1, 16, "decim_mfma_kernel"),
+                                  ((O.lowpass_taps_f64(77, 0.4 / 10) * 10).astype(np.float32), 10, 7, "resamp_mfma_kernel")):
+        op = ops.Resampler(taps_, L_, M_, max_block=0)
+        xs = O.synth_iq(0, M_ * 3000, seed=33)
+        y = op.process(dev(xs)).cpu().numpy()
+        assert op.last_kernel()["name"] == kernel
+        assert rel_rms(y, O.Resampler(taps_, L_, M_, acc=O.ACC_F64).process(xs)) < 1e-6
+
+
 def test_bench_size_mfma_kernels(ops, monkeypatch):
     """The MFMA kernels at the bench's size (2^27 input samples = 1 GiB: byte offsets past 2^31, > 10^4 wave tasks):
     the VFO's everyday shape through decim_mfma_kernel and 48 kHz -> 44.1 kHz through resamp_mfma_kernel against
