@@ -60,7 +60,7 @@ template <bool ROT> __global__ __launch_bounds__(256, 3) void resamp_mfma_kernel
             if (64 * e < a.total) xn[e] = p[min(64 * e + l, a.total - 1)];         // (past the tile: its last sample again, not stored)
     };
     auto put = [&](int u, float2 v) {
-        const int b = (int)__umulhi((unsigned)u, a.minv), c = u - b * M;
+        const int b = M == 1 ? u : (int)__umulhi((unsigned)u, a.minv), c = u - b * M;      // (ceil(2^32 / 1) does not fit the multiplier)
         tile[(u < a.total && b < rows) ? b * a.pitch + c : spare] = v;
         tile[(u < a.total && b >= 1 && c < a.ext) ? (b - 1) * a.pitch + M + c : spare] = v;
     };

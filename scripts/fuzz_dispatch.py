@@ -1,0 +1,73 @@
+"""Randomised differential run: random plans (interp, decim, taps, NCO) and random block sequences through the default
+dispatch and through the lifted-threshold dispatch, against the FP64-accumulating oracle.  Run on the GPU box:
+python scripts/fuzz_dispatch.py [seconds] [seed]"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import oracle as O
+from qdsp_amd import ops
+
+def rel_rms(a, b): return float(np.sqrt(np.mean(np.abs(a - b) ** 2) / max(np.mean(np.abs(b) ** 2), 1e-30)))
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+t_end = time.time() + budget
+n_cases, kernels, worst = 0, {}, 0.0
+while time.time() < t_end:
+    kind = rng.choice(["dec", "dec", "rat", "fir"])
+    if kind == "fir":
+        L, M = 1, 1
+        ntaps = int(rng.integers(1, 400))
+    elif kind == "dec":
+        L, M = 1, int(rng.choice([2, 3, 5, 8, 9, 12, 14, 16, 17, 24, 31, 32, 33, 50, 64, 100, 127, 128, 130, 200, 256, 300]))
+        ntaps = int(rng.integers(1, min(34 * M, 5000)))
+    else:
+        L = int(rng.choice([2, 3, 5, 7, 10, 12, 16, 33, 48, 64, 100, 147, 160, 192, 200]))
+        M = int(rng.choice([1, 2, 3, 5, 7, 8, 25, 49, 50, 147, 160, 175]))
+        if np.gcd(L, M) != 1:
+            continue
+        ntaps = int(rng.integers(L, 40 * L))
+    vfo = bool(rng.integers(0, 2)) and kind != "fir"
+    lift = bool(rng.integers(0, 2))
+    for k in ("QDSP_HIP_MF_MIN_COUNT", "QDSP_HIP_RM_MIN_COUNT", "QDSP_HIP_RM_MIN_INTERP"):
+        os.environ.pop(k, None)
+    if lift:
+        os.environ["QDSP_HIP_MF_MIN_COUNT"] = "0"
+        os.environ["QDSP_HIP_RM_MIN_COUNT"] = "0"
+        if rng.integers(0, 2):
+            os.environ["QDSP_HIP_RM_MIN_INTERP"] = "2"
+    taps = (O.lowpass_taps_f64(ntaps, 0.45 / max(L, M)) * L).astype(np.float32) if ntaps > 2 else rng.standard_normal(ntaps).astype(np.float32)
+    nblocks = int(rng.integers(1, 5))
+    total_budget = int(3e6 / max(1, ntaps / max(L, 1) / 16))
+    sizes = [int(rng.integers(0, max(2, min(total_budget, 400_000)))) for _ in range(nblocks)]
+    if rng.integers(0, 3) == 0:
+        sizes[int(rng.integers(0, nblocks))] = int(rng.integers(0, 3 * M + 2))
+    x = O.synth_iq(0, sum(sizes) + 1, seed=int(rng.integers(0, 1 << 30)))[:sum(sizes)]
+    cuts = np.cumsum([0] + sizes)
+    blocks = [x[a:b] for a, b in zip(cuts, cuts[1:])]
+    f = float(rng.uniform(-0.45, 0.45))
+    if kind == "fir":
+        op, orc = ops.Fir(taps, max_block=0), O.Fir(taps, acc=O.ACC_F64)
+        want = np.concatenate([orc.process(b) for b in blocks]) if sum(sizes) else np.zeros(0, np.complex64)
+    elif vfo:
+        op = ops.Vfo(taps, L, M, ops.phase_delta(1.0, f), max_block=0)
+        xl, rs = O.Xlator(1.0, f, exact=True, volk_gain=True), O.Resampler(taps, L, M, acc=O.ACC_F64)
+        want = np.concatenate([rs.process(xl.process(b)) for b in blocks])
+    else:
+        op, rs = ops.Resampler(taps, L, M, max_block=0), O.Resampler(taps, L, M, acc=O.ACC_F64)
+        want = np.concatenate([rs.process(b) for b in blocks])
+    got, names = [], set()
+    for b in blocks:
+        got.append(op.process(torch.from_numpy(b).cuda()).cpu().numpy())
+        if len(b):
+            names.add(op.last_kernel()["name"])
+    got = np.concatenate(got) if got else np.zeros(0, np.complex64)
+    err = rel_rms(got, want) if got.shape == want.shape and len(want) else (0.0 if got.shape == want.shape else float("inf"))
+    tol = 3e-6
+    for nm in names: kernels[nm] = kernels.get(nm, 0) + 1
+    n_cases += 1
+    worst = max(worst, err)
+    if not err < tol:
+        print(f"FAIL kind={kind} L={L} M={M} ntaps={ntaps} vfo={vfo} lift={lift} env={dict((k, os.environ.get(k)) for k in ('QDSP_HIP_RM_MIN_INTERP',))} sizes={sizes} f={f} kernels={names} err={err} shapes={got.shape}/{want.shape}", flush=True)
+        sys.exit(1)
+print(f"{n_cases} cases ok, worst rel rms {worst:.2e}, kernels {kernels}")

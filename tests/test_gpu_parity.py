@@ -1133,6 +1133,8 @@ def test_mfma_decimator_shapes(ops, M, ntaps):
 
 @pytest.mark.parametrize("L,M,tpp,forced", [(147, 160, 16, False), (160, 147, 16, False), (48, 50, 20, False), (192, 175, 9, False), (40, 39, 28, False),
                                             (6, 1, 10, False), (64, 63, 1, False),
+                                            # one or two taps per phase at decimation 1: the merged period is a single sample long (found by scripts/fuzz_dispatch.py)
+                                            (6, 1, 2, False), (12, 1, 1, False), (7, 1, 2, False),
                                             # the decimating side of the small ratios (merged periods, shared steps): faster than resamp_lm_kernel
                                             (10, 7, 8, False), (10, 3, 16, False), (5, 7, 20, False), (5, 8, 12, False), (4, 7, 20, False), (3, 8, 20, False), (2, 5, 20, False),
                                             # periods of <= 8 blocks share an MFMA step between period quads; periods shorter than their
