@@ -13,8 +13,41 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 t_end = time.time() + budget
 n_cases, kernels, worst = 0, {}, 0.0
+t_note = time.time()
 while time.time() < t_end:
-    kind = rng.choice(["dec", "dec", "rat", "fir"])
+    if time.time() - t_note > 30:
+        t_note = time.time()
+        print(f"... {n_cases} cases, worst {worst:.2e}", flush=True)
+    kind = rng.choice(["dec", "dec", "rat", "fir", "chan", "big"])
+    if kind == "chan":
+        # non-uniform channel bank (Splitter -> N x VFO): every channel against its own xlator -> resampler oracle
+        M = int(rng.choice([8, 10, 16, 25, 50, 64, 100]))
+        ntaps = int(rng.integers(M, 9 * M))
+        nch = int(rng.integers(2, 20))
+        taps = O.lowpass_taps_f64(ntaps, 0.45 / M).astype(np.float32)
+        freqs = [float(rng.uniform(-0.45, 0.45)) for _ in range(nch)]
+        os.environ["QDSP_HIP_MF_BATCH_MIN_WORK"] = str(int(rng.choice([0, 1 << 22])))
+        ch = ops.Channelizer(taps, 1, M, [ops.phase_delta(1.0, f) for f in freqs], max_block=0)
+        sizes = [int(rng.integers(0, 300_000)) for _ in range(int(rng.integers(1, 4)))]
+        x = O.synth_iq(0, sum(sizes) + 1, seed=int(rng.integers(0, 1 << 30)))[:sum(sizes)]
+        cuts = np.cumsum([0] + sizes)
+        ys = [ch.process(torch.from_numpy(x[a:b]).cuda()).cpu().numpy() for a, b in zip(cuts, cuts[1:])]
+        names = {ch.last_kernel()["name"]}
+        y = np.concatenate(ys, axis=1)
+        for c in rng.choice(nch, size=min(nch, 3), replace=False):
+            xl, rs = O.Xlator(1.0, freqs[c], exact=True, volk_gain=True), O.Resampler(taps, 1, M, acc=O.ACC_F64)
+            want = np.concatenate([rs.process(xl.process(x[a:b])) for a, b in zip(cuts, cuts[1:])])
+            err = rel_rms(y[c], want) if y[c].shape == want.shape and len(want) else (0.0 if y[c].shape == want.shape else float("inf"))
+            worst = max(worst, err)
+            if not err < 3e-6:
+                print(f"FAIL chan M={M} ntaps={ntaps} nch={nch} c={c} sizes={sizes} kernels={names} err={err}", flush=True)
+                sys.exit(1)
+        for nm in names: kernels[nm] = kernels.get(nm, 0) + 1
+        n_cases += 1
+        continue
+    big = kind == "big"
+    if big:
+        kind = "dec"
     if kind == "fir":
         L, M = 1, 1
         ntaps = int(rng.integers(1, 400))
@@ -40,6 +73,9 @@ while time.time() < t_end:
     nblocks = int(rng.integers(1, 5))
     total_budget = int(3e6 / max(1, ntaps / max(L, 1) / 16))
     sizes = [int(rng.integers(0, max(2, min(total_budget, 400_000)))) for _ in range(nblocks)]
+    if big and M >= 16 and ntaps <= 20 * M:
+        # one call past the size thresholds of the MFMA kernels (3e6 / 1.6e7 samples)
+        sizes[int(rng.integers(0, nblocks))] = int(rng.choice([3_200_000, 5_000_003, 17_000_000 if M >= 130 else 4_000_000]))
     if rng.integers(0, 3) == 0:
         sizes[int(rng.integers(0, nblocks))] = int(rng.integers(0, 3 * M + 2))
     x = O.synth_iq(0, sum(sizes) + 1, seed=int(rng.integers(0, 1 << 30)))[:sum(sizes)]
