@@ -49,6 +49,7 @@ struct FftArgs {
     int nwg;                  // persistent workgroups (grid = nwg + 1; the last one hands over history)
     int vec;                  // 1: in/out 16-byte aligned and segments start on even samples -> float4 path
     int grouped;              // dec >= 4: 1 = fir_fft_dec_kernel (groups of dec segments), 0 = one segment per workgroup
+    int m_shift;              // fir_fft1k_kernel, strided: log2(decm) when decm is a power of two <= 64 (a lane keeps all or none of its 16 elements), else -1
     int real2;                // 1: real samples (4-byte in/out/hist); block b = real segments 2b (re) and 2b+1 (im)
     // NCO (rot only).  x[j] exp(j phi(j)) filtered by h == exp(j phi(p - (N-1))) * (x filtered by
     // h[k] exp(j k dphase)) at output position p: the input is never rotated, only the KEPT outputs are.
@@ -59,6 +60,13 @@ struct FftArgs {
     float2 wtab[16];          // exp(j 2pi 256*n2*dphase)
     float gm1;                // |phase_inc| - 1 (VOLK magnitude sawtooth: a real scale of the input samples), 0 = off
 };
+
+// fft1k_fir.hip: 1024-point segments, one wave each (reference-sized calls).  Same FftArgs; Hf / TA / TB point at
+// that kernel's own tables (entry-major: [16][64] spectrum in its pass-C order, [16][64] W1024^(l ka), [16][4] W64^(j kb1)),
+// wtab[i] = exp(j 2pi 64 i dphase), nblocks segments = the grid minus the hand-over workgroup.
+constexpr int kFft1kN = 1024;
+constexpr int kFft1kPitch = 84;
+int launch_fir_fft1k(const FftArgs& a, hipStream_t stream);
 
 // Defined in fft_fir.hip (its own translation unit: built with -fno-slp-vectorize, see there).
 int launch_fir_fft(const FftArgs& a, int grid, hipStream_t stream);

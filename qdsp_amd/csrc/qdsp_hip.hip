@@ -90,6 +90,18 @@ struct Engine {
     float2* d_fft_TA = nullptr;
     float2* d_fft_TB = nullptr;
     int fft_ntaps = -1;         // tap count d_fft_H was built for (-1: not built)
+    // 1024-point segments, one wave each (fft1k_fir.hip): spectrum in that kernel's pass-C order + its twiddles
+    float2* d_f1k_H = nullptr;
+    float2* d_f1k_T = nullptr;  // [16][64] W1024^(l ka), then [16][4] W64^(j kb1)
+    int f1k_ntaps = -1;
+    unsigned long long f1k_dphase = 0;
+    // per-call NCO constants of the overlap-save launches, kept while the increment stands (16 long-double sincos
+    // per call are ~3 us of host time: more than a reference-sized call's kernel)
+    float2 wtab1k[16], wtab4k[16];
+    unsigned long long wtab1k_dphase = 0, wtab4k_dphase = 0, rot_step_dphase = 0;
+    bool wtab1k_ok = false, wtab4k_ok = false, rot_step_ok = false;
+    long double rot_step_mult = 0.0L;
+    double2 rot_step_val;
     unsigned long long fft_dphase = 0;   // NCO increment d_fft_H was built for (fused VFO), 0 otherwise
     float* d_taps_rm = nullptr;    // rational MFMA resampler (rm_resamp.hip.h): A operands + first columns, built with the taps
     int rm_ngrp = 0, rm_KB = 0, rm_ext = 0, rm_pitch = 0, rm_G = 0, rm_J = 1, rm_qpb = 1;
@@ -423,6 +435,7 @@ int configure(Engine* e, const float* taps, int ntaps, int interp, int decim) {
     if (rc) return rc;
     e->taps_host.assign(taps, taps + ntaps);
     e->fft_ntaps = -1;
+    e->f1k_ntaps = -1;
     e->pfb_ntaps = -1;
     const size_t bytes = (size_t)(newH > 0 ? newH : 1) * e->ch * sizeof(float);
     float* nh[2] = {nullptr, nullptr};
@@ -536,6 +549,8 @@ void destroy(Engine* e) {
     if (e->d_fft_H) (void)hipFree(e->d_fft_H);
     if (e->d_fft_TA) (void)hipFree(e->d_fft_TA);
     if (e->d_fft_TB) (void)hipFree(e->d_fft_TB);
+    if (e->d_f1k_H) (void)hipFree(e->d_f1k_H);
+    if (e->d_f1k_T) (void)hipFree(e->d_f1k_T);
     if (e->d_pfb) (void)hipFree(e->d_pfb);
     if (e->d_taps_mf) (void)hipFree(e->d_taps_mf);
     if (e->d_taps_rm) (void)hipFree(e->d_taps_rm);
@@ -902,6 +917,8 @@ bool any_direct_wins(const Engine* e) {
     return e->P <= per_m * e->M && e->P <= max_taps;
 }
 
+bool fft1k_eligible(const Engine* e, int64_t count);
+
 bool fft_eligible(const Engine* e, int64_t count) {
     if (!fft_dec(e)) return false;
     int mode = e->fir_mode ? e->fir_mode : env_int("QDSP_HIP_FIR_MODE", 0);
@@ -927,7 +944,9 @@ bool fft_eligible(const Engine* e, int64_t count) {
         min_taps = env_int("QDSP_HIP_FFT_MIN_TAPS", 8);
         // reference-sized calls (<= 1e6 samples, stream.h:7) are latency-bound: one 4096-point segment takes ~9 us
         // whatever the taps, the direct form 4.7 / 5.7 us at 31 / 63 taps (8.3 at 1e6 samples) and 11-16 us at 256
-        if (count < (1 << 21) && min_taps < 96) min_taps = env_int("QDSP_HIP_FFT_MIN_TAPS_SMALL", 96);
+        // (round 2: with one-wave 1024-point segments -- fft1k_fir.hip -- the small calls cross over at ~24 taps:
+        // 31 taps x 1e6 samples 6.8 us against 7.2, 95 taps x 262144 5.7 against 6.9; profiles/r02_tune_fft1k.txt)
+        if (count < (1 << 21) && min_taps < 96) min_taps = env_int("QDSP_HIP_FFT_MIN_TAPS_SMALL", fft1k_eligible(e, count) ? 24 : 96);
     } else {
         if (e->M >= 9 && !use_win(e) && any_direct_wins(e)) return false;
         // decimators (scripts/tune_small.py, profiles/r01_tune_small.txt): the direct form slows down with the
@@ -937,7 +956,8 @@ bool fft_eligible(const Engine* e, int64_t count) {
         const int dflt = e->M >= 7 ? 2 : 112;
         min_taps = env_int("QDSP_HIP_FFT_MIN_TAPS_DECIM", dflt);
     }
-    return e->ntaps >= min_taps && count >= env_int("QDSP_HIP_FFT_MIN_COUNT", 1 << 16);
+    // (below 2^16 samples a 4096-point segment per workgroup leaves most of the chip idle; one-wave segments go down to 2^14)
+    return e->ntaps >= min_taps && count >= env_int("QDSP_HIP_FFT_MIN_COUNT", fft1k_eligible(e, count) ? 1 << 14 : 1 << 16);
 }
 
 int fft_prepare(Engine* e) {
@@ -993,6 +1013,152 @@ int fft_prepare(Engine* e) {
     HIPCHK(hipMemcpy(e->d_fft_H, Hp.data(), sizeof(float2) * F, hipMemcpyHostToDevice));
     e->fft_ntaps = N;
     e->fft_dphase = key_dphase;
+    return 0;
+}
+
+// ---- overlap-save on 1024-point segments, one wave each (fft1k_fir.hip) --------------------------------
+// Reference-sized calls: a lone 4096-point segment takes its workgroup ~12 us whatever else runs (8 barriers), so a
+// call that cannot fill the chip four workgroups deep is better off as 4x as many independent one-wave segments.
+// Bounds: complex data, interp 1, taps up to half a segment; calls from the first size the 4096-point form is
+// picked for up to QDSP_HIP_FFT1K_MAX_COUNT (measured crossover, scripts/tune_call_size.py).
+bool fft1k_eligible(const Engine* e, int64_t count) {
+    if (e->ch != 2 || e->L != 1 || e->ntaps < 2 || e->ntaps > 513) return false;
+    if (e->kind != KIND_FIR && e->kind != KIND_DECIM && e->kind != KIND_VFO) return false;
+    const int mode = e->fir_mode ? e->fir_mode : env_int("QDSP_HIP_FIR_MODE", 0);
+    if (mode != 0 || env_int("QDSP_HIP_NO_FFT1K", 0)) return false;
+    const int forced = env_int("QDSP_HIP_FFT1K_MAX_COUNT", -1);
+    if (forced >= 0) return count <= forced;
+    // measured crossovers against the 4096-point kernels (scripts/tune_fft1k.py, profiles/r02_tune_fft1k.txt): the
+    // overlap grows with the taps (1024 - ntaps + 1 new points per segment), decimations 2 / 4 / 8 / 16 have the
+    // pruned inverse on the other side, the fused NCO costs this form 32 more complex products per lane
+    const bool pruned = e->kind != KIND_FIR && (e->M == 2 || e->M == 4 || e->M == 8 || e->M == 16);
+    int64_t lim = e->ntaps <= 128 ? 6 << 20 : e->ntaps <= 288 ? 4 << 20 : e->ntaps <= 416 ? 3 << 20 : 2 << 20;
+    if (pruned) lim = e->ntaps <= 288 ? 3 << 20 : 3 << 19;
+    if (e->rotate && (pruned || e->ntaps > 288)) lim = 3 << 19;
+    return count <= lim;
+}
+
+int fft1k_prepare(Engine* e) {
+    const unsigned long long key_dphase = e->rotate ? e->dphase : 0;
+    if (e->f1k_ntaps == e->ntaps && e->d_f1k_H && e->f1k_dphase == key_dphase) return 0;
+    constexpr int F = qk::kFft1kN;
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    std::vector<long double> cs(F), sn(F);
+    for (int i = 0; i < F; i++) {
+        cs[i] = cosl(two_pi * (long double)i / F);
+        sn[i] = sinl(two_pi * (long double)i / F);
+    }
+    const int N = e->ntaps;
+    // g[j] = taps[N-1-j] (x exp(j (N-1-j) dphase) for the fused VFO), Hf[k] = sum_j g[j] exp(-j 2pi jk/F) / F: as fft_prepare
+    std::vector<long double> gr(N), gi(N);
+    for (int j = 0; j < N; j++) {
+        const long double h = (long double)e->taps_host[N - 1 - j];
+        long double c = 1.0L, sn_ = 0.0L;
+        if (e->rotate) {
+            const long double tt = ldexpl((long double)e->dphase, -64) * (long double)(N - 1 - j);
+            c = cosl(two_pi * (tt - floorl(tt)));
+            sn_ = sinl(two_pi * (tt - floorl(tt)));
+        }
+        gr[j] = h * c;
+        gi[j] = h * sn_;
+    }
+    std::vector<float2> Hp(F), T(64 * 16 + 4 * 16);
+    for (int k = 0; k < F; k++) {
+        long double re = 0.0L, im = 0.0L;
+        for (int j = 0; j < N; j++) {
+            const int idx = (int)(((long long)j * k) % F);
+            re += gr[j] * cs[idx] + gi[j] * sn[idx];
+            im += gi[j] * cs[idx] - gr[j] * sn[idx];
+        }
+        // bin k = ka + 16 (4 g + s) + 256 kb0 sits with lane (ka << 2) | g, entry 4 s + kb0; tables are entry-major
+        // ([entry][lane]: a wave's load of one entry is 512 contiguous bytes)
+        const int ka = k & 15, kb1 = (k >> 4) & 15, kb0 = k >> 8;
+        Hp[(4 * (kb1 & 3) + kb0) * 64 + ((ka << 2) | (kb1 >> 2))] = make_float2((float)(re / F), (float)(im / F));
+    }
+    for (int l = 0; l < 64; l++)
+        for (int k = 0; k < 16; k++) T[k * 64 + l] = make_float2((float)cs[(l * k) % F], (float)(-sn[(l * k) % F]));
+    for (int j = 0; j < 4; j++)
+        for (int k = 0; k < 16; k++) T[1024 + k * 4 + j] = make_float2((float)cs[(16 * j * k) % F], (float)(-sn[(16 * j * k) % F]));
+    if (!e->d_f1k_H) {
+        HIPCHK(hipMalloc(&e->d_f1k_H, sizeof(float2) * F));
+        if (hipMalloc(&e->d_f1k_T, sizeof(float2) * T.size()) != hipSuccess) {
+            (void)hipFree(e->d_f1k_H);
+            e->d_f1k_H = nullptr;
+            return QDSP_HIP_ENOMEM;
+        }
+        HIPCHK(hipMemcpy(e->d_f1k_T, T.data(), sizeof(float2) * T.size(), hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipDeviceSynchronize());   // (retune / new taps: nothing in flight may still read the old spectrum)
+    HIPCHK(hipMemcpy(e->d_f1k_H, Hp.data(), sizeof(float2) * F, hipMemcpyHostToDevice));
+    e->f1k_ntaps = N;
+    e->f1k_dphase = key_dphase;
+    return 0;
+}
+
+int raw_history(Engine* e, hipStream_t s, const float2** hist, float2** hist_raw_next);
+
+int launch_fft1k(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d_out, hipStream_t s) {
+    int rc = fft1k_prepare(e);
+    if (rc) return rc;
+    qk::FftArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = static_cast<const float2*>(d_in);
+    a.out = static_cast<float2*>(d_out);
+    a.hist = reinterpret_cast<const float2*>(e->d_hist[e->cur]);
+    a.hist_keep = a.hist;
+    a.hist_next = reinterpret_cast<float2*>(e->d_hist[e->cur ^ 1]);
+    rc = raw_history(e, s, &a.hist, &a.hist_raw_next);
+    if (rc) return rc;
+    a.Hf = e->d_f1k_H;
+    a.TA = e->d_f1k_T;
+    a.TB = e->d_f1k_T + 1024;
+    a.count = count;
+    a.nout = nout;
+    a.H = e->H;
+    a.dec = 1;
+    a.rot = e->rotate ? 1 : 0;
+    a.decm = 1;
+    a.ov = e->ntaps - 1;
+    if (e->kind != KIND_FIR) {
+        // resampler / VFO: y[n'] sits at stream position n' M - 1: segments start one sample early
+        a.decm = e->M;
+        a.decm_inv = (e->M >= 2 && (unsigned long long)(e->M + qk::kFft1kN) * (unsigned long long)e->M < (1ULL << 32)) ? (unsigned)((1ULL << 32) / (unsigned)e->M) + 1u : 0u;
+        a.strided = 1;
+        a.m_shift = -1;
+        for (int sh = 0; sh <= 6; sh++)
+            if (e->M == (1 << sh)) a.m_shift = sh;
+        a.seg_shift = a.ov + 1;
+        a.L = qk::kFft1kN - a.ov;
+        a.nblocks = (int)((count + 1 + a.L - 1) / a.L);
+    } else {
+        a.seg_shift = a.ov;
+        a.L = qk::kFft1kN - a.ov;
+        a.nblocks = (int)((count + a.L - 1) / a.L);
+    }
+    a.nwg = a.nblocks;
+    if (a.rot) {
+        a.phase_in0 = e->phase;
+        a.phase0 = e->phase - (unsigned long long)(e->ntaps - 1) * e->dphase;
+        a.dphase = e->dphase;
+        a.gm1 = e->volk_gain ? e->gm1 : 0.0f;
+        if (!e->wtab1k_ok || e->wtab1k_dphase != e->dphase) {
+            for (int i = 0; i < 16; i++) {
+                double c, sn;
+                unit_of_fx(e->dphase, (long double)(64 * i), &c, &sn);
+                e->wtab1k[i] = make_float2((float)c, (float)sn);
+            }
+            e->wtab1k_dphase = e->dphase;
+            e->wtab1k_ok = true;
+        }
+        memcpy(a.wtab, e->wtab1k, sizeof(a.wtab));
+    }
+    rc = qk::launch_fir_fft1k(a, s);
+    if (rc) return rc;
+    e->raw_valid = e->rotate && e->H > 0;   // (the caller flips cur: the raw hand-over then sits at d_hist_raw[cur])
+    e->last.name = "fir_fft1k_kernel";
+    e->last.grid = a.nblocks + (a.H + 63) / 64;
+    e->last.block = 64;
+    e->last.lds = (int)(16 * qk::kFft1kPitch * sizeof(float2));
     return 0;
 }
 
@@ -1162,6 +1328,7 @@ int launch_pfb(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
 
 int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d_out, hipStream_t s) {
     if (pfb_eligible(e, count)) return launch_pfb(e, d_in, count, nout, d_out, s);
+    if (fft1k_eligible(e, count)) return launch_fft1k(e, d_in, count, nout, d_out, s);
     int rc = fft_prepare(e);
     if (rc) return rc;
     qk::FftArgs a;
@@ -1230,12 +1397,24 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
         a.dphase = e->dphase;
         a.gm1 = e->volk_gain ? e->gm1 : 0.0f;
         // one workgroup's step between its units: nwg segments (per-segment kernel), nwg groups of dec segments (grouped)
-        unit_of_fx(e->dphase, (long double)nwg * (long double)a.L * (long double)(grouped ? a.dec : 1), &a.rot_step.x, &a.rot_step.y);
-        for (int n2 = 0; n2 < 16; n2++) {
-            double c, sn;
-            unit_of_fx(e->dphase, (long double)(256 * n2), &c, &sn);
-            a.wtab[n2] = make_float2((float)c, (float)sn);
+        const long double step_mult = (long double)nwg * (long double)a.L * (long double)(grouped ? a.dec : 1);
+        if (!e->rot_step_ok || e->rot_step_dphase != e->dphase || e->rot_step_mult != step_mult) {
+            unit_of_fx(e->dphase, step_mult, &e->rot_step_val.x, &e->rot_step_val.y);
+            e->rot_step_dphase = e->dphase;
+            e->rot_step_mult = step_mult;
+            e->rot_step_ok = true;
         }
+        a.rot_step = e->rot_step_val;
+        if (!e->wtab4k_ok || e->wtab4k_dphase != e->dphase) {
+            for (int n2 = 0; n2 < 16; n2++) {
+                double c, sn;
+                unit_of_fx(e->dphase, (long double)(256 * n2), &c, &sn);
+                e->wtab4k[n2] = make_float2((float)c, (float)sn);
+            }
+            e->wtab4k_dphase = e->dphase;
+            e->wtab4k_ok = true;
+        }
+        memcpy(a.wtab, e->wtab4k, sizeof(a.wtab));
     }
     rc = qk::launch_fir_fft(a, nwg + 1, s);
     if (rc) return rc;
@@ -1315,7 +1494,8 @@ bool fir_lat_eligible(const Engine* e, int64_t count) {
     if (e->ntaps > 1024 || env_int("QDSP_HIP_NO_FIR_LAT", 0)) return false;
     // measured: 2.5 us + 1.7e-7 us per tap and sample (63 / 127 / 256 taps at 65 536 samples: 2.9 / 3.6 / 5.3 us); what it
     // competes with is the overlap-save kernel (~9 us up to 262 144 samples) from 96 taps on, fir_core_kernel (5.7-6.1 us) below
-    const int64_t limit = env_int("QDSP_HIP_FIR_LAT_MAX_WORK", e->ntaps >= 96 ? 1 << 25 : 1 << 24);
+    // -- and, for up to 513 taps, the one-wave-per-segment overlap-save kernel (5.2-5.9 us up to 262 144 samples whatever the taps)
+    const int64_t limit = env_int("QDSP_HIP_FIR_LAT_MAX_WORK", e->ntaps >= 96 && e->ntaps > 513 ? 1 << 25 : 1 << 24);
     return count > 0 && count * (int64_t)e->ntaps <= limit;
 }
 int launch_fir_lat(Engine* e, const void* d_in, int64_t count, void* d_out, hipStream_t s) {

@@ -52,7 +52,7 @@ while time.time() < t_end:
         L, M = 1, 1
         ntaps = int(rng.integers(1, 400))
     elif kind == "dec":
-        L, M = 1, int(rng.choice([2, 3, 5, 8, 9, 12, 14, 16, 17, 24, 31, 32, 33, 50, 64, 100, 127, 128, 130, 200, 256, 300]))
+        L, M = 1, int(rng.choice([1, 2, 3, 4, 5, 8, 9, 12, 14, 16, 17, 24, 31, 32, 33, 50, 64, 100, 127, 128, 130, 200, 256, 300]))
         ntaps = int(rng.integers(1, min(34 * M, 5000)))
     else:
         L = int(rng.choice([2, 3, 5, 7, 10, 12, 16, 33, 48, 64, 100, 147, 160, 192, 200]))
@@ -62,8 +62,10 @@ while time.time() < t_end:
         ntaps = int(rng.integers(L, 40 * L))
     vfo = bool(rng.integers(0, 2)) and kind != "fir"
     lift = bool(rng.integers(0, 2))
-    for k in ("QDSP_HIP_MF_MIN_COUNT", "QDSP_HIP_RM_MIN_COUNT", "QDSP_HIP_RM_MIN_INTERP"):
+    for k in ("QDSP_HIP_MF_MIN_COUNT", "QDSP_HIP_RM_MIN_COUNT", "QDSP_HIP_RM_MIN_INTERP", "QDSP_HIP_NO_FFT1K"):
         os.environ.pop(k, None)
+    if rng.integers(0, 3) == 0:
+        os.environ["QDSP_HIP_NO_FFT1K"] = "1"     # (the 4096-point overlap-save kernels on the calls the one-wave form takes by default)
     if lift:
         os.environ["QDSP_HIP_MF_MIN_COUNT"] = "0"
         os.environ["QDSP_HIP_RM_MIN_COUNT"] = "0"

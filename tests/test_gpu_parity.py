@@ -1546,3 +1546,120 @@ def test_bench_size_cross_checks(ops, gold, monkeypatch):
         yo = one.process(x)
         assert (yc[c] - yo).abs().max().item() < 4e-5 * yo.abs().max().item(), c
     torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------------------ overlap-save on one-wave 1024-point segments
+def _fft1k_case(ops, kind, taps, M, inc=None):
+    if kind == "fir":
+        return ops.Fir(taps), O.Fir(taps, acc=O.ACC_F64), None
+    if kind == "dec":
+        return ops.Resampler(taps, 1, M), O.Resampler(taps, 1, M, acc=O.ACC_F64), None
+    return ops.Vfo(taps, 1, M, inc), O.Resampler(taps, 1, M, acc=O.ACC_F64), O.Xlator(1.0, 0.1234, exact=True, volk_gain=True)
+
+
+@pytest.mark.default_dispatch
+@pytest.mark.parametrize("kind,M", [("fir", 1), ("dec", 1), ("dec", 2), ("dec", 3), ("dec", 8), ("dec", 64), ("vfo", 1), ("vfo", 4), ("vfo", 5), ("vfo", 8)])
+@pytest.mark.parametrize("ntaps", [24, 97, 255, 256, 257, 401, 513])
+def test_fft1k_small_calls_vs_oracle(ops, kind, M, ntaps):
+    """fir_fft1k_kernel under the default dispatch: FIR<complex_t>, PolyphaseResampler (interp 1, any decimation through the
+    strided store; powers of two up to 64 through the all-or-none lane path) and the fused VFO on reference-sized calls,
+    ragged sequences whose small members go to other kernel families mid-stream (state hand-over both ways), against
+    the FP64 oracle run over the same block sequence (the resampler's per-call phase restart included)."""
+    rng = np.random.default_rng(7000 + 13 * ntaps + M)
+    taps = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    inc = ops.phase_delta(1.0, 0.1234)
+    op, o, xl = _fft1k_case(ops, kind, taps, M, inc)
+    n = 420_000
+    x = O.synth_iq(0, n, seed=ntaps + M)
+    cuts = [0, 131_072 + 7, 131_072 + 7 + 1000, 131_072 + 7 + 1000 + 70_001, 131_072 + 7 + 1000 + 70_001 + 16_384, n]
+    ys, ws, names = [], [], []
+    for a, b in zip(cuts, cuts[1:]):
+        ys.append(np.array(op.process(x[a:b])))
+        names.append(op.last_kernel()["name"])
+        blk = xl.process(x[a:b]) if xl else x[a:b]
+        ws.append(o.process(blk))
+    y, w = np.concatenate(ys), np.concatenate(ws)
+    assert len(y) == len(w)
+    assert rel_rms(y, w) < TOL_FFT
+    assert np.abs(y - w).max() < 2e-5 * np.abs(w).max()
+    # which calls the 1024-point form takes: from 2^14 samples on, wherever the overlap-save path is AUTO's choice
+    # (FIR from 24 taps; decimators and the VFO where neither the short-filter nor the large-decimation direct kernels win)
+    if kind == "fir":
+        # (the latency-arranged direct form keeps the calls of up to 2^24 tap-samples: bit-exact, and quicker there)
+        want = ["fir_lat_kernel" if (b - a) * ntaps <= 1 << 24 else "fir_fft1k_kernel" for a, b in zip(cuts, cuts[1:])]
+        assert names == want, (names, want)
+        assert "fir_fft1k_kernel" in names or ntaps < 97
+    if kind != "fir" and ntaps >= 255 and M <= 8:
+        assert names[0] == "fir_fft1k_kernel" and names[2] == "fir_fft1k_kernel", names
+    # per-block windows right after each hand-over: a wrong history is an O(1) error there
+    pos = 0
+    for yb, wb in zip(ys, ws):
+        k = min(len(wb), 64)
+        if k:
+            assert rel_rms(yb[:k], wb[:k]) < 1e-5, (names, pos)
+        pos += len(wb)
+
+
+@pytest.mark.default_dispatch
+def test_fft1k_thresholds_and_exclusions(ops, gold, monkeypatch):
+    """Where the one-wave form stops: above its measured call-size limits the 4096-point kernels run, real-valued data
+    and filters past 513 taps never take it, QDSP_HIP_NO_FFT1K and the explicit FFT / DIRECT modes switch it off."""
+    import torch
+
+    taps = gold["taps256"]
+    x = ops.synth_iq(5 << 20, seed=3)
+    out = torch.empty(5 << 20, dtype=torch.complex64, device="cuda")
+    f = ops.Fir(taps, max_block=0)
+    for n, want in ((1 << 14, "fir_lat_kernel"), (1 << 17, "fir_fft1k_kernel"), (1_000_000, "fir_fft1k_kernel"), (4 << 20, "fir_fft1k_kernel"), (5 << 20, "fir_fft_kernel")):
+        f.process(x[:n], out[:n])
+        assert f.last_kernel()["name"] == want, (n, f.last_kernel())
+    f.set_mode(f.FFT)
+    f.process(x[:1_000_000], out[:1_000_000])
+    assert f.last_kernel()["name"] == "fir_fft_kernel"
+    f.set_mode(f.DIRECT)
+    f.process(x[:1_000_000], out[:1_000_000])
+    assert f.last_kernel()["name"] == "fir_core_kernel"
+    f.close()
+    d = ops.Resampler(taps, 1, 8, max_block=0)
+    for n, want in ((1_000_000, "fir_fft1k_kernel"), (3 << 20, "fir_fft1k_kernel"), (4 << 20, "fir_fft_kernel")):
+        d.process(x[:n], out[:n])
+        assert d.last_kernel()["name"] == want, (n, d.last_kernel())
+    d.close()
+    long_taps = np.resize(taps, 600).astype(np.float32)
+    g = ops.Fir(long_taps, max_block=0)
+    g.process(x[:1_000_000], out[:1_000_000])
+    assert g.last_kernel()["name"] == "fir_fft_kernel"
+    g.close()
+    r = ops.Fir(taps, complex_data=False, max_block=0)
+    r.process(torch.zeros(1_000_000, dtype=torch.float32, device="cuda"))
+    assert r.last_kernel()["name"] == "fir_fft_kernel"
+    r.close()
+    monkeypatch.setenv("QDSP_HIP_NO_FFT1K", "1")
+    h = ops.Fir(taps, max_block=0)
+    h.process(x[:1_000_000], out[:1_000_000])
+    assert h.last_kernel()["name"] == "fir_fft_kernel"
+    h.close()
+
+
+@pytest.mark.default_dispatch
+def test_fft1k_vfo_retune_and_ideal_nco(ops, gold):
+    """The fused VFO on the one-wave form: a retune between calls rebuilds the spectrum (the mixer is folded into the taps),
+    and the ideal-NCO setting (no VOLK magnitude sawtooth) matches the oracle's."""
+    taps = gold["taps256"]
+    n = 200_000
+    x = O.synth_iq(0, 3 * n, seed=99)
+    for vg in (True, False):
+        v = ops.Vfo(taps, 1, 8, ops.phase_delta(1.0, 0.1234))
+        v.set_volk_gain(vg)
+        xl = O.Xlator(1.0, 0.1234, exact=True, volk_gain=vg)
+        rs = O.Resampler(taps, 1, 8, acc=O.ACC_F64)
+        ys, ws = [], []
+        for k in range(3):
+            if k == 1:
+                v.set_phase_inc(*ops.phase_delta(1.0, -0.31))
+                O.lib().oracle_xlator_phase_delta(1.0, -0.31, O._fp(xl.delta))
+            blk = x[k * n:(k + 1) * n]
+            ys.append(np.array(v.process(blk)))
+            assert v.last_kernel()["name"] == "fir_fft1k_kernel"
+            ws.append(rs.process(xl.process(blk)))
+        assert rel_rms(np.concatenate(ys), np.concatenate(ws)) < TOL_FFT
