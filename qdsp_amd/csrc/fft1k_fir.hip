@@ -19,6 +19,15 @@
 //   ... and the same road back (conjugate twiddles), so no bit-reversal pass exists: Hf is stored in the order
 //   pass C leaves the spectrum in.  Row pitch 84 (= 4 mod 16) makes all four access patterns conflict-free for
 //   8-byte LDS accesses (16 lanes per phase, 32 banks).
+// Tried for the chip-filling calls and rejected (2^27 samples, 256 taps, same box and run): the same segments as
+// persistent workgroups of 12 waves (3 per SIMD), the three tables in LDS once per workgroup, the next segment's loads
+// in flight behind the current transform, each XCD on a contiguous eighth of every round of segments so that the
+// overlap is re-read from its L2 (FETCH_SIZE x 1.09 of the algorithmic bytes: it is): 535-545 us against 464-470 us for
+// fir_fft_kernel<1>.  Counters: 688 VALU instructions per segment (0.63x the 4096-point kernel's per output) = 223 us of
+// issue, LDS busy 253 us per CU (88 KB of transposes + table reads per segment), 2.26 GB of HBM traffic, waves waiting
+// 44 % of their cycles -- three half-used resources that three waves per SIMD do not overlap; with the tables in
+// registers instead (2 waves per SIMD, no prefetch) the same 535 us.  At 63 taps (94 % new points) it reaches 455 us
+// against 464: not worth a second kernel.
 // Same operator, state and semantics as fir_fft_kernel<1, ROT> (FIR, any-decimation resampler through the
 // strided store, fused VFO); built with -fno-slp-vectorize like the other FFT translation units.
 #include "fft_fir.hip.h"
@@ -60,46 +69,38 @@ __device__ __forceinline__ float2 fx_phasor_f32(unsigned long long ph) {
     return (qi & 2) ? make_float2(-c, -s2) : make_float2(c, s2);
 }
 
+// ---- the pieces both kernels are made of -------------------------------------------------------------------
+
+// history hand-over (filter.h:71 / resampling.h:129): element i of the last H samples of hist ++ in
 template <bool ROT>
-__global__ __launch_bounds__(64) void fir_fft1k_kernel(const FftArgs a) {
-    __shared__ __attribute__((aligned(16))) float2 lds[16 * kF1P];
-    const int l = threadIdx.x;
+__device__ __forceinline__ void f1k_hand_over(const FftArgs& a, int i) {
     const int H = a.H;
-    const int nh = (H + 63) >> 6;
-    if ((int)blockIdx.x < nh) {
-        // history hand-over (filter.h:71 / resampling.h:129): last H samples of hist ++ in, one element per lane of
-        // ceil(H / 64) extra workgroups -- the FIRST ones of the grid: with the NCO each element costs an FP64 sincos,
-        // which would be the tail of the launch if these started last
-        const int i = (int)blockIdx.x * 64 + l;
-        if (i < H) {
-            const long long g = a.count - H + i;
-            float2 v;
-            if (g < 0) {
-                v = a.hist_keep[g + H];
-                if (ROT && a.hist_raw_next) a.hist_raw_next[i] = a.hist[g + H];
-            } else {
-                v = a.in[g];
-                if (ROT) {
-                    const double2 p = fx_phasor(a.phase_in0 + (unsigned long long)g * a.dphase);
-                    const float gain = fmaf((float)(int)(g & 511), a.gm1, 1.0f);
-                    if (a.hist_raw_next) a.hist_raw_next[i] = make_float2(v.x * gain, v.y * gain);
-                    v = cmulc<false>(v, make_float2((float)p.x * gain, (float)p.y * gain));
-                }
-            }
-            a.hist_next[i] = v;
+    if (i >= H) return;
+    const long long g = a.count - H + i;
+    float2 v;
+    if (g < 0) {
+        v = a.hist_keep[g + H];
+        if (ROT && a.hist_raw_next) a.hist_raw_next[i] = a.hist[g + H];
+    } else {
+        v = a.in[g];
+        if (ROT) {
+            const double2 p = fx_phasor(a.phase_in0 + (unsigned long long)g * a.dphase);
+            const float gain = fmaf((float)(int)(g & 511), a.gm1, 1.0f);
+            if (a.hist_raw_next) a.hist_raw_next[i] = make_float2(v.x * gain, v.y * gain);
+            v = cmulc<false>(v, make_float2((float)p.x * gain, (float)p.y * gain));
         }
-        return;
     }
-    const int b = (int)blockIdx.x - nh;
-    const long long seg0 = (long long)b * a.L - a.seg_shift;   // stream position of element 0
-    const bool interior = seg0 >= 0 && seg0 + kFft1kN <= a.count;
-    v2f* ldv = reinterpret_cast<v2f*>(lds);
-    v2f v[16];
-    if (interior) {
+    a.hist_next[i] = v;
+}
+
+// the lane's 16 elements 64 i + l of the segment whose element 0 is stream position seg0
+__device__ __forceinline__ void f1k_load(const FftArgs& a, long long seg0, int l, v2f (&v)[16]) {
+    if (seg0 >= 0 && seg0 + kFft1kN <= a.count) {
         const float2* __restrict__ p = a.in + seg0 + l;
 #pragma unroll
-        for (int i = 0; i < 16; i++) { const v2f x = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(p + 64 * i)); v[i] = x; }
+        for (int i = 0; i < 16; i++) { const float2 x = p[64 * i]; v[i] = mk2(x.x, x.y); }   // (plain loads: the overlap with the neighbouring segment is meant to hit in L2)
     } else {
+        const int H = a.H;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             const long long g = seg0 + 64 * i + l;
@@ -109,48 +110,42 @@ __global__ __launch_bounds__(64) void fir_fft1k_kernel(const FftArgs a) {
             v[i] = mk2(x.x, x.y);
         }
     }
-    // per-lane constants (L1/L2-resident tables, the same for every wave)
-    const int kq = l >> 2, j = l & 3;
-    v2f ta[16], tb[16], hf[16];
+}
+
+// VOLK's magnitude sawtooth 1 + (g mod 512) gm1 on the INPUT samples (history carries its own); g = seg0 + 64 i + l:
+// elements i and i + 8 share their gain
+__device__ __forceinline__ void f1k_gain(const FftArgs& a, long long seg0, int l, v2f (&v)[16]) {
+    if (a.gm1 == 0.0f) return;
+    if (seg0 >= 0) {
+        const int base = (int)((seg0 + l) & 511);
 #pragma unroll
-    for (int k = 0; k < 16; k++) { const float2 t = a.TA[k * 64 + l]; ta[k] = mk2(t.x, t.y); }
+        for (int i = 0; i < 8; i++) {
+            const float gg = fmaf((float)((base + 64 * i) & 511), a.gm1, 1.0f);
+            v[i] = v[i] * mk2(gg, gg);
+            v[i + 8] = v[i + 8] * mk2(gg, gg);
+        }
+    } else {
 #pragma unroll
-    for (int k = 0; k < 16; k++) { const float2 t = a.TB[k * 4 + j]; tb[k] = mk2(t.x, t.y); }
-#pragma unroll
-    for (int k = 0; k < 16; k++) { const float2 t = a.Hf[k * 64 + l]; hf[k] = mk2(t.x, t.y); }
-    v2f q = mk2(1.0f, 0.0f);
-    if (ROT) {
-        // outputs at position p = seg0 + 64 i + l get exp(j (phase0 + p dphase)) = q * wtab[i]
-        const float2 pq = fx_phasor_f32(a.phase0 + (unsigned long long)(seg0 + l) * a.dphase);
-        q = mk2(pq.x, pq.y);
-        if (a.gm1 != 0.0f) {
-            // VOLK's magnitude sawtooth 1 + (g mod 512) gm1 stays on the INPUT samples (history carries its own);
-            // g = seg0 + 64 i + l: elements i and i + 8 share their gain
-            if (seg0 >= 0) {
-                const int base = (int)((seg0 + l) & 511);
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const float gg = fmaf((float)((base + 64 * i) & 511), a.gm1, 1.0f);
-                    v[i] = v[i] * mk2(gg, gg);
-                    v[i + 8] = v[i + 8] * mk2(gg, gg);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const long long g = seg0 + 64 * i + l;
-                    const float gg = g >= 0 ? fmaf((float)(int)(g & 511), a.gm1, 1.0f) : 1.0f;
-                    v[i] = v[i] * mk2(gg, gg);
-                }
-            }
+        for (int i = 0; i < 16; i++) {
+            const long long g = seg0 + 64 * i + l;
+            const float gg = g >= 0 ? fmaf((float)(int)(g & 511), a.gm1, 1.0f) : 1.0f;
+            v[i] = v[i] * mk2(gg, gg);
         }
     }
-    // All complex arithmetic is packed FP32 (cpk.hip.h): at one or two waves per SIMD -- all a reference-sized call
-    // puts there -- the 64-bit register pairs cost nothing and the halved issue count is the whole kernel time.
+}
+
+// 1024-point transform, spectrum product, inverse: v[i] = element 64 i + l in, filtered element 64 i + l at
+// v[rev16(i)] out.  ta(k) / tb(k) / hf(k): the lane's table entries (registers or LDS).  All complex arithmetic is
+// packed FP32 (cpk.hip.h): at the one to three waves per SIMD these kernels run at, the 64-bit register pairs cost
+// nothing and the halved issue count is kernel time.
+template <class TA, class TB, class HF>
+__device__ __forceinline__ void f1k_transform(v2f (&v)[16], v2f* ldv, int l, TA ta, TB tb, HF hf) {
+    const int kq = l >> 2, j = l & 3;
+    v2f* rowq = ldv + kq * kF1P;
     // ---- pass A (over i) + twiddle W1024^(l ka) ------------------------------------------------
     pk_fft16<false>(v);
 #pragma unroll
-    for (int k = 0; k < 16; k++) ldv[k * kF1P + l] = (k == 0) ? v[rev16(0)] : pk_cmulc<false>(v[rev16(k)], ta[k]);
-    v2f* rowq = ldv + kq * kF1P;
+    for (int k = 0; k < 16; k++) ldv[k * kF1P + l] = (k == 0) ? v[rev16(0)] : pk_cmulc<false>(v[rev16(k)], ta(k));
     wave_sync();
 #pragma unroll
     for (int m = 0; m < 16; m++) v[m] = rowq[j + 4 * m];
@@ -159,7 +154,7 @@ __global__ __launch_bounds__(64) void fir_fft1k_kernel(const FftArgs a) {
     pk_fft16<false>(v);
 #pragma unroll
     for (int k = 0; k < 16; k++)
-        rowq[5 * j + (k >> 2) + 20 * (k & 3)] = (k == 0) ? v[rev16(0)] : pk_cmulc<false>(v[rev16(k)], tb[k]);
+        rowq[5 * j + (k >> 2) + 20 * (k & 3)] = (k == 0) ? v[rev16(0)] : pk_cmulc<false>(v[rev16(k)], tb(k));
     // ---- pass C (over j), spectrum product, pass C' --------------------------------------------
     // lane (kq, g = j): entry s*4 + kb0 <-> bin kq + 16 (4 g + s) + 256 kb0
     wave_sync();
@@ -172,7 +167,7 @@ __global__ __launch_bounds__(64) void fir_fft1k_kernel(const FftArgs a) {
     for (int s = 0; s < 4; s++) {
         pk_fft4<false>(v[4 * s], v[4 * s + 1], v[4 * s + 2], v[4 * s + 3]);
 #pragma unroll
-        for (int k0 = 0; k0 < 4; k0++) v[4 * s + k0] = pk_cmulc<false>(v[4 * s + k0], hf[4 * s + k0]);
+        for (int k0 = 0; k0 < 4; k0++) v[4 * s + k0] = pk_cmulc<false>(v[4 * s + k0], hf(4 * s + k0));
         pk_fft4<true>(v[4 * s], v[4 * s + 1], v[4 * s + 2], v[4 * s + 3]);
     }
     wave_sync();
@@ -186,7 +181,7 @@ __global__ __launch_bounds__(64) void fir_fft1k_kernel(const FftArgs a) {
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         const v2f e = rowq[5 * j + (k >> 2) + 20 * (k & 3)];
-        v[k] = (k == 0) ? e : pk_cmulc<true>(e, tb[k]);
+        v[k] = (k == 0) ? e : pk_cmulc<true>(e, tb(k));
     }
     pk_fft16<true>(v);
     wave_sync();
@@ -197,11 +192,15 @@ __global__ __launch_bounds__(64) void fir_fft1k_kernel(const FftArgs a) {
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         const v2f e = ldv[k * kF1P + l];
-        v[k] = (k == 0) ? e : pk_cmulc<true>(e, ta[k]);
+        v[k] = (k == 0) ? e : pk_cmulc<true>(e, ta(k));
     }
     pk_fft16<true>(v);
+}
+
+// store the valid outputs: element 64 i + l >= ov (at v[rev16(i)]), stream position seg0 + 64 i + l
+template <bool ROT>
+__device__ __forceinline__ void f1k_store(const FftArgs& a, long long seg0, int l, v2f (&v)[16], v2f q) {
     if (ROT) asm volatile("" : "+v"(q) : "v"(v[0]));   // the 16 output phasors q * wtab[i] are formed HERE, not hoisted above the transform (32 live VGPRs)
-    // ---- store the valid outputs: element 64 i + l >= ov, stream position seg0 + 64 i + l -------
     auto rot_out = [&](int i, v2f y) {
         if (ROT) y = pk_cmulc<false>(y, (i == 0) ? q : pk_cmulc<false>(q, mk2(a.wtab[i].x, a.wtab[i].y)));
         return make_float2(y.x, y.y);
@@ -236,7 +235,7 @@ __global__ __launch_bounds__(64) void fir_fft1k_kernel(const FftArgs a) {
                 if (el >= a.ov && x - qq * (unsigned)a.decm == 0 && n >= 0 && n < a.nout) a.out[n] = rot_out(i, v[rev16(i)]);
             }
         }
-    } else if (interior && seg0 + kFft1kN <= a.nout) {
+    } else if (seg0 >= 0 && seg0 + kFft1kN <= a.count && seg0 + kFft1kN <= a.nout) {
         float2* __restrict__ o = a.out + seg0 + l;
 #pragma unroll
         for (int i = 0; i < 16; i++)
@@ -248,6 +247,42 @@ __global__ __launch_bounds__(64) void fir_fft1k_kernel(const FftArgs a) {
             if (64 * i + l >= a.ov && n < a.nout) a.out[n] = rot_out(i, v[rev16(i)]);
         }
     }
+}
+
+// ---- reference-sized calls: one workgroup = one wave = one segment ----------------------------------------------
+template <bool ROT>
+__global__ __launch_bounds__(64) void fir_fft1k_kernel(const FftArgs a) {
+    __shared__ __attribute__((aligned(16))) float2 lds[16 * kF1P];
+    const int l = threadIdx.x;
+    const int nh = (a.H + 63) >> 6;
+    if ((int)blockIdx.x < nh) {
+        // the hand-over runs in ceil(H / 64) extra workgroups, the FIRST ones of the grid: with the NCO each element costs
+        // an FP64 sincos, which would be the tail of the launch if these started last
+        f1k_hand_over<ROT>(a, (int)blockIdx.x * 64 + l);
+        return;
+    }
+    const int b = (int)blockIdx.x - nh;
+    const long long seg0 = (long long)b * a.L - a.seg_shift;   // stream position of element 0
+    v2f v[16];
+    f1k_load(a, seg0, l, v);
+    // per-lane constants (L1/L2-resident tables, the same for every wave)
+    const int j = l & 3;
+    v2f ta[16], tb[16], hf[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { const float2 t = a.TA[k * 64 + l]; ta[k] = mk2(t.x, t.y); }
+#pragma unroll
+    for (int k = 0; k < 16; k++) { const float2 t = a.TB[k * 4 + j]; tb[k] = mk2(t.x, t.y); }
+#pragma unroll
+    for (int k = 0; k < 16; k++) { const float2 t = a.Hf[k * 64 + l]; hf[k] = mk2(t.x, t.y); }
+    v2f q = mk2(1.0f, 0.0f);
+    if (ROT) {
+        // outputs at position p = seg0 + 64 i + l get exp(j (phase0 + p dphase)) = q * wtab[i]
+        const float2 pq = fx_phasor_f32(a.phase0 + (unsigned long long)(seg0 + l) * a.dphase);
+        q = mk2(pq.x, pq.y);
+        f1k_gain(a, seg0, l, v);
+    }
+    f1k_transform(v, reinterpret_cast<v2f*>(lds), l, [&](int k) { return ta[k]; }, [&](int k) { return tb[k]; }, [&](int k) { return hf[k]; });
+    f1k_store<ROT>(a, seg0, l, v, q);
 }
 
 int launch_fir_fft1k(const FftArgs& a, hipStream_t stream) {
