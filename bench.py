@@ -28,6 +28,9 @@ Rank 0 prints ONE JSON line (contract in the task statement) extended with
                   launch duration (HIP events on the launch stream, measured here)
   "roofline_fp32": the same launch vs the FP32 vector peak (the direct-form 256-tap FIR is
                   compute-bound: 1024 FLOP / 16 B per sample)
+  "block_call":   N = 1 only: per-call time of the same operator on ONE reference-sized block (1e6 samples, the most the
+                  reference's stream API hands over per call, stream.h:7), 200 back-to-back calls -- latency-bound, not
+                  part of `value`.
   "chain":        default run only: the fused xlating-FIR + decimate-by-8 chain (BASELINE configs[2]) timed by the same
                   protocol right behind the FIR, with its own roofline object
   "cpu_baseline": the CPU oracle timed on this host's cores, N = 1 only: scalar VOLK-generic order on all worker
@@ -469,6 +472,28 @@ def run_workload(name: str, args, ctx) -> dict:
     return res
 
 
+def block_call(name: str, ctx) -> dict:
+    """One reference-sized call: the block API the operators sit behind hands over at most 1e6 samples per call
+    (src/dsp/stream.h:7).  200 back-to-back calls on device buffers, HIP events on the operator's stream."""
+    import torch
+
+    from qdsp_amd import ops
+
+    w = WORKLOADS[name]
+    n = 1_000_000
+    n -= n % (w["decim"] if w.get("interp", 1) > 1 else 1)
+    op = make_op(ops, name, ctx["local_rank"])
+    x = ops.synth_iq(n, seed=4321, device=ctx["local_rank"])
+    nout = n // w["decim"] * w.get("interp", 1)
+    out = torch.empty((w["nchan"], nout) if name in ("chan64", "chan64m8") else nout + 8, dtype=torch.complex64, device=ctx["dev"])
+    op.process(x, out)
+    torch.cuda.synchronize()
+    ms = min(op.time_dev(x, out, 200) for _ in range(3))
+    kernel = op.last_kernel()["name"]
+    op.close()
+    return {"samples": n, "us_per_call": round(ms * 1e3, 2), "msps": round(n / ms / 1e3, 1), "kernel": kernel}
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -537,6 +562,11 @@ def main():
                              "steps": args.steps, "warmup": args.warmup, "config": chain["config"],
                              "roofline": chain["roofline"], "hbm_roofline_msps": chain["hbm_roofline_msps"],
                              "frac_of_hbm_roofline_msps": chain["frac_of_hbm_roofline_msps"]}
+        if world == 1:
+            # what a block of the reference's graph gets per call (latency-bound: DESIGN.md "Reference-sized calls")
+            line["block_call"] = block_call(args.workload, ctx)
+            if chain is not None:
+                line["chain"]["block_call"] = block_call("xlate_fir_decim8", ctx)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
         print(json.dumps(line), flush=True)
