@@ -208,6 +208,27 @@ void unit_of_fx(unsigned long long ph, long double mult, double* c, double* s) {
     *s = (double)sinl(two_pi * t);
 }
 
+// The same for the per-call NCO constants that only depend on the increment (step phasors, per-lane / per-row tables in
+// the kernel arguments): memoised per thread -- a block's worker thread launches for one handle -- because at
+// reference-sized calls 10-30 long-double sincos per call (1.5-4 us of host time) are as long as the kernel itself.
+// 128 direct-mapped entries keyed by (increment, integer multiple); a retune simply misses.
+void unit_of_fx_c(unsigned long long ph, long double mult, double* c, double* s) {
+    struct Memo { unsigned long long ph; long long m; double c, s; bool ok; };
+    static thread_local Memo memo[128];
+    const long long m = (long long)mult;
+    if ((long double)m != mult) { unit_of_fx(ph, mult, c, s); return; }
+    const unsigned idx = (unsigned)(((ph * 0x9E3779B97F4A7C15ULL) ^ ((unsigned long long)m * 0xC2B2AE3D27D4EB4FULL)) >> 57);
+    Memo& e = memo[idx];
+    if (!(e.ok && e.ph == ph && e.m == m)) {
+        unit_of_fx(ph, mult, &e.c, &e.s);
+        e.ph = ph;
+        e.m = m;
+        e.ok = true;
+    }
+    *c = e.c;
+    *s = e.s;
+}
+
 int64_t out_size(const Engine* e, int64_t count) {
     if (!e->has_filter) return count;
     return (count * e->L) / e->M;  // calcOutSize, resampling.h:95-97 (L = M = 1 for FIR)
@@ -568,11 +589,11 @@ void destroy(Engine* e) {
 // ---- launches --------------------------------------------------------------------------
 
 template <class ARGS> void fill_stage_rot(ARGS& a, int NT) {
-    unit_of_fx(a.dphase, (long double)NT, &a.rot_nt.x, &a.rot_nt.y);
-    unit_of_fx(a.dphase, (long double)(8 * NT), &a.rot_8nt.x, &a.rot_8nt.y);
+    unit_of_fx_c(a.dphase, (long double)NT, &a.rot_nt.x, &a.rot_nt.y);
+    unit_of_fx_c(a.dphase, (long double)(8 * NT), &a.rot_8nt.x, &a.rot_8nt.y);
     for (int k = 0; k < 8; k++) {
         double c, sn;
-        unit_of_fx(a.dphase, (long double)(k * NT), &c, &sn);
+        unit_of_fx_c(a.dphase, (long double)(k * NT), &c, &sn);
         a.rot_k[k] = make_float2((float)c, (float)sn);
     }
 }
@@ -585,9 +606,9 @@ int nco_tables(Engine* e, long long S, int NT, int na, const double2** tab) {
     }
     if (na < 64) na = 64;
     std::vector<double2> h((size_t)256 + na + NT);
-    for (int b = 0; b < 256; b++) unit_of_fx(e->dphase, (long double)b * (long double)S, &h[b].x, &h[b].y);
-    for (int a2 = 0; a2 < na; a2++) unit_of_fx(e->dphase, 256.0L * (long double)a2 * (long double)S, &h[256 + a2].x, &h[256 + a2].y);
-    for (int t = 0; t < NT; t++) unit_of_fx(e->dphase, (long double)t, &h[256 + na + t].x, &h[256 + na + t].y);
+    for (int b = 0; b < 256; b++) unit_of_fx_c(e->dphase, (long double)b * (long double)S, &h[b].x, &h[b].y);
+    for (int a2 = 0; a2 < na; a2++) unit_of_fx_c(e->dphase, 256.0L * (long double)a2 * (long double)S, &h[256 + a2].x, &h[256 + a2].y);
+    for (int t = 0; t < NT; t++) unit_of_fx_c(e->dphase, (long double)t, &h[256 + na + t].x, &h[256 + na + t].y);
     HIPCHK(hipDeviceSynchronize());       // (rare: nothing in flight may still read the old tables)
     if (e->d_nco_tab) HIPCHK(hipFree(e->d_nco_tab));
     e->d_nco_tab = nullptr;
@@ -639,8 +660,8 @@ int launch_core_t(Engine* e, qk::CoreArgs& a, hipStream_t s) {
     a.vec = ((uintptr_t)a.in & 15) == 0;
     if (ROT) {
         { int rcn = fill_stage_rot(e, a, NT, (long long)TILE * a.M, -(long long)a.H, a.nblocks); if (rcn) return rcn; }
-        unit_of_fx(a.dphase, 1.0L, &a.rot_one.x, &a.rot_one.y);
-        unit_of_fx(a.dphase, (long double)(2 * NT), &a.rot_2nt.x, &a.rot_2nt.y);
+        unit_of_fx_c(a.dphase, 1.0L, &a.rot_one.x, &a.rot_one.y);
+        unit_of_fx_c(a.dphase, (long double)(2 * NT), &a.rot_2nt.x, &a.rot_2nt.y);
     }
     hipLaunchKernelGGL((qk::fir_core_kernel<CH, R, NT, ROT, MT>), dim3(a.nblocks + 1), dim3(NT), lds, s, a);
     HIPCHK(hipGetLastError());
@@ -783,7 +804,7 @@ template <int CH, bool ROT> int launch_lm(Engine* e, const void* d_in, int64_t c
 // Tile plan of resamp_any_kernel: phase-table pitch and bytes in LDS (0: table stays in memory), padded layout,
 // outputs per tile (0: the taps of one phase do not fit) and the LDS elements a tile stages.
 struct AnyPlan { int Pp, tap_bytes; bool pad; long long tile, span; int ks_lanes, ks_shift, ks_chunk; };
-AnyPlan any_plan(int L, int M, int P, int ch) {
+AnyPlan any_plan(int L, int M, int P, int ch, long long nout = -1) {
     constexpr int NT = 256;
     AnyPlan p;
     // the phase table rides in LDS when it leaves at least half of the budget to the samples
@@ -809,6 +830,12 @@ AnyPlan any_plan(int L, int M, int P, int ch) {
     const bool ks_ok = L == 1 && P >= 64 && env_int("QDSP_HIP_ANY_NO_SPLIT", 0) == 0;
     auto need = [&](long long t) { return span_of(t) + ((ks_ok && t <= kSplitTile) ? NT : 0); };
     while (tile > 1 && need(tile) > max_elems) tile /= 2;
+    // reference-sized calls (nout known): 2048 outputs per tile leave a 1e6-sample block of a 24/125 audio resampler on 94
+    // workgroups and a 16 384-sample one on 2 (10.3 us per call whatever the size); one to four outputs per lane spread it
+    if (nout >= 0) {
+        const long long want = env_int("QDSP_HIP_ANY_SMALL_CALL_TILES", 512);   // (256 .. 4096 measured: 147/160 at 1e6 samples 9.5 / 9.1 / 10.0 / 11.2 us)
+        while (tile > NT && (nout + tile - 1) / tile < want) tile /= 2;
+    }
     // a half-workgroup tile with a long tap loop: the quarter tile with four lanes per output is faster (M = 50,
     // 401 taps: 0.24 -> 0.17 ms) unless it stages too little per lane (M = 32: 9 samples in batches of 8)
     if (ks_ok && tile == 2 * kSplitTile && P >= env_int("QDSP_HIP_ANY_SPLIT_MIN_TAPS", 192) && M >= 40) tile = kSplitTile;
@@ -825,9 +852,9 @@ AnyPlan any_plan(int L, int M, int P, int ch) {
 
 // Tile geometry of resamp_any_kernel into `a` (a.L / a.M / a.P / a.nout set by the caller); returns the dynamic LDS
 // bytes, 0 if the taps of one phase do not fit.
-size_t fill_any_geometry(qk::AnyArgs& a, int ch, bool* lt, bool* pad) {
+size_t fill_any_geometry(qk::AnyArgs& a, int ch, bool* lt, bool* pad, int nchan = 1) {
     constexpr int NT = 256;
-    const AnyPlan pl = any_plan(a.L, a.M, a.P, ch);
+    const AnyPlan pl = any_plan(a.L, a.M, a.P, ch, a.nout * nchan);   // (a batch launch runs nchan x nblocks tiles)
     if (pl.tile == 0) return 0;  // taps per phase beyond LDS
     *lt = pl.tap_bytes != 0;
     *pad = pl.pad;
@@ -957,7 +984,9 @@ bool fft_eligible(const Engine* e, int64_t count) {
         min_taps = env_int("QDSP_HIP_FFT_MIN_TAPS_DECIM", dflt);
     }
     // (below 2^16 samples a 4096-point segment per workgroup leaves most of the chip idle; one-wave segments go down to 2^14)
-    return e->ntaps >= min_taps && count >= env_int("QDSP_HIP_FFT_MIN_COUNT", fft1k_eligible(e, count) ? 1 << 14 : 1 << 16);
+    // (... and further where the alternative is fir_core_kernel on a long filter: 256-400 taps at decimation 3 / 8, 2048-16 000
+    // samples: 10-13 us against 5.6-5.9; the FIR itself has fir_lat_kernel there)
+    return e->ntaps >= min_taps && count >= env_int("QDSP_HIP_FFT_MIN_COUNT", fft1k_eligible(e, count) ? (e->kind == KIND_FIR ? 1 << 14 : 64) : 1 << 16);
 }
 
 int fft_prepare(Engine* e) {
@@ -1144,7 +1173,7 @@ int launch_fft1k(Engine* e, const void* d_in, int64_t count, int64_t nout, void*
         if (!e->wtab1k_ok || e->wtab1k_dphase != e->dphase) {
             for (int i = 0; i < 16; i++) {
                 double c, sn;
-                unit_of_fx(e->dphase, (long double)(64 * i), &c, &sn);
+                unit_of_fx_c(e->dphase, (long double)(64 * i), &c, &sn);
                 e->wtab1k[i] = make_float2((float)c, (float)sn);
             }
             e->wtab1k_dphase = e->dphase;
@@ -1232,7 +1261,7 @@ int pfb_prepare(Engine* e) {
     float2* EL = TI2 + 8 * R;              // exp(j 2pi 8 l dphase): the NCO over a lane's element offset (fused VFO)
     for (int l = 0; l < 64; l++) {
         double c = 1.0, sn = 0.0;
-        if (e->rotate) unit_of_fx(e->dphase, (long double)(8 * l), &c, &sn);
+        if (e->rotate) unit_of_fx_c(e->dphase, (long double)(8 * l), &c, &sn);
         EL[l] = make_float2((float)c, (float)sn);
     }
     if (!e->d_pfb) HIPCHK(hipMalloc(&e->d_pfb, tab.size() * sizeof(float2)));
@@ -1306,13 +1335,13 @@ int launch_pfb(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
         a.phase0 = e->phase - (unsigned long long)(e->ntaps - 1) * e->dphase;
         a.dphase = e->dphase;
         a.gm1 = e->volk_gain ? e->gm1 : 0.0f;
-        unit_of_fx(e->dphase, 8.0L * (long double)a.Lo * (long double)(4 * nwg), &a.rot_step.x, &a.rot_step.y);
+        unit_of_fx_c(e->dphase, 8.0L * (long double)a.Lo * (long double)(4 * nwg), &a.rot_step.x, &a.rot_step.y);
         if (4 * nwg > 4096) return QDSP_HIP_EINVAL;     // (seg_pow covers wave indices below 2^12)
         unit_of_fx(a.phase0 - (unsigned long long)(8 * (a.Q - 1) + 1) * a.dphase, 1.0L, &a.pb_base.x, &a.pb_base.y);
-        for (int k = 0; k < 12; k++) unit_of_fx(e->dphase, 8.0L * (long double)a.Lo * (long double)(1 << k), &a.seg_pow[k].x, &a.seg_pow[k].y);
+        for (int k = 0; k < 12; k++) unit_of_fx_c(e->dphase, 8.0L * (long double)a.Lo * (long double)(1 << k), &a.seg_pow[k].x, &a.seg_pow[k].y);
         for (int b1 = 0; b1 < 8; b1++) {
             double c, sn;
-            unit_of_fx(e->dphase, (long double)(512 * b1), &c, &sn);
+            unit_of_fx_c(e->dphase, (long double)(512 * b1), &c, &sn);
             a.wtab[b1] = make_float2((float)c, (float)sn);
         }
     }
@@ -1399,7 +1428,7 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
         // one workgroup's step between its units: nwg segments (per-segment kernel), nwg groups of dec segments (grouped)
         const long double step_mult = (long double)nwg * (long double)a.L * (long double)(grouped ? a.dec : 1);
         if (!e->rot_step_ok || e->rot_step_dphase != e->dphase || e->rot_step_mult != step_mult) {
-            unit_of_fx(e->dphase, step_mult, &e->rot_step_val.x, &e->rot_step_val.y);
+            unit_of_fx_c(e->dphase, step_mult, &e->rot_step_val.x, &e->rot_step_val.y);
             e->rot_step_dphase = e->dphase;
             e->rot_step_mult = step_mult;
             e->rot_step_ok = true;
@@ -1408,7 +1437,7 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
         if (!e->wtab4k_ok || e->wtab4k_dphase != e->dphase) {
             for (int n2 = 0; n2 < 16; n2++) {
                 double c, sn;
-                unit_of_fx(e->dphase, (long double)(256 * n2), &c, &sn);
+                unit_of_fx_c(e->dphase, (long double)(256 * n2), &c, &sn);
                 e->wtab4k[n2] = make_float2((float)c, (float)sn);
             }
             e->wtab4k_dphase = e->dphase;
@@ -1451,8 +1480,8 @@ int launch_xlate_inc(Engine* e, const void* d_in, int64_t count, void* d_out, un
     // one pair per lane up to 2^27 samples: measured 0.345 ms per 2^27 samples against 0.46 ms with 16 blocks per CU
     // looping 64 times (the per-lane FP64 sincos is cheaper than the lost memory-level parallelism)
     { const long long cap = 256LL * env_int("QDSP_HIP_XLATE_WG_PER_CU", 1024); if (grid > cap) grid = cap; }
-    unit_of_fx(dphase, 1.0L, &a.rot_one.x, &a.rot_one.y);
-    unit_of_fx(dphase, (long double)(2 * grid * NT), &a.rot_stride.x, &a.rot_stride.y);
+    unit_of_fx_c(dphase, 1.0L, &a.rot_one.x, &a.rot_one.y);
+    unit_of_fx_c(dphase, (long double)(2 * grid * NT), &a.rot_stride.x, &a.rot_stride.y);
     a.vec = (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0;   // d_in == nullptr (SineSource) counts as aligned
     a.gm1 = gm1;
     hipLaunchKernelGGL((qk::xlate_kernel<NT>), dim3((unsigned)grid), dim3(NT), 0, s, a);
@@ -1478,10 +1507,10 @@ void mf_tasks(qk::MfArgs& a, int64_t nout, int nchan, bool rot) {
 }
 // NCO tables: one tile (16 M samples) further in FP64, load i of a tile (64 i samples) in FP32
 void mf_rot_tables(unsigned long long dphase, int M, int KJ, double2* step, float2* rot_k) {
-    unit_of_fx(dphase, 16.0L * (long double)M, &step->x, &step->y);
+    unit_of_fx_c(dphase, 16.0L * (long double)M, &step->x, &step->y);
     for (int k = 0; k < 2 * KJ; k++) {
         double c, sn;
-        unit_of_fx(dphase, 64.0L * (long double)k, &c, &sn);
+        unit_of_fx_c(dphase, 64.0L * (long double)k, &c, &sn);
         rot_k[k] = make_float2((float)c, (float)sn);
     }
 }
@@ -1550,10 +1579,10 @@ int launch_rm(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d_
         a.phase0 = e->phase;
         a.dphase = e->dphase;
         a.gm1 = e->volk_gain ? e->gm1 : 0.0f;
-        unit_of_fx(e->dphase, (long double)nwaves * 4.0L * (long double)a.G * (long double)a.M, &a.rot_step.x, &a.rot_step.y);
+        unit_of_fx_c(e->dphase, (long double)nwaves * 4.0L * (long double)a.G * (long double)a.M, &a.rot_step.x, &a.rot_step.y);
         for (int k = 0; k < qk::kRmNE; k++) {
             double c, sn;
-            unit_of_fx(e->dphase, 64.0L * (long double)k, &c, &sn);
+            unit_of_fx_c(e->dphase, 64.0L * (long double)k, &c, &sn);
             a.rot_k[k] = make_float2((float)c, (float)sn);
         }
     }
@@ -1602,6 +1631,23 @@ int launch_mf(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d_
 // (decimations past 32, periods of >= 33 outputs); the crossover sits at 2-5e6 samples -- 1.4e7 for the decimations
 // run at half the row length -- and from there on the MFMA kernels are 1.3-2x faster.  Short rows (decimation <= 32)
 // and the small rational ratios are quicker at every size.
+// Reference-sized calls of the small-interpolation resamplers: resamp_lm_kernel gives every lane R x L accumulators over all
+// P taps -- the throughput form (0.27-0.30 ms per 2^26 samples where the general kernel needs 0.43-0.60) -- so a call
+// too small to fill the chip takes as long as ONE lane's chain: 6.5 us at 32 taps per phase, 14 us at 67 (3/7, 200
+// taps), 24-28 us at 128 (5/8, 640 taps) or on 10/7, whatever the size up to ~1e6 samples.  The general kernel with
+// its call-sized tiles (any_plan) takes 4.0-4.7 us there and grows with outputs x taps.  Measured crossovers
+// (profiles/r02_tune_small_resamp.txt), in outputs of the call: 16 384 x taps per phase at decimation 3-4, 2x that from
+// decimation 5, 2.5x at decimation 1-2, never beyond 2^20 outputs; filters under 16 taps per phase stay (3.8-4.5 us).
+// (interp 10, decim 7 past the MFMA kernel's tap range: the general kernel at every size -- 0.58 against 0.74 ms per 2^26)
+bool lm_yields_to_any(const Engine* e, int64_t nout) {
+    if (env_int("QDSP_HIP_NO_LM_SMALL_CALL_RULE", 0)) return false;
+    if (e->L == 10 && e->M == 7) return true;
+    if (e->P < 16) return false;
+    int64_t lim = (int64_t)e->P * (e->M >= 5 ? 32768 : e->M >= 3 ? 16384 : 40960);
+    if (lim > (1 << 20)) lim = 1 << 20;
+    return nout <= lim;
+}
+
 int64_t mf_min_count(const Engine* e) {
     const int v = env_int("QDSP_HIP_MF_MIN_COUNT", -1);
     if (v >= 0) return v;
@@ -1666,7 +1712,7 @@ int64_t process_dev(Engine* e, const void* d_in, int64_t count, void* d_out, voi
         // rational ratios with interp >= 6 (48 kHz <-> 44.1 kHz is 147 / 160) on the MFMA units (rm_resamp.hip.h)
         rc = launch_rm(e, d_in, count, nout, d_out, s);
         if (rc == 0) e->cur ^= 1;
-    } else if (use_lm(e) && e->d_taps_lm) {
+    } else if (use_lm(e) && e->d_taps_lm && !(mode_of(e) == 0 && lm_yields_to_any(e, nout))) {
         if (e->ch == 2) rc = e->rotate ? launch_lm<2, true>(e, d_in, count, nout, d_out, s) : launch_lm<2, false>(e, d_in, count, nout, d_out, s);
         else rc = launch_lm<1, false>(e, d_in, count, nout, d_out, s);
         if (rc == 0) e->cur ^= 1;
@@ -2109,7 +2155,7 @@ int chan_launch_batch(Chan* c, const void* d_in, int64_t count, int64_t nout, vo
     a.count = count;
     a.nout = nout;
     bool lt = false, pad = false;
-    const size_t lds = fill_any_geometry(a, 2, &lt, &pad);
+    const size_t lds = fill_any_geometry(a, 2, &lt, &pad, (int)c->vfo.size());
     if (lds == 0) return 1;
     if (!c->d_phases) {
         // the reference's [interp][tapsPerPhase] table (buildTapPhases, resampling.h:137-166), whatever layout the

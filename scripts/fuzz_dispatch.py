@@ -62,8 +62,10 @@ while time.time() < t_end:
         ntaps = int(rng.integers(L, 40 * L))
     vfo = bool(rng.integers(0, 2)) and kind != "fir"
     lift = bool(rng.integers(0, 2))
-    for k in ("QDSP_HIP_MF_MIN_COUNT", "QDSP_HIP_RM_MIN_COUNT", "QDSP_HIP_RM_MIN_INTERP", "QDSP_HIP_NO_FFT1K"):
+    for k in ("QDSP_HIP_MF_MIN_COUNT", "QDSP_HIP_RM_MIN_COUNT", "QDSP_HIP_RM_MIN_INTERP", "QDSP_HIP_NO_FFT1K", "QDSP_HIP_NO_LM_SMALL_CALL_RULE"):
         os.environ.pop(k, None)
+    if rng.integers(0, 3) == 0:
+        os.environ["QDSP_HIP_NO_LM_SMALL_CALL_RULE"] = "1"     # (resamp_lm_kernel on the small calls the general kernel takes by default)
     if rng.integers(0, 3) == 0:
         os.environ["QDSP_HIP_NO_FFT1K"] = "1"     # (the 4096-point overlap-save kernels on the calls the one-wave form takes by default)
     if lift:

@@ -28,8 +28,11 @@ def _mfma_kernels_on_small_inputs(request, monkeypatch):
         # bench-sized calls run -- untested at oracle-sized inputs.  test_gpu_parity pins them; the 1024-point form has
         # its own tests there (marked default_dispatch), and test_gpu_ring, test_host_cpp and the randomised run
         # (scripts/fuzz_dispatch.py) go through the defaults.
+        # Likewise the small-interpolation resampler kernel (resamp_lm_kernel), which hands calls of up to ~10^6 outputs to
+        # the general kernel by default (lm_yields_to_any in qdsp_hip.hip).
         if mod == "test_gpu_parity":
             monkeypatch.setenv("QDSP_HIP_FFT1K_MAX_COUNT", "0")
+            monkeypatch.setenv("QDSP_HIP_NO_LM_SMALL_CALL_RULE", "1")
 
 
 @pytest.fixture(scope="session")

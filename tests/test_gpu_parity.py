@@ -1663,3 +1663,76 @@ def test_fft1k_vfo_retune_and_ideal_nco(ops, gold):
             assert v.last_kernel()["name"] == "fir_fft1k_kernel"
             ws.append(rs.process(xl.process(blk)))
         assert rel_rms(np.concatenate(ys), np.concatenate(ws)) < TOL_FFT
+
+
+# ------------------------------------------------------------------------------ reference-sized calls of rational resamplers
+@pytest.mark.default_dispatch
+@pytest.mark.parametrize("L,M,ntaps", [(3, 7, 200), (2, 3, 64), (5, 2, 81), (10, 1, 160), (4, 5, 127), (10, 7, 400), (5, 8, 640),
+                                       (24, 125, 1001), (147, 160, 2048), (2, 1, 15)])
+@pytest.mark.parametrize("vfo", [False, True])
+def test_small_calls_of_rational_resamplers(ops, L, M, ntaps, vfo):
+    """Default dispatch on reference-sized blocks: the small-interpolation kernel (R x L accumulators per lane: the
+    throughput form) yields to the general kernel with call-sized tiles (any_plan: 256-2048 outputs per tile by the size
+    of the call) up to the measured crossover, and takes over beyond it mid-stream; same results either way (FP64 oracle
+    over the same block sequence, per-call phase restart included)."""
+    taps = (O.lowpass_taps_f64(ntaps, 0.4 / max(L, M)) * L).astype(np.float32)
+    P = -(-ntaps // L)
+    lim = min(P * (32768 if M >= 5 else 16384 if M >= 3 else 40960), 1 << 20)
+    lm_shape = L in (2, 3, 4, 5, 10) and M <= 8
+    sizes = [30_000 // M * M + 1, 7, 120_000, 2 * M + 1]
+    big = None
+    if lm_shape and P >= 16 and (L, M) != (10, 7):
+        big = (lim + 40_000) * M // L + M            # one call just past the crossover
+        if big < 3_000_000:
+            sizes.append(big)
+    n = sum(sizes)
+    x = O.synth_iq(0, n, seed=L * 1000 + M)
+    cuts = np.cumsum([0] + sizes)
+    if vfo:
+        op = ops.Vfo(taps, L, M, ops.phase_delta(1.0, -0.2345))
+        xl = O.Xlator(1.0, -0.2345, exact=True, volk_gain=True)
+    else:
+        op, xl = ops.Resampler(taps, L, M), None
+    o = O.Resampler(taps, L, M, acc=O.ACC_F64)
+    names = []
+    for a, b in zip(cuts, cuts[1:]):
+        y = np.array(op.process(x[a:b]))
+        names.append(op.last_kernel()["name"])
+        w = o.process(xl.process(x[a:b]) if xl else x[a:b])
+        assert y.shape == w.shape
+        if len(w):
+            assert rel_rms(y, w) < 2e-6, (names, a, b)
+            assert rel_rms(y[:16], w[:16]) < 1e-5 and rel_rms(y[-16:], w[-16:]) < 1e-5, (names, a, b)
+    if lm_shape and P >= 16:
+        want = ["resamp_any_kernel" if (L, M) == (10, 7) or (b - a) * L // M <= lim else "resamp_lm_kernel" for a, b in zip(cuts, cuts[1:])]
+        assert names == want, (names, want)
+        assert "resamp_any_kernel" in names
+    elif lm_shape:
+        assert names[0] == "resamp_lm_kernel", names          # short filters: 3.8-4.5 us per call already
+    else:
+        assert names[0] == "resamp_any_kernel", names
+
+
+@pytest.mark.default_dispatch
+def test_long_decimators_on_short_calls_take_the_one_wave_overlap_save(ops, gold):
+    """256-400 taps at decimation 3 / 8 on calls of 2048-16 000 samples: fir_core_kernel took 10-13 us there; the one-wave
+    1024-point form (from 64 samples on for resamplers and the fused VFO) 5.6-5.9."""
+    taps = gold["taps256"]
+    for M in (3, 8):
+        d = ops.Resampler(taps, 1, M)
+        v = ops.Vfo(taps, 1, M, ops.phase_delta(1.0, 0.1234))
+        o, ov = O.Resampler(taps, 1, M, acc=O.ACC_F64), O.Resampler(taps, 1, M, acc=O.ACC_F64)
+        xl = O.Xlator(1.0, 0.1234, exact=True, volk_gain=True)
+        x = O.synth_iq(0, 40_000, seed=M)
+        cuts = [0, 64, 64 + 2048, 64 + 2048 + 100, 64 + 2048 + 100 + 16_000, 40_000]
+        for a, b in zip(cuts, cuts[1:]):
+            y, w = np.array(d.process(x[a:b])), o.process(x[a:b])
+            yv, wv = np.array(v.process(x[a:b])), ov.process(xl.process(x[a:b]))
+            assert d.last_kernel()["name"] == "fir_fft1k_kernel" and v.last_kernel()["name"] == "fir_fft1k_kernel"
+            assert y.shape == w.shape and yv.shape == wv.shape
+            # (absolute bar: the first calls are the filter's start-up transient, outputs of 1e-8 .. 1e-3 next to input
+            # samples of magnitude 1 in the same transform -- an overlap-save kernel's rounding is relative to the latter)
+            if len(w):
+                assert np.abs(y - w).max() < 1e-6 and np.abs(yv - wv).max() < 1e-6, (M, a, b)
+            if b - a >= 16_000:
+                assert rel_rms(y, w) < TOL_FFT and rel_rms(yv, wv) < TOL_FFT, (M, a, b)
