@@ -835,6 +835,12 @@ AnyPlan any_plan(int L, int M, int P, int ch, long long nout = -1) {
     if (nout >= 0) {
         const long long want = env_int("QDSP_HIP_ANY_SMALL_CALL_TILES", 512);   // (256 .. 4096 measured: 147/160 at 1e6 samples 9.5 / 9.1 / 10.0 / 11.2 us)
         while (tile > NT && (nout + tile - 1) / tile < want) tile /= 2;
+        // large decimations (taps split over the lanes of an output): down to 16 outputs per tile = 16 lanes per output, as long
+        // as a lane keeps 16 taps -- the VFO's 401 taps / 50 on a 1e6-sample block: 100 dependent MACs per lane -> 25
+        if (ks_ok && want > 0) {
+            if (tile > kSplitTile && (nout + kSplitTile - 1) / kSplitTile < 4 * want && P >= 64) tile = kSplitTile;
+            while (tile > 16 && tile <= kSplitTile && (nout + tile - 1) / tile < want && P / (2 * NT / tile) >= 16) tile /= 2;
+        }
     }
     // a half-workgroup tile with a long tap loop: the quarter tile with four lanes per output is faster (M = 50,
     // 401 taps: 0.24 -> 0.17 ms) unless it stages too little per lane (M = 32: 9 samples in batches of 8)
@@ -986,7 +992,16 @@ bool fft_eligible(const Engine* e, int64_t count) {
     // (below 2^16 samples a 4096-point segment per workgroup leaves most of the chip idle; one-wave segments go down to 2^14)
     // (... and further where the alternative is fir_core_kernel on a long filter: 256-400 taps at decimation 3 / 8, 2048-16 000
     // samples: 10-13 us against 5.6-5.9; the FIR itself has fir_lat_kernel there)
-    return e->ntaps >= min_taps && count >= env_int("QDSP_HIP_FFT_MIN_COUNT", fft1k_eligible(e, count) ? (e->kind == KIND_FIR ? 1 << 14 : 64) : 1 << 16);
+    // Long filters outside that kernel's range (real data, more than 513 taps): the direct kernels cost 4-7.5e-6 us per tap and
+    // sample (1500 taps x 4096 samples: 49 us; 1000 taps at decimation 7: 29 us up to 65 534 samples), one 4096-point
+    // segment 9.5-12 us whatever it holds: from 2^21 tap-samples on the segment wins (the decimators' direct kernel does not
+    // get cheaper with the decimation: its time follows the taps a lane walks through)
+    int64_t min_count = fft1k_eligible(e, count) ? (e->kind == KIND_FIR ? 1 << 14 : 64) : 1 << 16;
+    if (min_count == (1 << 16) && e->ntaps >= 256) {
+        const int64_t by_work = (1 << 21) / e->ntaps;
+        min_count = by_work < 1024 ? 1024 : by_work;
+    }
+    return e->ntaps >= min_taps && count >= env_int("QDSP_HIP_FFT_MIN_COUNT", (int)min_count);
 }
 
 int fft_prepare(Engine* e) {
@@ -1648,6 +1663,14 @@ bool lm_yields_to_any(const Engine* e, int64_t nout) {
     return nout <= lim;
 }
 
+// The strided-window decimator on reference-sized calls: 6.0-8.2 us per call at 95-127 taps (decimation 2 / 4 / 8) where
+// the one-wave overlap-save kernel takes 5.5 whatever the taps; from ~1e6 samples on the window kernel is ahead again
+// (profiles/r02_tune_fft1k.txt).
+bool win_yields_to_fft1k(const Engine* e, int64_t count) {
+    if (e->ntaps < 96 || count > (1 << 19) || env_int("QDSP_HIP_NO_WIN_SMALL_CALL_RULE", 0)) return false;
+    return fft1k_eligible(e, count);
+}
+
 int64_t mf_min_count(const Engine* e) {
     const int v = env_int("QDSP_HIP_MF_MIN_COUNT", -1);
     if (v >= 0) return v;
@@ -1679,7 +1702,7 @@ int64_t process_dev(Engine* e, const void* d_in, int64_t count, void* d_out, voi
         // large integer decimations (the VFO's usual job) as an FP32 matrix product on the MFMA units (mf_dec.hip.h)
         rc = launch_mf(e, d_in, count, nout, d_out, s);
         if (rc == 0) e->cur ^= 1;
-    } else if (fft_eligible(e, count) && !(mode_of(e) == 0 && use_win(e) && e->d_taps_lm)) {
+    } else if (fft_eligible(e, count) && !(mode_of(e) == 0 && use_win(e) && e->d_taps_lm && !win_yields_to_fft1k(e, count))) {
         rc = launch_fft(e, d_in, count, nout, d_out, s);
         if (rc == 0) e->cur ^= 1;
         took_fft = true;
