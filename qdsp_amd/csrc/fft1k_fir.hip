@@ -249,8 +249,83 @@ __device__ __forceinline__ void f1k_store(const FftArgs& a, long long seg0, int 
     }
 }
 
+// ---- real data (FIR<float>, PolyphaseResampler<float>): a real filter keeps the real and imaginary parts of its input
+// apart, so TWO consecutive real segments ride one complex transform as re / im (as fir_fft_kernel<.., REAL> does with
+// its 4096-point segments); loads and stores are 4-byte.  Wave b takes real segments 2b (-> re) and 2b + 1 (-> im).
+__device__ __forceinline__ void f1k_hand_over_real(const FftArgs& a, int i) {
+    const int H = a.H;
+    if (i >= H) return;
+    const float* inr = reinterpret_cast<const float*>(a.in);
+    const float* hr = reinterpret_cast<const float*>(a.hist);
+    float* hn = reinterpret_cast<float*>(a.hist_next);
+    const long long g = a.count - H + i;
+    hn[i] = g < 0 ? hr[g + H] : inr[g];
+}
+
+__device__ __forceinline__ void f1k_load_real(const FftArgs& a, long long segA, long long segB, int l, v2f (&v)[16]) {
+    const float* __restrict__ inr = reinterpret_cast<const float*>(a.in);
+    const float* __restrict__ hr = reinterpret_cast<const float*>(a.hist);
+    if (segA >= 0 && segB + kFft1kN <= a.count) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = mk2(inr[segA + 64 * i + l], inr[segB + 64 * i + l]);
+    } else {
+        const int H = a.H;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const long long gA = segA + 64 * i + l, gB = segB + 64 * i + l;
+            float xa = 0.0f, xb = 0.0f;
+            if (gA < 0) { if (gA + H >= 0) xa = hr[gA + H]; }
+            else if (gA < a.count) xa = inr[gA];
+            if (gB < 0) { if (gB + H >= 0) xb = hr[gB + H]; }
+            else if (gB < a.count) xb = inr[gB];
+            v[i] = mk2(xa, xb);
+        }
+    }
+}
+
+// one real segment's valid outputs: component C of v (0 = re: segment A, 1 = im: segment B)
+template <int C>
+__device__ __forceinline__ void f1k_store_real_one(const FftArgs& a, long long seg0, int l, const v2f (&v)[16]) {
+    float* __restrict__ outr = reinterpret_cast<float*>(a.out);
+    auto val = [&](int i) { return C == 0 ? v[rev16(i)].x : v[rev16(i)].y; };
+    if (a.strided) {
+        const long long s1 = seg0 + 1;
+        long long q0 = s1 / a.decm;
+        long long r = s1 - q0 * a.decm;
+        if (r < 0) { r += a.decm; q0 -= 1; }
+        const int r0 = (int)r;
+        if (a.m_shift >= 0) {
+            const unsigned x0 = (unsigned)(r0 + l);
+            const long long n0 = q0 + (x0 >> a.m_shift);
+            const int per = 64 >> a.m_shift;
+            if ((x0 & ((1u << a.m_shift) - 1u)) == 0) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const long long n = n0 + i * per;
+                    if (64 * i + l >= a.ov && n >= 0 && n < a.nout) outr[n] = val(i);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int el = 64 * i + l;
+                const unsigned x = (unsigned)(r0 + el);
+                const unsigned qq = a.decm_inv ? (unsigned)(((unsigned long long)x * a.decm_inv) >> 32) : x / (unsigned)a.decm;
+                const long long n = q0 + qq;
+                if (el >= a.ov && x - qq * (unsigned)a.decm == 0 && n >= 0 && n < a.nout) outr[n] = val(i);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const long long n = seg0 + 64 * i + l;
+            if (64 * i + l >= a.ov && n < a.nout) outr[n] = val(i);
+        }
+    }
+}
+
 // ---- reference-sized calls: one workgroup = one wave = one segment ----------------------------------------------
-template <bool ROT>
+template <bool ROT, bool REAL = false>
 __global__ __launch_bounds__(64) void fir_fft1k_kernel(const FftArgs a) {
     __shared__ __attribute__((aligned(16))) float2 lds[16 * kF1P];
     const int l = threadIdx.x;
@@ -258,13 +333,16 @@ __global__ __launch_bounds__(64) void fir_fft1k_kernel(const FftArgs a) {
     if ((int)blockIdx.x < nh) {
         // the hand-over runs in ceil(H / 64) extra workgroups, the FIRST ones of the grid: with the NCO each element costs
         // an FP64 sincos, which would be the tail of the launch if these started last
-        f1k_hand_over<ROT>(a, (int)blockIdx.x * 64 + l);
+        if (REAL) f1k_hand_over_real(a, (int)blockIdx.x * 64 + l);
+        else f1k_hand_over<ROT>(a, (int)blockIdx.x * 64 + l);
         return;
     }
     const int b = (int)blockIdx.x - nh;
-    const long long seg0 = (long long)b * a.L - a.seg_shift;   // stream position of element 0
+    const long long seg0 = (long long)(REAL ? 2 * b : b) * a.L - a.seg_shift;   // stream position of element 0
+    const long long segB = seg0 + a.L;                                           // REAL: the second segment of the pair
     v2f v[16];
-    f1k_load(a, seg0, l, v);
+    if (REAL) f1k_load_real(a, seg0, segB, l, v);
+    else f1k_load(a, seg0, l, v);
     // per-lane constants (L1/L2-resident tables, the same for every wave)
     const int j = l & 3;
     v2f ta[16], tb[16], hf[16];
@@ -282,12 +360,19 @@ __global__ __launch_bounds__(64) void fir_fft1k_kernel(const FftArgs a) {
         f1k_gain(a, seg0, l, v);
     }
     f1k_transform(v, reinterpret_cast<v2f*>(lds), l, [&](int k) { return ta[k]; }, [&](int k) { return tb[k]; }, [&](int k) { return hf[k]; });
-    f1k_store<ROT>(a, seg0, l, v, q);
+    if (REAL) {
+        f1k_store_real_one<0>(a, seg0, l, v);
+        f1k_store_real_one<1>(a, segB, l, v);
+    } else {
+        f1k_store<ROT>(a, seg0, l, v, q);
+    }
 }
 
 int launch_fir_fft1k(const FftArgs& a, hipStream_t stream) {
-    if (a.rot) hipLaunchKernelGGL((fir_fft1k_kernel<true>), dim3(a.nblocks + (a.H + 63) / 64), dim3(64), 0, stream, a);
-    else hipLaunchKernelGGL((fir_fft1k_kernel<false>), dim3(a.nblocks + (a.H + 63) / 64), dim3(64), 0, stream, a);
+    const dim3 grid(a.nblocks + (a.H + 63) / 64);
+    if (a.real2) hipLaunchKernelGGL((fir_fft1k_kernel<false, true>), grid, dim3(64), 0, stream, a);
+    else if (a.rot) hipLaunchKernelGGL((fir_fft1k_kernel<true>), grid, dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL((fir_fft1k_kernel<false>), grid, dim3(64), 0, stream, a);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }

@@ -996,7 +996,13 @@ bool fft_eligible(const Engine* e, int64_t count) {
     // sample (1500 taps x 4096 samples: 49 us; 1000 taps at decimation 7: 29 us up to 65 534 samples), one 4096-point
     // segment 9.5-12 us whatever it holds: from 2^21 tap-samples on the segment wins (the decimators' direct kernel does not
     // get cheaper with the decimation: its time follows the taps a lane walks through)
-    int64_t min_count = fft1k_eligible(e, count) ? (e->kind == KIND_FIR ? 1 << 14 : 64) : 1 << 16;
+    int64_t min_count = 1 << 16;
+    if (fft1k_eligible(e, count)) {
+        // (FIR<complex_t> has fir_lat_kernel below 2^24 tap-samples; FIR<float> only fir_core_kernel: 3.4 us + 4e-6 per tap and sample)
+        if (e->kind != KIND_FIR) min_count = 64;
+        else if (e->ch == 2) min_count = 1 << 14;
+        else min_count = (1 << 19) / e->ntaps < 1024 ? 1024 : (1 << 19) / e->ntaps;
+    }
     if (min_count == (1 << 16) && e->ntaps >= 256) {
         const int64_t by_work = (1 << 21) / e->ntaps;
         min_count = by_work < 1024 ? 1024 : by_work;
@@ -1066,8 +1072,9 @@ int fft_prepare(Engine* e) {
 // Bounds: complex data, interp 1, taps up to half a segment; calls from the first size the 4096-point form is
 // picked for up to QDSP_HIP_FFT1K_MAX_COUNT (measured crossover, scripts/tune_call_size.py).
 bool fft1k_eligible(const Engine* e, int64_t count) {
-    if (e->ch != 2 || e->L != 1 || e->ntaps < 2 || e->ntaps > 513) return false;
+    if (e->L != 1 || e->ntaps < 2 || e->ntaps > 513) return false;
     if (e->kind != KIND_FIR && e->kind != KIND_DECIM && e->kind != KIND_VFO) return false;
+    if (e->ch != 2 && (e->kind == KIND_VFO || e->rotate || env_int("QDSP_HIP_NO_FFT1K_REAL", 0))) return false;   // real data: two real segments per wave
     const int mode = e->fir_mode ? e->fir_mode : env_int("QDSP_HIP_FIR_MODE", 0);
     if (mode != 0 || env_int("QDSP_HIP_NO_FFT1K", 0)) return false;
     const int forced = env_int("QDSP_HIP_FFT1K_MAX_COUNT", -1);
@@ -1075,6 +1082,12 @@ bool fft1k_eligible(const Engine* e, int64_t count) {
     // measured crossovers against the 4096-point kernels (scripts/tune_fft1k.py, profiles/r02_tune_fft1k.txt): the
     // overlap grows with the taps (1024 - ntaps + 1 new points per segment), decimations 2 / 4 / 8 / 16 have the
     // pruned inverse on the other side, the fused NCO costs this form 32 more complex products per lane
+    if (e->ch == 1) {
+        // real data (two real segments per wave): the other side is fir_fft_kernel<1, false, REAL> with its full inverse at every
+        // decimation -- 256 taps: FIR 59.6 against 69.9 us at 2^25 samples, decimate-by-8 115.8 against 152.2 at 2^26
+        if (e->kind == KIND_FIR) return count <= (e->ntaps <= 128 ? 1 << 27 : e->ntaps <= 288 ? 1 << 25 : e->ntaps <= 416 ? 1 << 24 : 1 << 23);
+        return count <= (e->ntaps <= 288 ? 1 << 27 : e->ntaps <= 416 ? 1 << 26 : 1 << 25);
+    }
     const bool pruned = e->kind != KIND_FIR && (e->M == 2 || e->M == 4 || e->M == 8 || e->M == 16);
     int64_t lim = e->ntaps <= 128 ? 6 << 20 : e->ntaps <= 288 ? 4 << 20 : e->ntaps <= 416 ? 3 << 20 : 2 << 20;
     if (pruned) lim = e->ntaps <= 288 ? 3 << 20 : 3 << 19;
@@ -1178,6 +1191,10 @@ int launch_fft1k(Engine* e, const void* d_in, int64_t count, int64_t nout, void*
         a.seg_shift = a.ov;
         a.L = qk::kFft1kN - a.ov;
         a.nblocks = (int)((count + a.L - 1) / a.L);
+    }
+    if (e->ch == 1) {   // real data: one wave = a PAIR of real segments (re / im of one transform)
+        a.real2 = 1;
+        a.nblocks = (a.nblocks + 1) / 2;
     }
     a.nwg = a.nblocks;
     if (a.rot) {
@@ -1667,7 +1684,7 @@ bool lm_yields_to_any(const Engine* e, int64_t nout) {
 // the one-wave overlap-save kernel takes 5.5 whatever the taps; from ~1e6 samples on the window kernel is ahead again
 // (profiles/r02_tune_fft1k.txt).
 bool win_yields_to_fft1k(const Engine* e, int64_t count) {
-    if (e->ntaps < 96 || count > (1 << 19) || env_int("QDSP_HIP_NO_WIN_SMALL_CALL_RULE", 0)) return false;
+    if (e->ch != 2 || e->ntaps < 96 || count > (1 << 19) || env_int("QDSP_HIP_NO_WIN_SMALL_CALL_RULE", 0)) return false;   // (real data: 5.6-6.8 us against 7.1-8.3)
     return fft1k_eligible(e, count);
 }
 

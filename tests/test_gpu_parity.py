@@ -1602,8 +1602,8 @@ def test_fft1k_small_calls_vs_oracle(ops, kind, M, ntaps):
 
 @pytest.mark.default_dispatch
 def test_fft1k_thresholds_and_exclusions(ops, gold, monkeypatch):
-    """Where the one-wave form stops: above its measured call-size limits the 4096-point kernels run, real-valued data
-    and filters past 513 taps never take it, QDSP_HIP_NO_FFT1K and the explicit FFT / DIRECT modes switch it off."""
+    """Where the one-wave form stops: above its measured call-size limits the 4096-point kernels run, filters past 513 taps
+    never take it, QDSP_HIP_NO_FFT1K (_REAL) and the explicit FFT / DIRECT modes switch it off."""
     import torch
 
     taps = gold["taps256"]
@@ -1630,10 +1630,19 @@ def test_fft1k_thresholds_and_exclusions(ops, gold, monkeypatch):
     g.process(x[:1_000_000], out[:1_000_000])
     assert g.last_kernel()["name"] == "fir_fft_kernel"
     g.close()
+    # real data: two real segments per wave, up to 2^25 samples at 256 taps; QDSP_HIP_NO_FFT1K_REAL keeps the 4096-point kernel
     r = ops.Fir(taps, complex_data=False, max_block=0)
-    r.process(torch.zeros(1_000_000, dtype=torch.float32, device="cuda"))
+    xr = torch.zeros((1 << 25) + 8, dtype=torch.float32, device="cuda")
+    outr = torch.empty((1 << 25) + 8, dtype=torch.float32, device="cuda")
+    for n, want in ((1_000_000, "fir_fft1k_kernel"), (1 << 25, "fir_fft1k_kernel"), ((1 << 25) + 8, "fir_fft_kernel")):
+        r.process(xr[:n], outr[:n])
+        assert r.last_kernel()["name"] == want, (n, r.last_kernel())
+    monkeypatch.setenv("QDSP_HIP_NO_FFT1K_REAL", "1")
+    r.process(xr[:1_000_000], outr[:1_000_000])
     assert r.last_kernel()["name"] == "fir_fft_kernel"
+    monkeypatch.delenv("QDSP_HIP_NO_FFT1K_REAL")
     r.close()
+    del xr, outr
     monkeypatch.setenv("QDSP_HIP_NO_FFT1K", "1")
     h = ops.Fir(taps, max_block=0)
     h.process(x[:1_000_000], out[:1_000_000])
@@ -1736,3 +1745,39 @@ def test_long_decimators_on_short_calls_take_the_one_wave_overlap_save(ops, gold
                 assert np.abs(y - w).max() < 1e-6 and np.abs(yv - wv).max() < 1e-6, (M, a, b)
             if b - a >= 16_000:
                 assert rel_rms(y, w) < TOL_FFT and rel_rms(yv, wv) < TOL_FFT, (M, a, b)
+
+
+@pytest.mark.default_dispatch
+@pytest.mark.parametrize("M", [1, 2, 3, 8])
+@pytest.mark.parametrize("ntaps", [97, 256, 513])
+def test_fft1k_real_data(ops, M, ntaps):
+    """FIR<float> / PolyphaseResampler<float> (interp 1) on the one-wave overlap-save kernel: two consecutive real segments ride
+    one 1024-point complex transform as re / im.  Ragged block sequence (odd lengths, a block shorter than the history, one
+    that ends inside the first segment of a pair), small members on the direct kernels, against the FP64 oracle."""
+    import torch
+
+    rng = np.random.default_rng(4100 + ntaps + M)
+    taps = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    n = 400_000
+    x = np.ascontiguousarray(O.synth_iq(0, n, seed=ntaps * 7 + M).real)
+    cuts = [0, 150_001, 150_001 + 31, 150_001 + 31 + 70_000, 150_001 + 31 + 70_000 + 1500, n]
+    if M == 1:
+        op, o = ops.Fir(taps, complex_data=False), O.Fir(taps, complex_data=False, acc=O.ACC_F64)
+    else:
+        op, o = ops.Resampler(taps, 1, M, complex_data=False), O.Resampler(taps, 1, M, complex_data=False, acc=O.ACC_F64)
+    names = []
+    for a, b in zip(cuts, cuts[1:]):
+        y = op.process(torch.from_numpy(x[a:b]).cuda()).cpu().numpy()
+        names.append(op.last_kernel()["name"])
+        w = o.process(x[a:b])
+        assert y.dtype == np.float32 and y.shape == w.shape
+        assert np.abs(y - w).max() < 2e-6 * max(1.0, np.abs(w).max()), (names, a, b)
+        if b - a > 10_000:
+            assert rel_rms(y, w) < TOL_FFT, (names, a, b)
+    # QDSP_HIP_FFT_MIN_TAPS_REAL and the real decimators' 32 taps per branch; the strided-window kernel keeps its tap range
+    win_max = {1: 7, 2: 150, 3: 150, 8: 200}[M]
+    fft_auto = ntaps >= max(96, 32 * M) and ntaps > win_max
+    if fft_auto:
+        assert names[0] == "fir_fft1k_kernel" and names[2] == "fir_fft1k_kernel" and names[4] == "fir_fft1k_kernel", names
+    else:
+        assert "fir_fft1k_kernel" not in names, names

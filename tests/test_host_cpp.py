@@ -116,9 +116,10 @@ def test_graph_fir256_custom_window_and_float(harness, data):
     run([harness, "fir", str(d / "x.cf32"), str(d / "y2.cf32"), "4096", str(d / "t256.f32")])
     y2 = np.fromfile(d / "y2.cf32", dtype=np.complex64)
     assert np.array_equal(y2, O.Fir(taps, acc=O.ACC_FMA).process(x))  # small blocks -> direct form, bit-exact
-    # FIR<float>: 4096-sample blocks stay on the direct form (bit-exact); 50000-sample blocks of a 256-tap filter are past
-    # 2^21 tap-samples, where one overlap-save segment (10.6 us) beats the direct kernel (~50 us): tolerance, not equality
-    run([harness, "firf", str(d / "x.f32"), str(d / "yf.f32"), "4096", str(d / "t256.f32")])
+    # FIR<float>: blocks of under 2^19 tap-samples (1024 samples at 256 taps) stay on the direct form (bit-exact); 50000-sample
+    # blocks go to the one-wave overlap-save kernel (two real segments per transform: 6.5 us against ~50 for the direct
+    # kernel): tolerance, not equality
+    run([harness, "firf", str(d / "x.f32"), str(d / "yf.f32"), "1024", str(d / "t256.f32")])
     yf = np.fromfile(d / "yf.f32", dtype=np.float32)
     xr = np.ascontiguousarray(x.real)
     assert np.array_equal(yf, O.Fir(taps, complex_data=False, acc=O.ACC_FMA).process(xr))
