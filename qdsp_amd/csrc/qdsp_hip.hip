@@ -992,7 +992,7 @@ bool fft_eligible(const Engine* e, int64_t count) {
     // (below 2^16 samples a 4096-point segment per workgroup leaves most of the chip idle; one-wave segments go down to 2^14)
     // (... and further where the alternative is fir_core_kernel on a long filter: 256-400 taps at decimation 3 / 8, 2048-16 000
     // samples: 10-13 us against 5.6-5.9; the FIR itself has fir_lat_kernel there)
-    // Long filters outside that kernel's range (real data, more than 513 taps): the direct kernels cost 4-7.5e-6 us per tap and
+    // Long filters outside that kernel's range (more than 769 taps): the direct kernels cost 4-7.5e-6 us per tap and
     // sample (1500 taps x 4096 samples: 49 us; 1000 taps at decimation 7: 29 us up to 65 534 samples), one 4096-point
     // segment 9.5-12 us whatever it holds: from 2^21 tap-samples on the segment wins (the decimators' direct kernel does not
     // get cheaper with the decimation: its time follows the taps a lane walks through)
@@ -1000,7 +1000,7 @@ bool fft_eligible(const Engine* e, int64_t count) {
     if (fft1k_eligible(e, count)) {
         // (FIR<complex_t> has fir_lat_kernel below 2^24 tap-samples; FIR<float> only fir_core_kernel: 3.4 us + 4e-6 per tap and sample)
         if (e->kind != KIND_FIR) min_count = 64;
-        else if (e->ch == 2) min_count = 1 << 14;
+        else if (e->ch == 2) min_count = e->ntaps > 320 ? 64 : 1 << 14;
         else min_count = (1 << 19) / e->ntaps < 1024 ? 1024 : (1 << 19) / e->ntaps;
     }
     if (min_count == (1 << 16) && e->ntaps >= 256) {
@@ -1072,7 +1072,7 @@ int fft_prepare(Engine* e) {
 // Bounds: complex data, interp 1, taps up to half a segment; calls from the first size the 4096-point form is
 // picked for up to QDSP_HIP_FFT1K_MAX_COUNT (measured crossover, scripts/tune_call_size.py).
 bool fft1k_eligible(const Engine* e, int64_t count) {
-    if (e->L != 1 || e->ntaps < 2 || e->ntaps > 513) return false;
+    if (e->L != 1 || e->ntaps < 2 || e->ntaps > 769) return false;   // (769 taps: a quarter of every segment is new)
     if (e->kind != KIND_FIR && e->kind != KIND_DECIM && e->kind != KIND_VFO) return false;
     if (e->ch != 2 && (e->kind == KIND_VFO || e->rotate || env_int("QDSP_HIP_NO_FFT1K_REAL", 0))) return false;   // real data: two real segments per wave
     const int mode = e->fir_mode ? e->fir_mode : env_int("QDSP_HIP_FIR_MODE", 0);
@@ -1085,13 +1085,14 @@ bool fft1k_eligible(const Engine* e, int64_t count) {
     if (e->ch == 1) {
         // real data (two real segments per wave): the other side is fir_fft_kernel<1, false, REAL> with its full inverse at every
         // decimation -- 256 taps: FIR 59.6 against 69.9 us at 2^25 samples, decimate-by-8 115.8 against 152.2 at 2^26
+        if (e->ntaps > 513) return count <= (1 << 20);
         if (e->kind == KIND_FIR) return count <= (e->ntaps <= 128 ? 1 << 27 : e->ntaps <= 288 ? 1 << 25 : e->ntaps <= 416 ? 1 << 24 : 1 << 23);
         return count <= (e->ntaps <= 288 ? 1 << 27 : e->ntaps <= 416 ? 1 << 26 : 1 << 25);
     }
     const bool pruned = e->kind != KIND_FIR && (e->M == 2 || e->M == 4 || e->M == 8 || e->M == 16);
-    int64_t lim = e->ntaps <= 128 ? 6 << 20 : e->ntaps <= 288 ? 4 << 20 : e->ntaps <= 416 ? 3 << 20 : 2 << 20;
-    if (pruned) lim = e->ntaps <= 288 ? 3 << 20 : 3 << 19;
-    if (e->rotate && (pruned || e->ntaps > 288)) lim = 3 << 19;
+    int64_t lim = e->ntaps <= 128 ? 6 << 20 : e->ntaps <= 288 ? 4 << 20 : e->ntaps <= 416 ? 3 << 20 : e->ntaps <= 513 ? 2 << 20 : pruned ? 1 << 18 : 1 << 19;
+    if (pruned && e->ntaps <= 513) lim = e->ntaps <= 288 ? 3 << 20 : 3 << 19;
+    if (e->rotate && (pruned || e->ntaps > 288) && e->ntaps <= 513) lim = 3 << 19;
     return count <= lim;
 }
 
@@ -1553,10 +1554,12 @@ void mf_rot_tables(unsigned long long dphase, int M, int KJ, double2* step, floa
 bool fir_lat_eligible(const Engine* e, int64_t count) {
     if (e->kind != KIND_FIR || e->ch != 2 || !e->has_filter || e->L != 1 || e->M != 1) return false;
     if (e->ntaps > 1024 || env_int("QDSP_HIP_NO_FIR_LAT", 0)) return false;
+    // (a wave walks all taps of its 64 outputs: 600 taps take 9.3 us on 4096 samples, the one-wave overlap-save kernel 5.6)
+    if (e->ntaps > 320 && fft1k_eligible(e, count)) return false;
     // measured: 2.5 us + 1.7e-7 us per tap and sample (63 / 127 / 256 taps at 65 536 samples: 2.9 / 3.6 / 5.3 us); what it
     // competes with is the overlap-save kernel (~9 us up to 262 144 samples) from 96 taps on, fir_core_kernel (5.7-6.1 us) below
-    // -- and, for up to 513 taps, the one-wave-per-segment overlap-save kernel (5.2-5.9 us up to 262 144 samples whatever the taps)
-    const int64_t limit = env_int("QDSP_HIP_FIR_LAT_MAX_WORK", e->ntaps >= 96 && e->ntaps > 513 ? 1 << 25 : 1 << 24);
+    // -- and, for up to 769 taps, the one-wave-per-segment overlap-save kernel (5.2-5.9 us up to 262 144 samples whatever the taps)
+    const int64_t limit = env_int("QDSP_HIP_FIR_LAT_MAX_WORK", e->ntaps > 769 ? 1 << 25 : 1 << 24);
     return count > 0 && count * (int64_t)e->ntaps <= limit;
 }
 int launch_fir_lat(Engine* e, const void* d_in, int64_t count, void* d_out, hipStream_t s) {

@@ -1559,7 +1559,7 @@ def _fft1k_case(ops, kind, taps, M, inc=None):
 
 @pytest.mark.default_dispatch
 @pytest.mark.parametrize("kind,M", [("fir", 1), ("dec", 1), ("dec", 2), ("dec", 3), ("dec", 8), ("dec", 64), ("vfo", 1), ("vfo", 4), ("vfo", 5), ("vfo", 8)])
-@pytest.mark.parametrize("ntaps", [24, 97, 255, 256, 257, 401, 513])
+@pytest.mark.parametrize("ntaps", [24, 97, 255, 256, 257, 401, 513, 769])
 def test_fft1k_small_calls_vs_oracle(ops, kind, M, ntaps):
     """fir_fft1k_kernel under the default dispatch: FIR<complex_t>, PolyphaseResampler (interp 1, any decimation through the
     strided store; powers of two up to 64 through the all-or-none lane path) and the fused VFO on reference-sized calls,
@@ -1586,7 +1586,7 @@ def test_fft1k_small_calls_vs_oracle(ops, kind, M, ntaps):
     # (FIR from 24 taps; decimators and the VFO where neither the short-filter nor the large-decimation direct kernels win)
     if kind == "fir":
         # (the latency-arranged direct form keeps the calls of up to 2^24 tap-samples: bit-exact, and quicker there)
-        want = ["fir_lat_kernel" if (b - a) * ntaps <= 1 << 24 else "fir_fft1k_kernel" for a, b in zip(cuts, cuts[1:])]
+        want = ["fir_lat_kernel" if (b - a) * ntaps <= 1 << 24 and ntaps <= 320 else "fir_fft1k_kernel" for a, b in zip(cuts, cuts[1:])]
         assert names == want, (names, want)
         assert "fir_fft1k_kernel" in names or ntaps < 97
     if kind != "fir" and ntaps >= 255 and M <= 8:
@@ -1625,9 +1625,16 @@ def test_fft1k_thresholds_and_exclusions(ops, gold, monkeypatch):
         d.process(x[:n], out[:n])
         assert d.last_kernel()["name"] == want, (n, d.last_kernel())
     d.close()
+    # 514-769 taps (at most a quarter .. half of a segment new): calls up to 2^19 samples, and no fir_lat_kernel detour for
+    # filters past 320 taps (a wave would walk 600 taps for each of its 64 outputs: 9.3 us on 4096 samples against 5.6)
     long_taps = np.resize(taps, 600).astype(np.float32)
     g = ops.Fir(long_taps, max_block=0)
-    g.process(x[:1_000_000], out[:1_000_000])
+    for n, want in ((4096, "fir_fft1k_kernel"), (1 << 19, "fir_fft1k_kernel"), (1_000_000, "fir_fft_kernel")):
+        g.process(x[:n], out[:n])
+        assert g.last_kernel()["name"] == want, (n, g.last_kernel())
+    g.close()
+    g = ops.Fir(np.resize(taps, 800).astype(np.float32), max_block=0)
+    g.process(x[:100_000], out[:100_000])
     assert g.last_kernel()["name"] == "fir_fft_kernel"
     g.close()
     # real data: two real segments per wave, up to 2^25 samples at 256 taps; QDSP_HIP_NO_FFT1K_REAL keeps the 4096-point kernel
