@@ -253,6 +253,9 @@ def parse_args(argv=None):
     ap.add_argument("--log2n", type=int, default=27, help="input samples per GPU per step = 2^log2n")
     ap.add_argument("--cpu-seconds", type=float, default=14.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-block-call", action="store_true",
+                    help="skip the `block_call` measurement (profiling runs: its 600 small launches would share kernel names with the "
+                         "timed launches in rocprofv3's per-kernel statistics)")
     ap.add_argument("--no-chain", action="store_true",
                     help="default run (fir256) only: skip the second driver-timed leg, the fused xlating-FIR + decimate-by-8 chain "
                          "(BASELINE configs[2]) reported as the `chain` object of the same JSON line")
@@ -562,7 +565,7 @@ def main():
                              "steps": args.steps, "warmup": args.warmup, "config": chain["config"],
                              "roofline": chain["roofline"], "hbm_roofline_msps": chain["hbm_roofline_msps"],
                              "frac_of_hbm_roofline_msps": chain["frac_of_hbm_roofline_msps"]}
-        if world == 1:
+        if world == 1 and not args.no_block_call:
             # what a block of the reference's graph gets per call (latency-bound: DESIGN.md "Reference-sized calls")
             line["block_call"] = block_call(args.workload, ctx)
             if chain is not None:

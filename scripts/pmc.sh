@@ -12,7 +12,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "TCC_HIT_sum TCC_MISS_sum" \
            "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum"; do
   i=$((i+1))
-  timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/bench.py --workload $W --steps 2 --warmup 1 --kernel-iters 2 --spinup-ms 0 --no-cpu-baseline --no-chain > /dev/null 2> $OUT/p$i.err || echo "pass $i failed"
+  timeout -k 10 200 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/bench.py --workload $W --steps 2 --warmup 1 --kernel-iters 2 --spinup-ms 0 --no-cpu-baseline --no-chain --no-block-call > /dev/null 2> $OUT/p$i.err || echo "pass $i failed"
 done
 python3 - <<PY
 import csv,glob,collections
