@@ -1010,16 +1010,56 @@ bool fft_eligible(const Engine* e, int64_t count) {
     return e->ntaps >= min_taps && count >= env_int("QDSP_HIP_FFT_MIN_COUNT", (int)min_count);
 }
 
+// Spectrum of a short sequence zero-padded to F = 2^m points, FP64 radix-2 (twiddles from sincosl, rounded once): what the
+// overlap-save kernels multiply by.  The direct long-double DFT this replaces cost F x taps x87 operations -- 4-8 ms per
+// handle at 4096 points and 256 taps, on creation and on every retune of a fused VFO; this is ~0.1 ms, and its error
+// (1e-16 x log2 F) stays nine orders below the FP32 rounding of the result.
+void host_spectrum(const std::vector<long double>& gr, const std::vector<long double>& gi, int F, std::vector<double>& re, std::vector<double>& im) {
+    re.assign((size_t)F, 0.0);
+    im.assign((size_t)F, 0.0);
+    int bits = 0;
+    while ((1 << bits) < F) bits++;
+    for (size_t j = 0; j < gr.size() && j < (size_t)F; j++) {
+        unsigned r = 0;
+        for (int b = 0; b < bits; b++) r |= ((j >> b) & 1u) << (bits - 1 - b);
+        re[r] = (double)gr[j];
+        im[r] = (double)gi[j];
+    }
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    std::vector<double> wr((size_t)F / 2), wi((size_t)F / 2);
+    for (int i = 0; i < F / 2; i++) {
+        wr[i] = (double)cosl(two_pi * (long double)i / F);
+        wi[i] = (double)(-sinl(two_pi * (long double)i / F));
+    }
+    for (int len = 2; len <= F; len <<= 1) {
+        const int half = len >> 1, step = F / len;
+        for (int base = 0; base < F; base += len)
+            for (int k = 0; k < half; k++) {
+                const double cr = wr[(size_t)k * step], ci = wi[(size_t)k * step];
+                const double xr = re[base + k + half], xi = im[base + k + half];
+                const double tr = xr * cr - xi * ci, ti = xr * ci + xi * cr;
+                re[base + k + half] = re[base + k] - tr;
+                im[base + k + half] = im[base + k] - ti;
+                re[base + k] += tr;
+                im[base + k] += ti;
+            }
+    }
+}
+
 int fft_prepare(Engine* e) {
     // fused VFO: the spectrum is that of taps[k] * exp(j k dphase) (fft_fir.hip.h), so it follows the NCO
     const unsigned long long key_dphase = e->rotate ? e->dphase : 0;
     if (e->fft_ntaps == e->ntaps && e->d_fft_H && e->fft_dphase == key_dphase) return 0;
     constexpr int F = qk::kFftN;
     const long double two_pi = 6.283185307179586476925286766559005768L;
-    std::vector<long double> cs(F), sn(F);
-    for (int i = 0; i < F; i++) {
-        cs[i] = cosl(two_pi * (long double)i / F);
-        sn[i] = sinl(two_pi * (long double)i / F);
+    std::vector<long double> cs, sn;
+    if (!e->d_fft_H) {   // (the twiddle tables below: once per handle)
+        cs.resize(F);
+        sn.resize(F);
+        for (int i = 0; i < F; i++) {
+            cs[i] = cosl(two_pi * (long double)i / F);
+            sn[i] = sinl(two_pi * (long double)i / F);
+        }
     }
     const int N = e->ntaps;
     // g[j] = taps[N-1-j]:  c[p] = sum_j g[j] s[p-j] = sum_k taps[k] s[p-(N-1)+k];
@@ -1037,22 +1077,17 @@ int fft_prepare(Engine* e) {
         gr[j] = h * c;
         gi[j] = h * sn_;
     }
+    std::vector<double> sre, sim;
+    host_spectrum(gr, gi, F, sre, sim);
     for (int k = 0; k < F; k++) {
-        long double re = 0.0L, im = 0.0L;
-        for (int j = 0; j < N; j++) {
-            const int idx = (int)(((long long)j * k) % F);
-            // (gr + j gi)(cs - j sn)
-            re += gr[j] * cs[idx] + gi[j] * sn[idx];
-            im += gi[j] * cs[idx] - gr[j] * sn[idx];
-        }
         const int k0 = k & 15, k1 = (k >> 4) & 15, k2 = k >> 8;
-        Hp[(k0 * 16 + k1) * 16 + k2] = make_float2((float)(re / F), (float)(im / F));
+        Hp[(k0 * 16 + k1) * 16 + k2] = make_float2((float)(sre[k] / F), (float)(sim[k] / F));
     }
-    for (int t = 0; t < 256; t++)
-        for (int k = 0; k < 16; k++) TA[t * 16 + k] = make_float2((float)cs[(t * k) % F], (float)(-sn[(t * k) % F]));
-    for (int lo = 0; lo < 16; lo++)
-        for (int k = 0; k < 16; k++) TB[lo * 16 + k] = make_float2((float)cs[(16 * lo * k) % F], (float)(-sn[(16 * lo * k) % F]));
     if (!e->d_fft_H) {
+        for (int t = 0; t < 256; t++)
+            for (int k = 0; k < 16; k++) TA[t * 16 + k] = make_float2((float)cs[(t * k) % F], (float)(-sn[(t * k) % F]));
+        for (int lo = 0; lo < 16; lo++)
+            for (int k = 0; k < 16; k++) TB[lo * 16 + k] = make_float2((float)cs[(16 * lo * k) % F], (float)(-sn[(16 * lo * k) % F]));
         HIPCHK(hipMalloc(&e->d_fft_H, sizeof(float2) * F));
         HIPCHK(hipMalloc(&e->d_fft_TA, sizeof(float2) * 256 * 16));
         HIPCHK(hipMalloc(&e->d_fft_TB, sizeof(float2) * 16 * 16));
@@ -1101,10 +1136,14 @@ int fft1k_prepare(Engine* e) {
     if (e->f1k_ntaps == e->ntaps && e->d_f1k_H && e->f1k_dphase == key_dphase) return 0;
     constexpr int F = qk::kFft1kN;
     const long double two_pi = 6.283185307179586476925286766559005768L;
-    std::vector<long double> cs(F), sn(F);
-    for (int i = 0; i < F; i++) {
-        cs[i] = cosl(two_pi * (long double)i / F);
-        sn[i] = sinl(two_pi * (long double)i / F);
+    std::vector<long double> cs, sn;
+    if (!e->d_f1k_H) {   // (the twiddle tables below: once per handle)
+        cs.resize(F);
+        sn.resize(F);
+        for (int i = 0; i < F; i++) {
+            cs[i] = cosl(two_pi * (long double)i / F);
+            sn[i] = sinl(two_pi * (long double)i / F);
+        }
     }
     const int N = e->ntaps;
     // g[j] = taps[N-1-j] (x exp(j (N-1-j) dphase) for the fused VFO), Hf[k] = sum_j g[j] exp(-j 2pi jk/F) / F: as fft_prepare
@@ -1121,23 +1160,20 @@ int fft1k_prepare(Engine* e) {
         gi[j] = h * sn_;
     }
     std::vector<float2> Hp(F), T(64 * 16 + 4 * 16);
+    std::vector<double> sre, sim;
+    host_spectrum(gr, gi, F, sre, sim);
     for (int k = 0; k < F; k++) {
-        long double re = 0.0L, im = 0.0L;
-        for (int j = 0; j < N; j++) {
-            const int idx = (int)(((long long)j * k) % F);
-            re += gr[j] * cs[idx] + gi[j] * sn[idx];
-            im += gi[j] * cs[idx] - gr[j] * sn[idx];
-        }
+        const double re = sre[k], im = sim[k];
         // bin k = ka + 16 (4 g + s) + 256 kb0 sits with lane (ka << 2) | g, entry 4 s + kb0; tables are entry-major
         // ([entry][lane]: a wave's load of one entry is 512 contiguous bytes)
         const int ka = k & 15, kb1 = (k >> 4) & 15, kb0 = k >> 8;
         Hp[(4 * (kb1 & 3) + kb0) * 64 + ((ka << 2) | (kb1 >> 2))] = make_float2((float)(re / F), (float)(im / F));
     }
-    for (int l = 0; l < 64; l++)
-        for (int k = 0; k < 16; k++) T[k * 64 + l] = make_float2((float)cs[(l * k) % F], (float)(-sn[(l * k) % F]));
-    for (int j = 0; j < 4; j++)
-        for (int k = 0; k < 16; k++) T[1024 + k * 4 + j] = make_float2((float)cs[(16 * j * k) % F], (float)(-sn[(16 * j * k) % F]));
     if (!e->d_f1k_H) {
+        for (int l = 0; l < 64; l++)
+            for (int k = 0; k < 16; k++) T[k * 64 + l] = make_float2((float)cs[(l * k) % F], (float)(-sn[(l * k) % F]));
+        for (int j = 0; j < 4; j++)
+            for (int k = 0; k < 16; k++) T[1024 + k * 4 + j] = make_float2((float)cs[(16 * j * k) % F], (float)(-sn[(16 * j * k) % F]));
         HIPCHK(hipMalloc(&e->d_f1k_H, sizeof(float2) * F));
         if (hipMalloc(&e->d_f1k_T, sizeof(float2) * T.size()) != hipSuccess) {
             (void)hipFree(e->d_f1k_H);
