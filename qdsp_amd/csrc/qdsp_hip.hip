@@ -838,8 +838,14 @@ AnyPlan any_plan(int L, int M, int P, int ch, long long nout = -1) {
         // large decimations (taps split over the lanes of an output): down to 16 outputs per tile = 16 lanes per output, as long
         // as a lane keeps 16 taps -- the VFO's 401 taps / 50 on a 1e6-sample block: 100 dependent MACs per lane -> 25
         if (ks_ok && want > 0) {
-            if (tile > kSplitTile && (nout + kSplitTile - 1) / kSplitTile < 4 * want && P >= 64) tile = kSplitTile;
-            while (tile > 16 && tile <= kSplitTile && (nout + tile - 1) / tile < want && P / (2 * NT / tile) >= 16) tile /= 2;
+            if (tile > kSplitTile && (nout + kSplitTile - 1) / kSplitTile <= 768 && P >= 64) tile = kSplitTile;
+            // (... and as long as the halved tiles still fit one round of the chip: the NCO variant keeps 3 workgroups per CU
+            // resident, and a 769th workgroup waits for a whole round -- 401-513 taps / 40-64 on 1e6 samples: 9.4-9.5 us with
+            // 783-978 tiles against 7.3-7.4 with 392-490)
+            const long long tmin = env_int("QDSP_HIP_ANY_MIN_SPLIT_TILE", 16);
+            while (tile > tmin && tile <= kSplitTile && (nout + tile - 1) / tile < want && (nout + tile / 2 - 1) / (tile / 2) <= 768 &&
+                   P / (2 * NT / tile) >= 16)
+                tile /= 2;
         }
     }
     // a half-workgroup tile with a long tap loop: the quarter tile with four lanes per output is faster (M = 50,
