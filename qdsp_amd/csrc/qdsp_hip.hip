@@ -1309,17 +1309,19 @@ int pfb_prepare(Engine* e) {
     for (int i = 0; i < F; i++) { cs[i] = cosl(two_pi * i / F); ss[i] = sinl(two_pi * i / F); }
     std::vector<float2> tab((size_t)qk::kPfbTableElems, make_float2(0.0f, 0.0f));
     // G: row (k0*64 + kq*8 + c), element kg: spectrum of column c's filter gamma_c[q] = g[8q + 7 - c] at bin k0 + 8 kq + 64 kg, / 512
-    for (int c = 0; c < D; c++)
-        for (int k = 0; k < F; k++) {
-            long double re = 0.0L, im = 0.0L;
-            for (int q = 0; q < Q; q++) {
-                const int j = D * q + (D - 1 - c), idx = (int)(((long long)q * k) % F);
-                re += gr[j] * cs[idx] + gi[j] * ss[idx];      // (gr + j gi)(cs - j ss)
-                im += gi[j] * cs[idx] - gr[j] * ss[idx];
-            }
-            const int k0 = k & 7, kq = (k >> 3) & 7, kg = k >> 6;
-            tab[(size_t)((k0 * 64 + kq * 8 + c) * R + kg)] = make_float2((float)(re / F), (float)(im / F));
+    for (int c = 0; c < D; c++) {
+        std::vector<long double> cr((size_t)Q), ci((size_t)Q);
+        for (int q = 0; q < Q; q++) {
+            cr[q] = gr[D * q + (D - 1 - c)];
+            ci[q] = gi[D * q + (D - 1 - c)];
         }
+        std::vector<double> sre, sim;
+        host_spectrum(cr, ci, F, sre, sim);      // (FP64 radix-2 FFT: see fft_prepare)
+        for (int k = 0; k < F; k++) {
+            const int k0 = k & 7, kq = (k >> 3) & 7, kg = k >> 6;
+            tab[(size_t)((k0 * 64 + kq * 8 + c) * R + kg)] = make_float2((float)(sre[k] / F), (float)(sim[k] / F));
+        }
+    }
     float2* TW = tab.data() + 512 * R;     // row (k0*8 + kq), element g': W512^(g' (k0 + 8 kq))
     for (int k0 = 0; k0 < 8; k0++)
         for (int kq = 0; kq < 8; kq++)
