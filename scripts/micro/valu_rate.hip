@@ -102,7 +102,7 @@ template <int MODE> __global__ void k(float* out, int iters, float s) {
 }
 
 template <int MODE> void run(const char* name, float* d) {
-    for (int wps = 1; wps <= 2; wps *= 2) {
+    for (int wps = 1; wps <= 4; wps *= 2) {
         const int iters = 4000, grid = 256 * 4 * wps;     // wps waves per SIMD (one 64-thread block = one wave)
         hipEvent_t e0, e1;
         hipEventCreate(&e0);
