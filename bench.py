@@ -403,7 +403,7 @@ def run_workload(name: str, args, ctx) -> dict:
     # the overlap-save kernel: 6 radix-16 passes + 4 twiddle passes + spectrum product per
     # 4096-point block = 1524 FLOP/lane x 256 lanes / (4097 - ntaps) valid outputs.
     flops = w["flops"]
-    if kinfo["name"] == "fir_fft_kernel":
+    if kinfo["name"] in ("fir_fft_kernel", "fir_fft_dma_kernel", "fir_fft_dmapk_kernel"):
         flops = 1524.0 * 256 / (4097 - w["ntaps"])
     elif kinfo["name"] == "pfb_dec8_kernel":
         # polyphase overlap-save, one wave per segment of 4096 inputs: ~2860 VALU instructions per wave (PMC), of which

@@ -41,8 +41,11 @@
 // SIMDs once two waves share a SIMD, need no shuffles, and fit in 126 VGPRs (4 waves/SIMD).
 #include "fft_fir.hip.h"
 #include "cfft.hip.h"
+#include "cpk.hip.h"
 
 namespace qk {
+
+typedef float f4v __attribute__((ext_vector_type(4)));
 
 // Column of element e in LDS layout 1 ([k0][element], row pitch kFftRow1 = 272): even elements
 // first, odd elements from column 136.  Keeps the pass-A writes (lanes own elements 2l', then
@@ -404,6 +407,456 @@ __global__ __launch_bounds__(kFftNT, (DEC == 1 && !ROT && !REAL) ? 4 : 3) void f
     }
 }
 
+// ---- fir_fft_dma_kernel (round 3): FIR<complex_t>, interior segments fed by LDS-DMA ------------------------------
+// The same transform as fir_fft_kernel<1> (passes, tables, rounding: bit-identical results), re-arranged around what the
+// ablation of that kernel showed (profiles/r03_ablate_fir_fft.txt): arithmetic + LDS + barriers alone take 0.335 ms per
+// 2^27 samples, the loads add 0.05 ms and the stores 0.08 ms -- a workgroup's wait for its next segment (vmcnt counts in
+// order) also waits until the eight stores it has just issued are acknowledged.  Here
+//   * the NEXT segment is requested before this segment's last pass: `global_load_lds_dwordx4` straight into the exchange
+//     buffer (no VGPRs: the kernel stays at 4 waves per SIMD), issued right after the last read of the inverse (r4), so it
+//     travels under pass A' and the stores, and is OLDER than those stores in the vmcnt order: the wait at the top of the
+//     next segment is `vmcnt(8)` -- the eight stores stay in flight and are never waited for;
+//   * a lane owns one column of the segment (elements te + 256 n2) in passes A / A'; a wave only ever touches ITS 64 columns
+//     between the last barrier of a segment and the first of the next, so the DMA (sixteen 512-byte half-wave requests,
+//     one per row, into the wave's own columns), the raw read-back and the in-place write of pass A need no barrier:
+//     seven barriers per segment instead of eight, and none of them drains the vector-memory counter (raw s_barrier behind
+//     an LDS-only wait; `__syncthreads()` would wait for the DMA and the stores);
+//   * layout 1 is plain [row][column] (the DMA delivers pairs of samples, so fir_fft_kernel's even/odd split is not
+//     available): lanes l / l + 16 own adjacent columns, which keeps every ds_read_b64 group on one contiguous 256-byte run
+//     (the in-place ds_write_b64 of pass A is 2-way conflicted: 8 LDS cycles against the 6 the instruction takes anyway)
+//     and lets a v_permlane16_swap build the 16-byte stores.
+// Segments that touch the history or the end of the input take guarded loads into registers as in fir_fft_kernel.
+// The DMA instruction is inline asm (it must not enter hipcc's own vmcnt bookkeeping, which would drain it together with
+// the stores at the next barrier): M0 is saved and restored inside the statement (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void dma16_to_lds(const void* sbase, unsigned voff, unsigned lds_byte) {   // sbase, lds_byte wave-uniform
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+}
+__device__ __forceinline__ void dma16_to_lds_nt(const void* sbase, unsigned voff, unsigned lds_byte) {   // the same, non-temporal
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+}
+#define QK_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+__global__ __launch_bounds__(kFftNT, 4) void fir_fft_dma_kernel(const FftArgs a) {
+    __shared__ __attribute__((aligned(16))) float2 lds[kFftLdsElems + 16 * 17];
+    float2* tbl = lds + kFftLdsElems;  // pass-B twiddles W256^(lo*k), rows padded to 17
+    const int t = threadIdx.x;
+    const int hi = t >> 4, lo = t & 15;
+    const int H = a.H;
+    // Column of the segment this lane owns in passes A / A' (elements te + 256 n2).  Lanes l and l + 16 own the adjacent
+    // columns 2c, 2c + 1, so that lanes 0-15 / 16-31 of a half-wave read the even / odd elements of sixteen consecutive
+    // pairs (one contiguous 256-byte run per ds_read_b64 group) and a v_permlane16_swap pairs them up for 16-byte stores.
+    const int half = (t >> 4) & 1;
+    const int te = (t & ~31) | ((t & 15) << 1) | half;
+
+    if ((int)blockIdx.x == a.nwg) {   // history hand-over (filter.h:71): last H samples of hist ++ in
+        for (int i = t; i < H; i += kFftNT) {
+            const long long g = a.count - H + i;
+            a.hist_next[i] = g < 0 ? a.hist_keep[g + H] : a.in[g];
+        }
+        return;
+    }
+    float2 ta[16], hf[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        hf[k] = a.Hf[t * 16 + k];
+        ta[k] = a.TA[te * 16 + k];
+    }
+    tbl[(t >> 4) * 17 + (t & 15)] = a.TB[t];
+    const float2* tb = tbl + lo * 17;
+    // the table loads are waited for HERE: left to hipcc, the wait (vmcnt(0): stores and DMA included) lands at their
+    // first use, inside the segment loop
+    {
+        float touch = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) touch += hf[k].x + hf[k].y + (k ? ta[k].x + ta[k].y : 0.0f);
+        asm volatile("" ::"v"(touch));
+    }
+    __syncthreads();
+
+    // this wave's 64 columns of row 0 as an LDS byte address, its first column, and the lane's byte offset in a row request
+    const int wcol = __builtin_amdgcn_readfirstlane(t & ~63);
+    const unsigned lds_cols = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds) + (unsigned)wcol * 8u;
+    const unsigned voff = (unsigned)(t & 31) * 16u;
+    auto seg_start = [&](int b) { return (long long)b * a.L - a.seg_shift; };
+    auto is_interior = [&](int b) {
+        const long long s0 = seg_start(b);
+        return b < a.nblocks && s0 >= 0 && s0 + kFftN <= a.count;
+    };
+    auto request = [&](int b) {   // rows 0..15 of segment b -> this wave's columns (lanes 0-31: 512 bytes per row)
+        const float2* src = a.in + seg_start(b) + wcol;
+        if ((t & 32) == 0) {
+#pragma unroll
+            for (int n2 = 0; n2 < 16; n2++) dma16_to_lds(src + n2 * 256, voff, lds_cols + (unsigned)(n2 * kFftRow1) * 8u);
+        }
+    };
+
+    int b = blockIdx.x;
+    bool landed_in_lds = false, eight_younger = false;
+    if (b < a.nblocks && is_interior(b)) {
+        request(b);
+        landed_in_lds = true;
+    }
+    for (; b < a.nblocks; b += a.nwg) {
+        const long long seg0 = seg_start(b);
+        float2 v[16];
+        if (landed_in_lds) {
+            if (eight_younger) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            // first / last segments: guarded loads, parked in the wave's own columns so that both kinds of segment continue
+            // through the same read-back (hipcc's wait-count pass merges the two paths: loads still pending at the join
+            // would put an `s_waitcnt vmcnt(0)` -- stores included -- in front of the fast path's read-back)
+            // (all per-lane indices are 32-bit offsets from wave-uniform bases: 64-bit per-lane pointers hoisted out of
+            // the segment loop were what spilled)
+            const int first_in = seg0 < 0 ? (int)-seg0 : 0;                                          // elements below: history / zeros
+            const int end_in = a.count - seg0 < kFftN ? (int)(a.count - seg0) : kFftN;               // elements from here on: zeros
+            const float2* __restrict__ seg_in = a.in + seg0;
+            const float2* __restrict__ seg_hist = a.hist + (H - first_in);                           // element i < first_in -> hist[i - first_in + H]
+            int tev = te;
+            asm volatile("" : "+v"(tev));   // opaque: keeps hipcc from hoisting sixteen 64-bit per-lane addresses out of the segment loop
+#pragma unroll
+            for (int n2 = 0; n2 < 16; n2++) {
+                const int i = n2 * 256 + tev;
+                float2 x = make_float2(0.0f, 0.0f);
+                if (i < first_in) { if (i - first_in + H >= 0) x = seg_hist[i]; }
+                else if (i < end_in) x = seg_in[i];
+                lds[n2 * kFftRow1 + te] = x;
+            }
+        }
+#pragma unroll
+        for (int n2 = 0; n2 < 16; n2++) v[n2] = lds[n2 * kFftRow1 + te];
+        // ---- pass A (over n2) + twiddle W4096^(t*k0), written back in place (the wave's own columns) ------------
+        fft16<false>(v);
+#pragma unroll
+        for (int k = 0; k < 16; k++) lds[k * kFftRow1 + te] = (k == 0) ? v[rev16(0)] : cmulc<false>(v[rev16(k)], ta[k]);
+        QK_LDS_BARRIER();
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] = lds[hi * kFftRow1 + j * 16 + lo];
+        // ---- pass B (over n1) + twiddle W256^(n0*k1) -----------------------------------------------------------
+        fft16<false>(v);
+        QK_LDS_BARRIER();
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            lds[(hi * 16 + k) * kFftRow2 + lo] = (k == 0) ? v[rev16(0)] : cmulc<false>(v[rev16(k)], tb[k]);
+        QK_LDS_BARRIER();
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] = lds[t * kFftRow2 + j];
+        // ---- pass C (over n0), spectrum * Hf, pass C' (over k2) ---------------------------------------------------
+        fft16<false>(v);
+        float2 y[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) y[k] = cmulc<false>(v[rev16(k)], hf[k]);
+        fft16<true>(y);
+        QK_LDS_BARRIER();
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            lds[t * kFftRow2 + j] = (j == 0) ? y[rev16(0)] : cmulc<true>(y[rev16(j)], tb[j]);
+        QK_LDS_BARRIER();
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] = lds[(hi * 16 + j) * kFftRow2 + lo];
+        // ---- pass B' (over k1) --------------------------------------------------------------------------------------
+        fft16<true>(v);
+        QK_LDS_BARRIER();
+#pragma unroll
+        for (int j = 0; j < 16; j++) lds[hi * kFftRow1 + j * 16 + lo] = v[rev16(j)];
+        QK_LDS_BARRIER();
+        float2 e[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) e[k] = lds[k * kFftRow1 + te];
+        // ---- the next segment's samples: requested now, into the columns this wave has just read ---------------------
+        const int nb = b + a.nwg;
+        landed_in_lds = is_interior(nb);
+        if (landed_in_lds) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads above have returned
+            request(nb);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = (k == 0) ? e[k] : cmulc<true>(e[k], ta[k]);
+        // ---- pass A' (over k0) and store the L valid outputs --------------------------------------------------------
+        fft16<true>(v);
+        eight_younger = false;
+        if (seg0 >= 0 && seg0 + kFftN <= a.nout) {
+            // 16-byte stores: the lane with half == 0 stores both columns of its pair for rows 0-7, its partner for rows 8-15
+            // (one wave instruction = four 256-byte runs: two of row r, two of row r + 8)
+            f4v* __restrict__ o4 = reinterpret_cast<f4v*>(a.out + seg0);   // wave-uniform; 16-byte units
+            int pair = (te >> 1) + half * 8 * 128;
+            asm volatile("" : "+v"(pair));   // (as above)
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const float2 lo_row = v[rev16(r)], hi_row = v[rev16(8 + r)];
+                const auto sx = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo_row.x), __float_as_uint(hi_row.x), false, false);
+                const auto sy = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo_row.y), __float_as_uint(hi_row.y), false, false);
+                // now (x,y | z,w) = columns (te & ~1, +1) of row half*8 + r
+                if ((half * 8 + r) * 256 + (te & ~1) >= a.ov)   // ov is even: both elements or neither
+                    o4[pair + r * 128] = (f4v){__uint_as_float(sx[0]), __uint_as_float(sy[0]), __uint_as_float(sx[1]), __uint_as_float(sy[1])};
+            }
+            eight_younger = true;   // (rows 8..15 always lie past the overlap: ov <= 2048 on this path, so all eight are issued)
+        } else {
+            const int first_out = seg0 < 0 ? (int)-seg0 : 0;                                          // output index >= 0
+            const int from = a.ov > first_out ? a.ov : first_out;
+            const int end_out = a.nout - seg0 < kFftN ? (int)(a.nout - seg0) : kFftN;
+            float2* __restrict__ seg_out = a.out + seg0;
+            int tev = te;
+            asm volatile("" : "+v"(tev));   // (as above)
+#pragma unroll
+            for (int n2 = 0; n2 < 16; n2++) {
+                const int i = n2 * 256 + tev;
+                if (i >= from && i < end_out) seg_out[i] = v[rev16(n2)];
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---- fir_fft_dmapk_kernel: the same kernel with its complex arithmetic on packed FP32 pairs -------------------------------
+// PMC of fir_fft_dma_kernel (profiles/r03_pmc_fir_fft_dma_kernel.json): waits 39 % -> 20 % of the wave cycles, issue stalls 30 % ->
+// 45 %: with the memory waits gone the kernel is VALU-issue-bound at ~4.1 cycles per instruction (5261 instructions per segment).
+// Packed instructions do two lanes' worth per issue: v_pk_add_f32 for the butterflies' adds, and a complex product is two
+// instructions -- v_pk_mul_f32 + v_pk_fma_f32 with the swap on op_sel and the ONE-lane sign on neg_lo / neg_hi (inline asm:
+// hipcc folds whole-vector negation only) -- instead of 2 v_mul + 2 v_fmac.
+template <bool CONJ> __device__ __forceinline__ v2f pk_cmul2(v2f a, v2f b) {   // a * b, CONJ: a * conj(b)
+    v2f r;
+    if (!CONJ)
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+            : "=&v"(r) : "v"(a), "v"(b));
+    else
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+            : "=&v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// STAMPS: diagnostic build (never shipped to a caller: launch_fir_fft takes it only when FftArgs::stamps is set, which only
+// scripts/stamp_fir_fft.py does): every wave sums, per phase of the segment loop, the shader-clock ticks (s_memtime) it
+// spent there; wave 0 of each workgroup writes its sixteen sums to stamps[blockIdx.x * 16 ..].  Nothing is computed from them.
+template <bool CONJ, int ABL> __device__ __forceinline__ v2f abl_cmul(v2f a, v2f b) {
+    if (ABL & 1) return a;
+    return pk_cmul2<CONJ>(a, b);
+}
+
+// ABL: ablations for profiles/r03_ablate_fir_fft_dmapk.txt (diagnostic builds): 1 = no arithmetic (the LDS exchanges, barriers, DMA and stores
+// stay), 2 = no global stores, 4 = no DMA (the segments are whatever lies in LDS).
+template <bool STAMPS, int ABL = 0>
+__global__ __launch_bounds__(kFftNT, 4) void fir_fft_dmapk_kernel(const FftArgs a) {
+    __shared__ __attribute__((aligned(16))) v2f lds[kFftLdsElems + 16 * 17];
+    v2f* tbl = lds + kFftLdsElems;  // pass-B twiddles W256^(lo*k), rows padded to 17
+    const int t = threadIdx.x;
+    const int hi = t >> 4, lo = t & 15;
+    const int H = a.H;
+    // Column of the segment this lane owns in passes A / A' (elements te + 256 n2).  Lanes l and l + 16 own the adjacent
+    // columns 2c, 2c + 1, so that lanes 0-15 / 16-31 of a half-wave read the even / odd elements of sixteen consecutive
+    // pairs (one contiguous 256-byte run per ds_read_b64 group) and a v_permlane16_swap pairs them up for 16-byte stores.
+    const int half = (t >> 4) & 1;
+    const int te = (t & ~31) | ((t & 15) << 1) | half;
+
+    if ((int)blockIdx.x == a.nwg) {   // history hand-over (filter.h:71): last H samples of hist ++ in
+        for (int i = t; i < H; i += kFftNT) {
+            const long long g = a.count - H + i;
+            a.hist_next[i] = g < 0 ? a.hist_keep[g + H] : a.in[g];
+        }
+        return;
+    }
+    v2f ta[16], hf[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        hf[k] = reinterpret_cast<const v2f*>(a.Hf)[t * 16 + k];
+        ta[k] = reinterpret_cast<const v2f*>(a.TA)[te * 16 + k];
+    }
+    tbl[(t >> 4) * 17 + (t & 15)] = reinterpret_cast<const v2f*>(a.TB)[t];
+    const v2f* tb = tbl + lo * 17;
+    // the table loads are waited for HERE: left to hipcc, the wait (vmcnt(0): stores and DMA included) lands at their
+    // first use, inside the segment loop
+    {
+        float touch = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) touch += hf[k].x + hf[k].y + (k ? ta[k].x + ta[k].y : 0.0f);
+        asm volatile("" ::"v"(touch));
+    }
+    __syncthreads();
+
+    // this wave's 64 columns of row 0 as an LDS byte address, its first column, and the lane's byte offset in a row request
+    const int wcol = __builtin_amdgcn_readfirstlane(t & ~63);
+    const unsigned lds_cols = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds) + (unsigned)wcol * 8u;
+    const unsigned voff = (unsigned)(t & 31) * 16u;
+    auto seg_start = [&](int b) { return (long long)b * a.L - a.seg_shift; };
+    auto is_interior = [&](int b) {
+        const long long s0 = seg_start(b);
+        return b < a.nblocks && s0 >= 0 && s0 + kFftN <= a.count;
+    };
+    auto request = [&](int b) {   // rows 0..15 of segment b -> this wave's columns (lanes 0-31: 512 bytes per row)
+        const float2* src = a.in + seg_start(b) + wcol;
+        if ((t & 32) == 0 && !(ABL & 4)) {
+            if (a.nt & 1) {   // rows 0 and 15 hold the overlap the neighbouring segments read as well: those stay cacheable
+#pragma unroll
+                for (int n2 = 0; n2 < 16; n2++) {
+                    if (n2 == 0 || n2 == 15) dma16_to_lds(src + n2 * 256, voff, lds_cols + (unsigned)(n2 * kFftRow1) * 8u);
+                    else dma16_to_lds_nt(src + n2 * 256, voff, lds_cols + (unsigned)(n2 * kFftRow1) * 8u);
+                }
+            } else {
+#pragma unroll
+                for (int n2 = 0; n2 < 16; n2++) dma16_to_lds(src + n2 * 256, voff, lds_cols + (unsigned)(n2 * kFftRow1) * 8u);
+            }
+        }
+    };
+
+    unsigned acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tick = 0;
+    if constexpr (STAMPS) tick = __builtin_amdgcn_s_memtime();
+#define QK_STAMP(i)                                                          \
+    if constexpr (STAMPS) {                                                  \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();        \
+        acc[i] += (unsigned)(now_ - tick);                                   \
+        tick = now_;                                                         \
+    }
+    int b = blockIdx.x;
+    bool landed_in_lds = false, eight_younger = false;
+    if (b < a.nblocks && is_interior(b)) {
+        request(b);
+        landed_in_lds = true;
+    }
+    for (; b < a.nblocks; b += a.nwg) {
+        const long long seg0 = seg_start(b);
+        v2f v[16];
+        QK_STAMP(15)   // pass A', stores, loop control
+        if (landed_in_lds) {
+            if (eight_younger) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            QK_STAMP(0)   // wait for the DMA
+        } else {
+            // first / last segments: guarded loads, parked in the wave's own columns so that both kinds of segment continue
+            // through the same read-back (hipcc's wait-count pass merges the two paths: loads still pending at the join
+            // would put an `s_waitcnt vmcnt(0)` -- stores included -- in front of the fast path's read-back)
+            // (all per-lane indices are 32-bit offsets from wave-uniform bases: 64-bit per-lane pointers hoisted out of
+            // the segment loop were what spilled)
+            const int first_in = seg0 < 0 ? (int)-seg0 : 0;                                          // elements below: history / zeros
+            const int end_in = a.count - seg0 < kFftN ? (int)(a.count - seg0) : kFftN;               // elements from here on: zeros
+            const float2* __restrict__ seg_in = a.in + seg0;
+            const float2* __restrict__ seg_hist = a.hist + (H - first_in);                           // element i < first_in -> hist[i - first_in + H]
+            int tev = te;
+            asm volatile("" : "+v"(tev));   // opaque: keeps hipcc from hoisting sixteen 64-bit per-lane addresses out of the segment loop
+#pragma unroll
+            for (int n2 = 0; n2 < 16; n2++) {
+                const int i = n2 * 256 + tev;
+                float2 x = make_float2(0.0f, 0.0f);
+                if (i < first_in) { if (i - first_in + H >= 0) x = seg_hist[i]; }
+                else if (i < end_in) x = seg_in[i];
+                lds[n2 * kFftRow1 + te] = mk2(x.x, x.y);
+            }
+        }
+#pragma unroll
+        for (int n2 = 0; n2 < 16; n2++) v[n2] = lds[n2 * kFftRow1 + te];
+        // ---- pass A (over n2) + twiddle W4096^(t*k0), written back in place (the wave's own columns) ------------
+        if (!(ABL & 1)) pk_fft16<false>(v);
+#pragma unroll
+        for (int k = 0; k < 16; k++) lds[k * kFftRow1 + te] = (k == 0) ? v[rev16(0)] : abl_cmul<false, ABL>(v[rev16(k)], ta[k]);
+        QK_STAMP(1)
+        QK_LDS_BARRIER();
+        QK_STAMP(2)
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] = lds[hi * kFftRow1 + j * 16 + lo];
+        // ---- pass B (over n1) + twiddle W256^(n0*k1) -----------------------------------------------------------
+        if (!(ABL & 1)) pk_fft16<false>(v);
+        QK_STAMP(3)
+        QK_LDS_BARRIER();
+        QK_STAMP(4)
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            lds[(hi * 16 + k) * kFftRow2 + lo] = (k == 0) ? v[rev16(0)] : abl_cmul<false, ABL>(v[rev16(k)], tb[k]);
+        QK_STAMP(5)
+        QK_LDS_BARRIER();
+        QK_STAMP(6)
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] = lds[t * kFftRow2 + j];
+        // ---- pass C (over n0), spectrum * Hf, pass C' (over k2) ---------------------------------------------------
+        if (!(ABL & 1)) pk_fft16<false>(v);
+        v2f y[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) y[k] = abl_cmul<false, ABL>(v[rev16(k)], hf[k]);
+        if (!(ABL & 1)) pk_fft16<true>(y);
+        QK_STAMP(7)
+        QK_LDS_BARRIER();
+        QK_STAMP(8)
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            lds[t * kFftRow2 + j] = (j == 0) ? y[rev16(0)] : abl_cmul<true, ABL>(y[rev16(j)], tb[j]);
+        QK_STAMP(9)
+        QK_LDS_BARRIER();
+        QK_STAMP(10)
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] = lds[(hi * 16 + j) * kFftRow2 + lo];
+        // ---- pass B' (over k1) --------------------------------------------------------------------------------------
+        if (!(ABL & 1)) pk_fft16<true>(v);
+        QK_STAMP(11)
+        QK_LDS_BARRIER();
+        QK_STAMP(12)
+#pragma unroll
+        for (int j = 0; j < 16; j++) lds[hi * kFftRow1 + j * 16 + lo] = v[rev16(j)];
+        QK_STAMP(13)
+        QK_LDS_BARRIER();
+        QK_STAMP(14)
+        v2f e[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) e[k] = lds[k * kFftRow1 + te];
+        // ---- the next segment's samples: requested now, into the columns this wave has just read ---------------------
+        const int nb = b + a.nwg;
+        landed_in_lds = is_interior(nb);
+        if (landed_in_lds) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads above have returned
+            request(nb);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = (k == 0) ? e[k] : abl_cmul<true, ABL>(e[k], ta[k]);
+        // ---- pass A' (over k0) and store the L valid outputs --------------------------------------------------------
+        if (!(ABL & 1)) pk_fft16<true>(v);
+        eight_younger = false;
+        if (seg0 >= 0 && seg0 + kFftN <= a.nout) {
+            // 16-byte stores: the lane with half == 0 stores both columns of its pair for rows 0-7, its partner for rows 8-15
+            // (one wave instruction = four 256-byte runs: two of row r, two of row r + 8)
+            f4v* __restrict__ o4 = reinterpret_cast<f4v*>(a.out + seg0);   // wave-uniform; 16-byte units
+            int pair = (te >> 1) + half * 8 * 128;
+            asm volatile("" : "+v"(pair));   // (as above)
+            const bool nts = (a.nt & 2) != 0;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const v2f lo_row = v[rev16(r)], hi_row = v[rev16(8 + r)];
+                const auto sx = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo_row.x), __float_as_uint(hi_row.x), false, false);
+                const auto sy = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo_row.y), __float_as_uint(hi_row.y), false, false);
+                // now (x,y | z,w) = columns (te & ~1, +1) of row half*8 + r
+                if ((half * 8 + r) * 256 + (te & ~1) >= a.ov) {   // ov is even: both elements or neither
+                    const f4v o = {__uint_as_float(sx[0]), __uint_as_float(sy[0]), __uint_as_float(sx[1]), __uint_as_float(sy[1])};
+                    if (ABL & 2) { if (o.x == 1.2345e30f) o4[pair + r * 128] = o; }
+                    else if (nts) __builtin_nontemporal_store(o, o4 + pair + r * 128);
+                    else o4[pair + r * 128] = o;
+                }
+            }
+            eight_younger = true;   // (rows 8..15 always lie past the overlap: ov <= 2048 on this path, so all eight are issued)
+        } else {
+            const int first_out = seg0 < 0 ? (int)-seg0 : 0;                                          // output index >= 0
+            const int from = a.ov > first_out ? a.ov : first_out;
+            const int end_out = a.nout - seg0 < kFftN ? (int)(a.nout - seg0) : kFftN;
+            v2f* __restrict__ seg_out = reinterpret_cast<v2f*>(a.out) + seg0;
+            int tev = te;
+            asm volatile("" : "+v"(tev));   // (as above)
+#pragma unroll
+            for (int n2 = 0; n2 < 16; n2++) {
+                const int i = n2 * 256 + tev;
+                if (i >= from && i < end_out) seg_out[i] = v[rev16(n2)];
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (STAMPS) {
+        if (t == 0) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) a.stamps[(long long)blockIdx.x * 16 + q] = acc[q];
+        }
+    }
+#undef QK_STAMP
+}
+
 // Decimating variant, grouped: one workgroup runs the forward half (load [+NCO], passes
 // A, B, C, spectrum product, pass C') of DEC consecutive segments, each leaving only its
 // 16/DEC wanted values of n0 per lane in an LDS staging area; then ONE full-width inverse
@@ -612,7 +1065,15 @@ int launch_fir_fft(const FftArgs& a, int grid, hipStream_t stream) {
     const bool r = a.rot != 0;
     switch (a.dec) {
         case 1:  // FIR, or any-decimation resampler / VFO through the strided store (a.decm)
-            if (a.real2) hipLaunchKernelGGL((fir_fft_kernel<1, false, true>), dim3(grid), dim3(kFftNT), 0, stream, a);
+            if (a.dma == 2 && a.abl == 1) hipLaunchKernelGGL((fir_fft_dmapk_kernel<false, 1>), dim3(grid), dim3(kFftNT), 0, stream, a);
+            else if (a.dma == 2 && a.abl == 2) hipLaunchKernelGGL((fir_fft_dmapk_kernel<false, 2>), dim3(grid), dim3(kFftNT), 0, stream, a);
+            else if (a.dma == 2 && a.abl == 4) hipLaunchKernelGGL((fir_fft_dmapk_kernel<false, 4>), dim3(grid), dim3(kFftNT), 0, stream, a);
+            else if (a.dma == 2 && a.abl == 6) hipLaunchKernelGGL((fir_fft_dmapk_kernel<false, 6>), dim3(grid), dim3(kFftNT), 0, stream, a);
+            else if (a.dma == 2 && a.abl == 7) hipLaunchKernelGGL((fir_fft_dmapk_kernel<false, 7>), dim3(grid), dim3(kFftNT), 0, stream, a);
+            else if (a.dma == 2 && a.stamps) hipLaunchKernelGGL(fir_fft_dmapk_kernel<true>, dim3(grid), dim3(kFftNT), 0, stream, a);
+            else if (a.dma == 2) hipLaunchKernelGGL(fir_fft_dmapk_kernel<false>, dim3(grid), dim3(kFftNT), 0, stream, a);
+            else if (a.dma) hipLaunchKernelGGL(fir_fft_dma_kernel, dim3(grid), dim3(kFftNT), 0, stream, a);
+            else if (a.real2) hipLaunchKernelGGL((fir_fft_kernel<1, false, true>), dim3(grid), dim3(kFftNT), 0, stream, a);
             else if (r) hipLaunchKernelGGL((fir_fft_kernel<1, true>), dim3(grid), dim3(kFftNT), 0, stream, a);
             else hipLaunchKernelGGL((fir_fft_kernel<1, false>), dim3(grid), dim3(kFftNT), 0, stream, a);
             break;

@@ -50,6 +50,10 @@ struct FftArgs {
     int vec;                  // 1: in/out 16-byte aligned and segments start on even samples -> float4 path
     int grouped;              // dec >= 4: 1 = fir_fft_dec_kernel (groups of dec segments), 0 = one segment per workgroup
     int m_shift;              // fir_fft1k_kernel, strided: log2(decm) when decm is a power of two <= 64 (a lane keeps all or none of its 16 elements), else -1
+    int abl;                  // diagnostic builds of fir_fft_dmapk_kernel: ablation mask (0: the product)
+    unsigned* stamps;         // diagnostic build of fir_fft_dmapk_kernel only: [grid][16] per-phase tick sums (nullptr: off)
+    int nt;                   // fir_fft_dmapk_kernel: bit 0 = non-temporal DMA of the rows no neighbour re-reads, bit 1 = non-temporal stores
+    int dma;                  // 1: fir_fft_dma_kernel (FIR<complex_t>, 16-byte aligned in / out, overlap <= 2048): segments arrive by LDS-DMA
     int real2;                // 1: real samples (4-byte in/out/hist); block b = real segments 2b (re) and 2b+1 (im)
     // NCO (rot only).  x[j] exp(j phi(j)) filtered by h == exp(j phi(p - (N-1))) * (x filtered by
     // h[k] exp(j k dphase)) at output position p: the input is never rotated, only the KEPT outputs are.

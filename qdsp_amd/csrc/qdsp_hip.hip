@@ -1490,6 +1490,11 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
     // Decimators work in groups of `dec` segments, 2 resident per CU (70 KB LDS).
     // (grouped only when the groups fill the chip -- measured crossover ~1000 groups, 2^25 samples at decimation 8 --
     // below that the segments run one per workgroup: a 1e6-sample block 10 us instead of 28)
+    // FIR<complex_t> on aligned buffers: the LDS-DMA form (fir_fft_dma_kernel, fft_fir.hip)
+    a.nt = env_int("QDSP_HIP_FFT_NT", 0);
+    a.abl = env_int("QDSP_HIP_FFT_ABL", 0);
+    if (const char* st = getenv("QDSP_HIP_FFT_STAMPS")) a.stamps = reinterpret_cast<unsigned*>(strtoull(st, nullptr, 0));   // diagnostic: scripts/stamp_fir_fft.py
+    a.dma = (a.dec == 1 && !a.strided && !a.rot && e->ch == 2 && a.vec && a.ov <= 2048) ? env_int("QDSP_HIP_FFT_DMA", 1) : 0;   // 1: scalar arithmetic, 2: packed
     const bool grouped = a.dec >= 4 && (a.nblocks + a.dec - 1) / a.dec >= env_int("QDSP_HIP_FFT_GROUP_MIN_UNITS", 1024);
     a.grouped = grouped ? 1 : 0;
     const int per_cu = env_int("QDSP_HIP_FFT_WG_PER_CU", grouped ? 4 : 16);
@@ -1525,7 +1530,7 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
     rc = qk::launch_fir_fft(a, nwg + 1, s);
     if (rc) return rc;
     e->raw_valid = e->rotate && e->H > 0;   // (the caller flips cur: the raw hand-over then sits at d_hist_raw[cur])
-    e->last.name = "fir_fft_kernel";
+    e->last.name = a.dma == 2 ? "fir_fft_dmapk_kernel" : a.dma ? "fir_fft_dma_kernel" : "fir_fft_kernel";
     e->last.grid = nwg + 1;
     e->last.block = qk::kFftNT;
     e->last.lds = (int)(((grouped ? 2 : 1) * qk::kFftLdsElems + 16 * 17) * sizeof(float2));

@@ -48,3 +48,11 @@ def rel_rms(a, b):
     b = np.asarray(b).astype(np.complex128)
     den = np.sqrt(np.mean(np.abs(b) ** 2))
     return float(np.sqrt(np.mean(np.abs(a - b) ** 2)) / (den if den > 0 else 1.0))
+
+
+def kname(op):
+    """Kernel family behind an operator's last call.  FIR<complex_t> on 16-byte aligned buffers runs the LDS-DMA form of the
+    4096-point overlap-save kernel (fir_fft_dma_kernel, bit-identical results; fir_fft_dmapk_kernel with QDSP_HIP_FFT_DMA=2): the
+    tests that pin "the 4096-point overlap-save kernel" mean the family (test_fft_fir_dma_forms_agree tells the members apart)."""
+    name = op.last_kernel()["name"]
+    return "fir_fft_kernel" if name in ("fir_fft_dma_kernel", "fir_fft_dmapk_kernel") else name

@@ -18,7 +18,7 @@ import numpy as np
 import pytest
 
 import oracle as O
-from conftest import rel_rms
+from conftest import kname, rel_rms
 
 pytestmark = pytest.mark.gpu
 
@@ -188,12 +188,45 @@ def test_fft_fir_vs_oracle(ops, ntaps):
     f.set_mode(f.FFT)
     sizes = [20_001, 4097, 1, 3000, 22_901]   # ragged calls: partial blocks, calls shorter than the history
     y = run_blocks(f, x, sizes)
-    assert f.last_kernel()["name"] == "fir_fft_kernel"
+    assert kname(f) == "fir_fft_kernel"
     w64 = O.Fir(taps, acc=O.ACC_F64).process(x)
     w32 = O.Fir(taps).process(x)
     assert rel_rms(y, w64) < TOL_FFT and rel_rms(y, w32) < TOL_FFT < TOL_RMS
     assert np.abs(y - w64).max() < 2e-5 * np.abs(w64).max()
     assert np.array_equal(f.get_history(), x[n - (ntaps - 1):]) if ntaps > 1 else True
+
+
+@pytest.mark.parametrize("ntaps", [2, 63, 256, 1000, 2049])
+def test_fft_fir_dma_forms_agree(ops, monkeypatch, ntaps):
+    """FIR<complex_t> (filter.h:51-74) on aligned buffers: the LDS-DMA form of the 4096-point overlap-save kernel is the same
+    transform as fir_fft_kernel<1> -- bit-identical with scalar arithmetic, within FP32 rounding with packed arithmetic -- on
+    a ragged block sequence whose segments are interior (DMA), first (history) and last (end of input); an unaligned input
+    falls back to fir_fft_kernel."""
+    import torch
+
+    rng = np.random.default_rng(7 + ntaps)
+    taps = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
+    n = 90_000
+    x = O.synth_iq(0, n, seed=3 + ntaps)
+    sizes = [40_001, 4096, 3, 20_000, 25_900]
+    out = {}
+    for dma, name in (("0", "fir_fft_kernel"), ("1", "fir_fft_dma_kernel"), ("2", "fir_fft_dmapk_kernel")):
+        monkeypatch.setenv("QDSP_HIP_FFT_DMA", dma)
+        f = ops.Fir(taps)
+        f.set_mode(f.FFT)
+        out[dma] = run_blocks(f, x, sizes)
+        assert f.last_kernel()["name"] == (name if ntaps <= 2049 else "fir_fft_kernel")
+    assert np.array_equal(out["0"], out["1"])
+    w64 = O.Fir(taps, acc=O.ACC_F64).process(x)
+    assert rel_rms(out["2"], w64) < TOL_FFT and rel_rms(out["0"], w64) < TOL_FFT
+    assert np.abs(out["2"] - out["0"]).max() < 4e-6 * np.abs(w64).max()
+    # 8-byte-aligned device input: no 16-byte loads, no DMA
+    monkeypatch.setenv("QDSP_HIP_FFT_DMA", "1")
+    f = ops.Fir(taps, max_block=0)
+    f.set_mode(f.FFT)
+    xd = torch.from_numpy(np.concatenate([np.zeros(1, np.complex64), x])).cuda()
+    y = f.process(xd[1:]).cpu().numpy()
+    assert f.last_kernel()["name"] == "fir_fft_kernel" and rel_rms(y, w64) < TOL_FFT
 
 
 def test_fft_fir_golden_and_auto_mode(ops, gold):
@@ -205,12 +238,12 @@ def test_fft_fir_golden_and_auto_mode(ops, gold):
     f = ops.Fir(taps)           # AUTO: 256 taps, >= 65536 samples per call -> FFT
     y = f.process(dev(x))
     torch.cuda.synchronize()
-    assert f.last_kernel()["name"] == "fir_fft_kernel"
+    assert kname(f) == "fir_fft_kernel"
     want = O.Fir(taps).process(x)
     assert rel_rms(y.cpu().numpy(), want) < TOL_FFT
     # small calls stay on the direct form (bit-exact; the latency arrangement of it) and share the same history
     y2 = f.process(dev(x[:1000]))
-    assert f.last_kernel()["name"] == "fir_lat_kernel"
+    assert kname(f) == "fir_lat_kernel"
     o = O.Fir(taps, acc=O.ACC_FMA)
     o.process(x)
     assert np.array_equal(y2.cpu().numpy(), o.process(x[:1000]))
@@ -259,7 +292,7 @@ def test_fft_decimator_vs_oracle(ops, dec, ntaps):
     r.set_mode(r.FFT)
     sizes = [20_003, 4097, 5, 3000, 32_895]   # count % dec != 0 -> per-call phase restart
     y = run_blocks(r, x, sizes)
-    assert r.last_kernel()["name"] == "fir_fft_kernel"
+    assert kname(r) == "fir_fft_kernel"
     w64 = run_blocks(O.Resampler(taps, 1, dec, acc=O.ACC_F64), x, sizes)
     w32 = run_blocks(O.Resampler(taps, 1, dec), x, sizes)
     assert len(y) == len(w64)
@@ -291,7 +324,7 @@ def test_polyphase_overlap_save_decimator_vs_oracle(ops, monkeypatch, ntaps, rot
     ys = []
     for a, b in zip(cuts, cuts[1:]):
         ys.append(op.process(dev(x[a:b])).cpu().numpy())
-        assert (op.last_kernel()["name"] == "pfb_dec8_kernel") == (b - a >= 4096)
+        assert (kname(op) == "pfb_dec8_kernel") == (b - a >= 4096)
     torch.cuda.synchronize()
     y = np.concatenate(ys)
     rs = O.Resampler(taps, 1, 8, acc=O.ACC_F64)
@@ -308,7 +341,7 @@ def test_polyphase_overlap_save_decimator_vs_oracle(ops, monkeypatch, ntaps, rot
     op2 = ops.Vfo(taps, 1, 8, inc, max_block=0) if rot else ops.Resampler(taps, 1, 8, max_block=0)
     op2.set_mode(op2.FFT)
     y2 = np.concatenate([op2.process(dev(x[a:b])).cpu().numpy() for a, b in zip(cuts, cuts[1:])])
-    assert op2.last_kernel()["name"] == "fir_fft_kernel" and rel_rms(y, y2) < 2e-6
+    assert kname(op2) == "fir_fft_kernel" and rel_rms(y, y2) < 2e-6
     assert np.allclose(op.get_history(), op2.get_history(), rtol=0, atol=2e-6)       # same (rotated) history handed over
 
 
@@ -324,7 +357,7 @@ def test_polyphase_overlap_save_decimator_switches_forms_mid_stream(ops, gold, m
     ys, names = [], []
     for a, b in zip(cuts, cuts[1:]):
         ys.append(op.process(dev(x[a:b])).cpu().numpy())
-        names.append(op.last_kernel()["name"])
+        names.append(kname(op))
     assert names[0] == "pfb_dec8_kernel" and names[2] == "pfb_dec8_kernel" and names[1] != "pfb_dec8_kernel"
     xl, rs = O.Xlator(1.0, 0.1234, exact=True, volk_gain=True), O.Resampler(taps, 1, 8, acc=O.ACC_F64)
     want = np.concatenate([rs.process(xl.process(x[a:b])) for a, b in zip(cuts, cuts[1:])])
@@ -343,7 +376,7 @@ def test_fft_any_decimation_vs_oracle(ops, dec, ntaps):
     r = ops.Resampler(taps, 1, dec)
     r.set_mode(r.FFT)
     y = run_blocks(r, x, sizes)
-    assert r.last_kernel()["name"] == "fir_fft_kernel"
+    assert kname(r) == "fir_fft_kernel"
     want = run_blocks(O.Resampler(taps, 1, dec, acc=O.ACC_F64), x, sizes)
     assert len(y) == len(want) and rel_rms(y, want) < TOL_FFT
     assert np.array_equal(r.get_history(), x[n - ntaps:])
@@ -351,7 +384,7 @@ def test_fft_any_decimation_vs_oracle(ops, dec, ntaps):
     v = ops.Vfo(taps, 1, dec, inc)
     v.set_mode(v.FFT)
     yv = run_blocks(v, x, sizes)
-    assert v.last_kernel()["name"] == "fir_fft_kernel"
+    assert kname(v) == "fir_fft_kernel"
     xl, rs = O.Xlator(1.0, -0.0777, exact=True, volk_gain=True), O.Resampler(taps, 1, dec, acc=O.ACC_F64)
     wv = np.concatenate([rs.process(xl.process(x[a:b])) for a, b in ((0, 30_001), (30_001, 30_005), (30_005, n))])
     assert len(yv) == len(wv) and rel_rms(yv, wv) < TOL_FFT
@@ -370,7 +403,7 @@ def test_fft_fused_vfo_vs_oracle(ops, gold, dec):
         v.set_mode(v.FFT)
         v.set_volk_gain(vg)
         y = run_blocks(v, x, sizes)
-        assert v.last_kernel()["name"] == "fir_fft_kernel"
+        assert kname(v) == "fir_fft_kernel"
         xl, rs = O.Xlator(1.0, 0.1234, exact=True, volk_gain=vg), O.Resampler(taps, 1, dec, acc=O.ACC_F64)
         want = np.concatenate([rs.process(xl.process(x[a:b])) for a, b in ((0, 65_536), (65_536, 95_537), (95_537, n))])
         assert len(y) == len(want) and rel_rms(y, want) < TOL_FFT
@@ -426,7 +459,7 @@ def test_resampler_both_kernels_agree(ops, gold, monkeypatch):
     monkeypatch.setenv("QDSP_HIP_FORCE_ANY", "1")
     r = ops.Resampler(gold["taps256"], 1, 8)
     b = run_blocks(r, x, [3000])
-    assert r.last_kernel()["name"] == "resamp_any_kernel"
+    assert kname(r) == "resamp_any_kernel"
     assert rel_rms(a, b) < 1e-6
 
 
@@ -577,7 +610,7 @@ def test_channelizer_64_channels(ops, gold, dec):
     cuts = [0, n // 2 + 64 * 7, n]                           # two calls, history + 64 NCO phases carried
     ys = [np.array(ch.process(x[a:b])) for a, b in zip(cuts, cuts[1:])]
     y = np.concatenate(ys, axis=1)
-    fast = ch.last_kernel()["name"] == "chan_uniform_kernel"
+    fast = kname(ch) == "chan_uniform_kernel"
     assert fast
     assert y.shape == (nch, n // dec)
     tol = 4e-6
@@ -601,7 +634,7 @@ def test_channelizer_64_channels(ops, gold, dec):
     ch3 = ops.Channelizer(taps, 1, dec, incs, max_block=0)
     ch3.set_mode(ch3.DIRECT)
     y3 = ch3.process(dev(x[: n // 4])).cpu().numpy()
-    assert ch3.last_kernel()["name"] != "chan_uniform_kernel"
+    assert kname(ch3) != "chan_uniform_kernel"
     for c in range(0, nch, 7):
         assert rel_rms(yd[c][: y3.shape[1]], y3[c]) < 2 * tol, c
     torch.cuda.synchronize()
@@ -629,8 +662,8 @@ def test_channelizer_small_and_ragged_blocks(ops, gold, dec):
         ys = np.array(slow.process(blk))
         assert yf.shape == ys.shape == (nch, m // dec)
         if m:
-            assert fast.last_kernel()["name"] == "chan_uniform_kernel"
-            assert slow.last_kernel()["name"] != "chan_uniform_kernel"
+            assert kname(fast) == "chan_uniform_kernel"
+            assert kname(slow) != "chan_uniform_kernel"
         outs_f.append(yf)
         outs_s.append(ys)
     yf = np.concatenate(outs_f, axis=1)
@@ -665,7 +698,7 @@ def test_channelizer_guard_bands_and_odd_strides(ops, gold, dec):
         b = ops.Channelizer(taps, 1, dec, incs, max_block=0)
         got = b.process(xin[off:], out=big)
         torch.cuda.synchronize()
-        assert b.last_kernel()["name"] == "chan_uniform_kernel"
+        assert kname(b) == "chan_uniform_kernel"
         host = big.cpu().numpy()
         assert got.shape == (nch, no)
         assert (host[:, no:] == sentinel).all(), (dec, n, stride, off)
@@ -696,7 +729,7 @@ def test_channelizer_non_uniform_plan_one_batched_launch(ops, gold, kernel, monk
     ch2 = ops.Channelizer(taps, 1, 64, incs, max_block=n)
     ch2.set_mode(ch2.DIRECT)
     y2 = np.array(ch2.process(x))
-    assert "batch" not in ch2.last_kernel()["name"]
+    assert "batch" not in kname(ch2)
     for c in range(4):
         assert rel_rms(y[c], y2[c]) < 2e-6
 
@@ -737,7 +770,7 @@ def test_channelizer_batched_stream_of_blocks(ops, plan, monkeypatch):
         ys.append(ch.process(blk).cpu().numpy())
         if m:
             mf = mf_plan and (plan == "dec20x130" or nch * m >= 1 << 22)
-            assert ch.last_kernel()["name"] == ("decim_mfma_batch_kernel" if mf else "resamp_any_batch_kernel"), (plan, m)
+            assert kname(ch) == ("decim_mfma_batch_kernel" if mf else "resamp_any_batch_kernel"), (plan, m)
     torch.cuda.synchronize()
     y = np.concatenate(ys, axis=1)
     check = range(nch) if nch <= 16 else (0, 1, 2, 64, 127, 128, 129)
@@ -837,7 +870,7 @@ def test_channelizer_time_sharded_halo(ops, gold, mode):
 
     whole = make()
     y = whole.process(x).cpu().numpy()
-    assert (whole.last_kernel()["name"] == "chan_uniform_kernel") == (mode == "uniform")
+    assert (kname(whole) == "chan_uniform_kernel") == (mode == "uniform")
     second = make()
     second.advance(cut)
     second.set_history_dev(x[cut - second.history_len:cut].contiguous())
@@ -859,7 +892,7 @@ def test_fir_f32_fft_path_matches_direct(ops, gold, ntaps):
     f = ops.Fir(taps, complex_data=False)
     f.set_mode(f.FFT)
     y = f.process(dev(x)).cpu().numpy()
-    assert f.last_kernel()["name"] == "fir_fft_kernel" and y.dtype == np.float32 and y.shape == (n,)
+    assert kname(f) == "fir_fft_kernel" and y.dtype == np.float32 and y.shape == (n,)
     want = O.Fir(taps, complex_data=False, acc=O.ACC_F64).process(x)
     assert rel_rms(y, want) < 2e-6
     d = ops.Fir(taps, complex_data=False)
@@ -885,7 +918,7 @@ def test_resampler_f32_fft_path(ops, gold, M):
     r.set_mode(r.FFT)
     cuts = [0, 200_000, n]                       # multiples of M: the per-block phase restart (H4) lands the same
     y = np.concatenate([r.process(dev(x[a:b])).cpu().numpy() for a, b in zip(cuts, cuts[1:])])
-    assert r.last_kernel()["name"] == "fir_fft_kernel"
+    assert kname(r) == "fir_fft_kernel"
     o = O.Resampler(taps, 1, M, complex_data=False, acc=O.ACC_F64)
     want = np.concatenate([o.process(x[a:b]) for a, b in zip(cuts, cuts[1:])])
     assert y.shape == want.shape and rel_rms(y, want) < 2e-6
@@ -919,7 +952,7 @@ def test_resampler_small_interp_kernel_details(ops, gold, LM):
     sizes = [50_001, 3, 99_996]
     r = ops.Resampler(taps, L, M)
     y = run_blocks(r, x, sizes)
-    assert r.last_kernel()["name"] == "resamp_lm_kernel"
+    assert kname(r) == "resamp_lm_kernel"
     want = run_blocks(O.Resampler(taps, L, M, acc=O.ACC_F64), x, sizes)
     assert len(y) == len(want) and rel_rms(y, want) < 1e-6
     xr = np.ascontiguousarray(x.real)
@@ -928,7 +961,7 @@ def test_resampler_small_interp_kernel_details(ops, gold, LM):
     inc = ops.phase_delta(48000.0, 1234.0)
     v = ops.Vfo(taps, L, M, inc)
     yv = run_blocks(v, x, sizes)
-    assert v.last_kernel()["name"] == "resamp_lm_kernel"
+    assert kname(v) == "resamp_lm_kernel"
     xl, rs = O.Xlator(48000.0, 1234.0, exact=True, volk_gain=True), O.Resampler(taps, L, M, acc=O.ACC_F64)
     wv = np.concatenate([rs.process(xl.process(x[a:b])) for a, b in zip(np.cumsum([0] + sizes)[:-1], np.cumsum(sizes))])
     assert len(yv) == len(wv) and rel_rms(yv, wv) < 2e-6
@@ -946,7 +979,7 @@ def test_decimator_short_filter_kernel(ops, gold, M):
         sizes = [M * 1001, M * 3, M * 7000]          # multiples of M: every input sample is consumed (H4)
         r = ops.Resampler(taps, 1, M)
         y = run_blocks(r, x, sizes)
-        assert r.last_kernel()["name"] == "decim_win_kernel", (M, ntaps)
+        assert kname(r) == "decim_win_kernel", (M, ntaps)
         assert np.array_equal(y, run_blocks(O.Resampler(taps, 1, M, acc=O.ACC_FMA), x, sizes)), (M, ntaps)
     xr = np.ascontiguousarray(x.real)
     yr = run_blocks(ops.Resampler(taps, 1, M, complex_data=False), xr, sizes)
@@ -954,7 +987,7 @@ def test_decimator_short_filter_kernel(ops, gold, M):
     inc = ops.phase_delta(48000.0, -2500.0)
     v = ops.Vfo(gold["taps63"], 1, M, inc)
     yv = run_blocks(v, x, sizes)
-    assert v.last_kernel()["name"] == "decim_win_kernel"
+    assert kname(v) == "decim_win_kernel"
     xl, rs = O.Xlator(48000.0, -2500.0, exact=True, volk_gain=True), O.Resampler(gold["taps63"], 1, M, acc=O.ACC_F64)
     edges = np.cumsum([0] + [sizes[i % 3] for i in range(64)])
     edges = edges[edges < len(x)].tolist() + [len(x)]
@@ -1000,13 +1033,13 @@ def test_equal_rate_resampler_and_xlating_fir_fft_path(ops, gold):
     cuts = [0, 170_001, 300_000]
     r = ops.Resampler(taps, 1, 1)
     y = np.concatenate([r.process(dev(x[a:b])).cpu().numpy() for a, b in zip(cuts, cuts[1:])])
-    assert r.last_kernel()["name"] == "fir_fft_kernel"
+    assert kname(r) == "fir_fft_kernel"
     o = O.Resampler(taps, 1, 1, acc=O.ACC_F64)
     assert rel_rms(y, np.concatenate([o.process(x[a:b]) for a, b in zip(cuts, cuts[1:])])) < 2e-6
     inc = ops.phase_delta(1.0, 0.0625)
     v = ops.Vfo(taps, 1, 1, inc)
     yv = np.concatenate([v.process(dev(x[a:b])).cpu().numpy() for a, b in zip(cuts, cuts[1:])])
-    assert v.last_kernel()["name"] == "fir_fft_kernel"
+    assert kname(v) == "fir_fft_kernel"
     xl, rs = O.Xlator(1.0, 0.0625, exact=True, volk_gain=True), O.Resampler(taps, 1, 1, acc=O.ACC_F64)
     assert rel_rms(yv, np.concatenate([rs.process(xl.process(x[a:b])) for a, b in zip(cuts, cuts[1:])])) < 2e-6
     d = ops.Vfo(taps, 1, 1, inc)
@@ -1025,7 +1058,7 @@ def test_any_decimation_strided_store(ops, gold, M):
     r.set_mode(r.FFT)
     cuts = [0, (n // 2 // M) * M, n]
     y = np.concatenate([r.process(dev(x[a:b])).cpu().numpy() for a, b in zip(cuts, cuts[1:])])
-    assert r.last_kernel()["name"] == "fir_fft_kernel"
+    assert kname(r) == "fir_fft_kernel"
     o = O.Resampler(taps, 1, M, acc=O.ACC_F64)
     want = np.concatenate([o.process(x[a:b]) for a, b in zip(cuts, cuts[1:])])
     assert y.shape == want.shape and len(y) >= 3 and rel_rms(y, want) < 2e-6
@@ -1084,13 +1117,13 @@ def test_large_decimation_direct_kernel(ops, M, ntaps, monkeypatch):
             if M >= 1000:
                 op.set_mode(op.DIRECT)      # (AUTO: overlap-save; here the tap split at 1-8 outputs per tile is under test)
             got = np.concatenate([op.process(dev(b)).cpu().numpy() for b in blocks])
-            assert op.last_kernel()["name"] == ("resamp_any_kernel" if no_mf else "decim_mfma_kernel"), (M, ntaps, vfo, op.last_kernel())
+            assert kname(op) == ("resamp_any_kernel" if no_mf else "decim_mfma_kernel"), (M, ntaps, vfo, op.last_kernel())
             assert got.shape == want.shape and rel_rms(got, want) < 2e-6, (M, ntaps, vfo, no_mf)
         # the overlap-save form of the same plan agrees
         ref = mk()
         ref.set_mode(ref.FFT)
         alt = np.concatenate([ref.process(dev(b)).cpu().numpy() for b in blocks])
-        assert ref.last_kernel()["name"] == "fir_fft_kernel"
+        assert kname(ref) == "fir_fft_kernel"
         assert rel_rms(got, alt) < 3e-6, (M, ntaps, vfo)
 
 
@@ -1112,7 +1145,7 @@ def test_mfma_decimator_shapes(ops, M, ntaps):
     blocks = [x[a:b] for a, b in zip(cuts, cuts[1:])]
     r = ops.Resampler(taps, 1, M, max_block=0)
     got = np.concatenate([r.process(dev(b)).cpu().numpy() for b in blocks])
-    assert r.last_kernel()["name"] == "decim_mfma_kernel", r.last_kernel()
+    assert kname(r) == "decim_mfma_kernel", r.last_kernel()
     rs = O.Resampler(taps, 1, M, acc=O.ACC_F64)
     want = np.concatenate([rs.process(b) for b in blocks])
     assert got.shape == want.shape and rel_rms(got, want) < 1e-6, (M, ntaps)
@@ -1126,7 +1159,7 @@ def test_mfma_decimator_shapes(ops, M, ntaps):
             O.lib().oracle_xlator_phase_delta(1.0, -0.111, O._fp(xl.delta))
         gv.append(v.process(dev(b)).cpu().numpy())
         wv.append(rs.process(xl.process(b)))
-    assert v.last_kernel()["name"] == "decim_mfma_kernel"
+    assert kname(v) == "decim_mfma_kernel"
     gv, wv = np.concatenate(gv), np.concatenate(wv)
     assert gv.shape == wv.shape and rel_rms(gv, wv) < 1e-6, (M, ntaps)
 
@@ -1158,7 +1191,7 @@ def test_rational_mfma_resampler(ops, L, M, tpp, forced, monkeypatch):
     blocks = [x[a:b] for a, b in zip(cuts, cuts[1:])]
     r = ops.Resampler(taps, L, M, max_block=0)
     got = np.concatenate([r.process(dev(b)).cpu().numpy() for b in blocks])
-    assert r.last_kernel()["name"] == "resamp_mfma_kernel", r.last_kernel()
+    assert kname(r) == "resamp_mfma_kernel", r.last_kernel()
     rs = O.Resampler(taps, L, M, acc=O.ACC_F64)
     want = np.concatenate([rs.process(b) for b in blocks])
     assert got.shape == want.shape and rel_rms(got, want) < 1e-6, (L, M)
@@ -1171,14 +1204,14 @@ def test_rational_mfma_resampler(ops, L, M, tpp, forced, monkeypatch):
             O.lib().oracle_xlator_phase_delta(1.0, -0.111, O._fp(xl.delta))
         gv.append(v.process(dev(b)).cpu().numpy())
         wv.append(rs.process(xl.process(b)))
-    assert v.last_kernel()["name"] == "resamp_mfma_kernel"
+    assert kname(v) == "resamp_mfma_kernel"
     gv, wv = np.concatenate(gv), np.concatenate(wv)
     assert gv.shape == wv.shape and rel_rms(gv, wv) < 1e-6, (L, M)
     # the general direct kernel on the same plan agrees
     monkeypatch.setenv("QDSP_HIP_NO_RM", "1")
     r2 = ops.Resampler(taps, L, M, max_block=0)
     alt = np.concatenate([r2.process(dev(b)).cpu().numpy() for b in blocks])
-    assert r2.last_kernel()["name"] != "resamp_mfma_kernel" and rel_rms(got, alt) < 1e-6
+    assert kname(r2) != "resamp_mfma_kernel" and rel_rms(got, alt) < 1e-6
 
 
 @pytest.mark.parametrize("seed", range(24))
@@ -1222,10 +1255,10 @@ def test_random_plans_every_dispatch_path(ops, seed):
         op.set_mode(mode)
         print("plan", seed, case, L, M, ntaps, kind, mode, sizes, flush=True)
         got = np.concatenate([np.array(op.process(b)) for b in blocks])
-        seen.add(op.last_kernel()["name"])
+        seen.add(kname(op))
         assert got.shape == want.shape, (L, M, ntaps, kind, mode, sizes)
         if len(want):
-            assert rel_rms(got, want) < 4e-6, (L, M, ntaps, kind, mode, sizes, op.last_kernel()["name"])
+            assert rel_rms(got, want) < 4e-6, (L, M, ntaps, kind, mode, sizes, kname(op))
     assert len(seen) >= 2, seen
 
 
@@ -1284,9 +1317,9 @@ def test_random_device_pointers_and_guard_bands(ops, seed):
             assert y.numel() == len(want), (kind, L, M, ntaps, mode, m)
             host = big.cpu().numpy()
             lo, hi = host[: pad + oo], host[pad + oo + len(want) :]
-            assert (lo == sentinel).all() and (hi == sentinel).all(), (kind, L, M, ntaps, mode, m, oi, oo, op.last_kernel()["name"])
+            assert (lo == sentinel).all() and (hi == sentinel).all(), (kind, L, M, ntaps, mode, m, oi, oo, kname(op))
             if len(want):
-                assert rel_rms(host[pad + oo : pad + oo + len(want)], want) < 4e-6, (kind, L, M, ntaps, mode, m, oi, oo, op.last_kernel()["name"])
+                assert rel_rms(host[pad + oo : pad + oo + len(want)], want) < 4e-6, (kind, L, M, ntaps, mode, m, oi, oo, kname(op))
 
 
 def test_vfo_history_forms_across_kernel_switches(ops, gold):
@@ -1313,7 +1346,7 @@ def test_vfo_history_forms_across_kernel_switches(ops, gold):
         seg = x[pos : pos + m]
         pos += m
         got = v.process(dev(seg)).cpu().numpy()
-        names.append(v.last_kernel()["name"])
+        names.append(kname(v))
         want = rs.process(xl.process(seg))
         assert got.shape == want.shape and rel_rms(got, want) < 3e-6, (i, m, names)
     assert names.count("fir_fft_kernel") >= 6 and len(set(names)) >= 2, names
@@ -1347,7 +1380,7 @@ def test_calls_beyond_2_31_samples(ops, gold):
         y = torch.empty(nout + 8, dtype=torch.complex64, device="cuda")
         got = op.process(x, out=y)
         torch.cuda.synchronize()
-        assert got.numel() == nout and op.last_kernel()["name"] == kernel, (name, op.last_kernel())
+        assert got.numel() == nout and kname(op) == kernel, (name, op.last_kernel())
         step = 512 * M // int(np.gcd(512, M))
         for target in ((1 << 31) + 4096, n - 70_000):
             s0 = (target // step) * step
@@ -1382,7 +1415,7 @@ def test_resampler_reconfigure_across_kernel_families(ops, gold):
             r.configure(taps, L, M)
         n = len(x) // M * M
         y = r.process(dev(x[:n])).cpu().numpy()
-        assert r.last_kernel()["name"] == kernel, (L, M, ntaps, r.last_kernel())
+        assert kname(r) == kernel, (L, M, ntaps, r.last_kernel())
         want = O.Resampler(taps, L, M, acc=O.ACC_F64).process(x[:n])
         skip = (-(-ntaps // L) * L) // M + L + 2          # outputs whose window reaches into what came before the call
         assert y.shape == want.shape and rel_rms(y[skip:], want[skip:]) < 1e-6, (L, M, ntaps)
@@ -1403,7 +1436,7 @@ def test_default_size_thresholds_of_the_mfma_kernels(ops):
     got, want, names = [], [], []
     for a, b in zip(cuts, cuts[1:]):
         got.append(v.process(dev(x[a:b])).cpu().numpy())
-        names.append(v.last_kernel()["name"])
+        names.append(kname(v))
         want.append(rs.process(xl.process(x[a:b])))
     assert names == ["resamp_any_kernel", "decim_mfma_kernel", "resamp_any_kernel", "decim_mfma_kernel"], names
     got, want = np.concatenate(got), np.concatenate(want)
@@ -1418,7 +1451,7 @@ def test_default_size_thresholds_of_the_mfma_kernels(ops):
     got, want, names = [], [], []
     for a, b in zip(cuts, cuts[1:]):
         got.append(r.process(dev(x[a:b])).cpu().numpy())
-        names.append(r.last_kernel()["name"])
+        names.append(kname(r))
         want.append(rs.process(x[a:b]))
     assert names == ["resamp_any_kernel", "resamp_mfma_kernel", "resamp_any_kernel"], names
     got, want = np.concatenate(got), np.concatenate(want)
@@ -1428,7 +1461,7 @@ def test_default_size_thresholds_of_the_mfma_kernels(ops):
         op = ops.Resampler(taps_, L_, M_, max_block=0)
         xs = O.synth_iq(0, M_ * 3000, seed=33)
         y = op.process(dev(xs)).cpu().numpy()
-        assert op.last_kernel()["name"] == kernel
+        assert kname(op) == kernel
         assert rel_rms(y, O.Resampler(taps_, L_, M_, acc=O.ACC_F64).process(xs)) < 1e-6
 
 
@@ -1444,7 +1477,7 @@ def test_bench_size_mfma_kernels(ops, monkeypatch):
     t401 = O.lowpass_taps_f64(401, 0.4 / 50).astype(np.float32)
     v = ops.Vfo(t401, 1, 50, ops.phase_delta(1.0, 0.1234), max_block=0)
     yv = v.process(x)
-    assert v.last_kernel()["name"] == "decim_mfma_kernel" and yv.numel() == n // 50
+    assert kname(v) == "decim_mfma_kernel" and yv.numel() == n // 50
     step = 12800                                                     # lcm(50, 512): polyphase counter and VOLK gain cadence restart together
     for start in (0, ((1 << 26) + 777_000) // step * step, (n - 400_000) // step * step):
         lo = max(start - step, 0)                                    # one aligned stretch of history in front
@@ -1459,7 +1492,7 @@ def test_bench_size_mfma_kernels(ops, monkeypatch):
     monkeypatch.setenv("QDSP_HIP_NO_MF", "1")
     v2 = ops.Vfo(t401, 1, 50, ops.phase_delta(1.0, 0.1234), max_block=0)
     y2 = v2.process(x)
-    assert v2.last_kernel()["name"] == "resamp_any_kernel"
+    assert kname(v2) == "resamp_any_kernel"
     monkeypatch.delenv("QDSP_HIP_NO_MF")
     assert (yv - y2).abs().max().item() < 2e-5 * y2.abs().max().item()
     del yv, y2, v, v2
@@ -1468,7 +1501,7 @@ def test_bench_size_mfma_kernels(ops, monkeypatch):
     nr = n // M * M
     r = ops.Resampler(taps, L, M, max_block=0)
     yr = r.process(x[:nr])
-    assert r.last_kernel()["name"] == "resamp_mfma_kernel" and yr.numel() == nr // M * L
+    assert kname(r) == "resamp_mfma_kernel" and yr.numel() == nr // M * L
     for start in (0, ((1 << 26) + 555_555) // M * M, nr - 300 * M):
         lo = max(start - 4 * M, 0)
         xh = O.synth_iq(lo, min(120_000 // M * M, nr - start) + (start - lo), seed=4242)
@@ -1479,7 +1512,7 @@ def test_bench_size_mfma_kernels(ops, monkeypatch):
     monkeypatch.setenv("QDSP_HIP_NO_RM", "1")
     r2 = ops.Resampler(taps, L, M, max_block=0)
     y2 = r2.process(x[:nr])
-    assert r2.last_kernel()["name"] == "resamp_any_kernel"
+    assert kname(r2) == "resamp_any_kernel"
     assert (yr - y2).abs().max().item() < 2e-5 * y2.abs().max().item()
     torch.cuda.synchronize()
 
@@ -1496,7 +1529,7 @@ def test_bench_size_cross_checks(ops, gold, monkeypatch):
     x = ops.synth_iq(n, seed=1234)
     f = ops.Fir(taps)
     y = f.process(x)
-    assert f.last_kernel()["name"] == "fir_fft_kernel"
+    assert kname(f) == "fir_fft_kernel"
     for start in (0, (1 << 26) + 12_345, n - 70_000):            # the far windows sit past the 2^31-byte mark
         lo = max(start - 255, 0)
         xh = O.synth_iq(lo, 65_536 + (start - lo), seed=1234)
@@ -1512,7 +1545,7 @@ def test_bench_size_cross_checks(ops, gold, monkeypatch):
     inc = ops.phase_delta(1.0, 0.1234)
     v = ops.Vfo(taps, 1, 8, inc)
     yv = v.process(x)
-    assert v.last_kernel()["name"] == "pfb_dec8_kernel" and yv.numel() == n // 8
+    assert kname(v) == "pfb_dec8_kernel" and yv.numel() == n // 8
     for start in (0, (1 << 26) + 8 * 1543, n - 8 * 9000):        # oracle windows of the fused VFO, incl. past the 2^31-byte mark
         lo = max(start - 256, 0)
         xh = O.synth_iq(lo, 65_536 + (start - lo), seed=1234)
@@ -1532,14 +1565,14 @@ def test_bench_size_cross_checks(ops, gold, monkeypatch):
     monkeypatch.setenv("QDSP_HIP_NO_PFB", "1")
     xl, rs = ops.Xlator(phase_inc=inc), ops.Resampler(taps, 1, 8)
     y2 = rs.process(xl.process(x))
-    assert rs.last_kernel()["name"] == "fir_fft_kernel"
+    assert kname(rs) == "fir_fft_kernel"
     monkeypatch.delenv("QDSP_HIP_NO_PFB")
     assert (yv - y2).abs().max().item() < 2e-5 * y2.abs().max().item()
     del y2, yv
     incs = [ops.phase_delta(1.0, -(c - 31.5) / 64.0) for c in range(64)]
     ch = ops.Channelizer(gold["taps256"], 1, 64, incs, max_block=0)
     yc = ch.process(x)
-    assert ch.last_kernel()["name"] == "chan_uniform_kernel" and tuple(yc.shape) == (64, n // 64)
+    assert kname(ch) == "chan_uniform_kernel" and tuple(yc.shape) == (64, n // 64)
     for c in (0, 37, 63):
         one = ops.Vfo(gold["taps256"], 1, 64, incs[c])
         one.set_mode(one.DIRECT)
@@ -1575,7 +1608,7 @@ def test_fft1k_small_calls_vs_oracle(ops, kind, M, ntaps):
     ys, ws, names = [], [], []
     for a, b in zip(cuts, cuts[1:]):
         ys.append(np.array(op.process(x[a:b])))
-        names.append(op.last_kernel()["name"])
+        names.append(kname(op))
         blk = xl.process(x[a:b]) if xl else x[a:b]
         ws.append(o.process(blk))
     y, w = np.concatenate(ys), np.concatenate(ws)
@@ -1612,18 +1645,18 @@ def test_fft1k_thresholds_and_exclusions(ops, gold, monkeypatch):
     f = ops.Fir(taps, max_block=0)
     for n, want in ((1 << 14, "fir_lat_kernel"), (1 << 17, "fir_fft1k_kernel"), (1_000_000, "fir_fft1k_kernel"), (4 << 20, "fir_fft1k_kernel"), (5 << 20, "fir_fft_kernel")):
         f.process(x[:n], out[:n])
-        assert f.last_kernel()["name"] == want, (n, f.last_kernel())
+        assert kname(f) == want, (n, f.last_kernel())
     f.set_mode(f.FFT)
     f.process(x[:1_000_000], out[:1_000_000])
-    assert f.last_kernel()["name"] == "fir_fft_kernel"
+    assert kname(f) == "fir_fft_kernel"
     f.set_mode(f.DIRECT)
     f.process(x[:1_000_000], out[:1_000_000])
-    assert f.last_kernel()["name"] == "fir_core_kernel"
+    assert kname(f) == "fir_core_kernel"
     f.close()
     d = ops.Resampler(taps, 1, 8, max_block=0)
     for n, want in ((1_000_000, "fir_fft1k_kernel"), (3 << 20, "fir_fft1k_kernel"), (4 << 20, "fir_fft_kernel")):
         d.process(x[:n], out[:n])
-        assert d.last_kernel()["name"] == want, (n, d.last_kernel())
+        assert kname(d) == want, (n, d.last_kernel())
     d.close()
     # 514-769 taps (at most a quarter .. half of a segment new): calls up to 2^19 samples, and no fir_lat_kernel detour for
     # filters past 320 taps (a wave would walk 600 taps for each of its 64 outputs: 9.3 us on 4096 samples against 5.6)
@@ -1631,11 +1664,11 @@ def test_fft1k_thresholds_and_exclusions(ops, gold, monkeypatch):
     g = ops.Fir(long_taps, max_block=0)
     for n, want in ((4096, "fir_fft1k_kernel"), (1 << 19, "fir_fft1k_kernel"), (1_000_000, "fir_fft_kernel")):
         g.process(x[:n], out[:n])
-        assert g.last_kernel()["name"] == want, (n, g.last_kernel())
+        assert kname(g) == want, (n, g.last_kernel())
     g.close()
     g = ops.Fir(np.resize(taps, 800).astype(np.float32), max_block=0)
     g.process(x[:100_000], out[:100_000])
-    assert g.last_kernel()["name"] == "fir_fft_kernel"
+    assert kname(g) == "fir_fft_kernel"
     g.close()
     # real data: two real segments per wave, up to 2^25 samples at 256 taps; QDSP_HIP_NO_FFT1K_REAL keeps the 4096-point kernel
     r = ops.Fir(taps, complex_data=False, max_block=0)
@@ -1643,17 +1676,17 @@ def test_fft1k_thresholds_and_exclusions(ops, gold, monkeypatch):
     outr = torch.empty((1 << 25) + 8, dtype=torch.float32, device="cuda")
     for n, want in ((1_000_000, "fir_fft1k_kernel"), (1 << 25, "fir_fft1k_kernel"), ((1 << 25) + 8, "fir_fft_kernel")):
         r.process(xr[:n], outr[:n])
-        assert r.last_kernel()["name"] == want, (n, r.last_kernel())
+        assert kname(r) == want, (n, r.last_kernel())
     monkeypatch.setenv("QDSP_HIP_NO_FFT1K_REAL", "1")
     r.process(xr[:1_000_000], outr[:1_000_000])
-    assert r.last_kernel()["name"] == "fir_fft_kernel"
+    assert kname(r) == "fir_fft_kernel"
     monkeypatch.delenv("QDSP_HIP_NO_FFT1K_REAL")
     r.close()
     del xr, outr
     monkeypatch.setenv("QDSP_HIP_NO_FFT1K", "1")
     h = ops.Fir(taps, max_block=0)
     h.process(x[:1_000_000], out[:1_000_000])
-    assert h.last_kernel()["name"] == "fir_fft_kernel"
+    assert kname(h) == "fir_fft_kernel"
     h.close()
 
 
@@ -1676,7 +1709,7 @@ def test_fft1k_vfo_retune_and_ideal_nco(ops, gold):
                 O.lib().oracle_xlator_phase_delta(1.0, -0.31, O._fp(xl.delta))
             blk = x[k * n:(k + 1) * n]
             ys.append(np.array(v.process(blk)))
-            assert v.last_kernel()["name"] == "fir_fft1k_kernel"
+            assert kname(v) == "fir_fft1k_kernel"
             ws.append(rs.process(xl.process(blk)))
         assert rel_rms(np.concatenate(ys), np.concatenate(ws)) < TOL_FFT
 
@@ -1713,7 +1746,7 @@ def test_small_calls_of_rational_resamplers(ops, L, M, ntaps, vfo):
     names = []
     for a, b in zip(cuts, cuts[1:]):
         y = np.array(op.process(x[a:b]))
-        names.append(op.last_kernel()["name"])
+        names.append(kname(op))
         w = o.process(xl.process(x[a:b]) if xl else x[a:b])
         assert y.shape == w.shape
         if len(w):
@@ -1744,7 +1777,7 @@ def test_long_decimators_on_short_calls_take_the_one_wave_overlap_save(ops, gold
         for a, b in zip(cuts, cuts[1:]):
             y, w = np.array(d.process(x[a:b])), o.process(x[a:b])
             yv, wv = np.array(v.process(x[a:b])), ov.process(xl.process(x[a:b]))
-            assert d.last_kernel()["name"] == "fir_fft1k_kernel" and v.last_kernel()["name"] == "fir_fft1k_kernel"
+            assert kname(d) == "fir_fft1k_kernel" and kname(v) == "fir_fft1k_kernel"
             assert y.shape == w.shape and yv.shape == wv.shape
             # (absolute bar: the first calls are the filter's start-up transient, outputs of 1e-8 .. 1e-3 next to input
             # samples of magnitude 1 in the same transform -- an overlap-save kernel's rounding is relative to the latter)
@@ -1775,7 +1808,7 @@ def test_fft1k_real_data(ops, M, ntaps):
     names = []
     for a, b in zip(cuts, cuts[1:]):
         y = op.process(torch.from_numpy(x[a:b]).cuda()).cpu().numpy()
-        names.append(op.last_kernel()["name"])
+        names.append(kname(op))
         w = o.process(x[a:b])
         assert y.dtype == np.float32 and y.shape == w.shape
         assert np.abs(y - w).max() < 2e-6 * max(1.0, np.abs(w).max()), (names, a, b)
