@@ -50,6 +50,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+CHAN_ROW_PAD = 32           # samples between the end of a channel row and the start of the next (see run_workload)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
 FP32_PEAK_TFLOPS = 157.3   # FP32 vector == FP32 MFMA peak (same file)
 
@@ -319,7 +320,10 @@ def run_workload(name: str, args, ctx) -> dict:
     # the real one: every step each rank's tail goes to its ring successor over RCCL, prefetched under the kernel.
     x = ops.synth_iq(n, first_sample=rank * n, seed=1234, device=local_rank)
     nout = n // w["decim"] * w.get("interp", 1)
-    out = torch.empty((w["nchan"], nout) if is_chan else nout, dtype=torch.complex64, device=dev)
+    # channel rows 32 samples (256 bytes) longer than the data: with a power-of-two row stride (2^24 samples at M = 8) the 64 lines a
+    # tile writes -- one per channel -- fall on the same memory channel (chan64m8: 2.85 ms, 2.46 with the pad).  The
+    # stride is the caller's to choose (qdsp_hip_chan_cf32_process_dev's out_stride argument); reported in config.out_row_stride.
+    out = torch.empty((w["nchan"], nout + CHAN_ROW_PAD) if is_chan else nout, dtype=torch.complex64, device=dev)
     ring = RingStream(op, n, rank, world, transport="host" if rehearse else "device", align=align,
                       exchange=(world > 1 or self_ring),
                       prefetch=os.environ.get("QDSP_BENCH_NO_PREFETCH", "0") != "1")
@@ -435,6 +439,7 @@ def run_workload(name: str, args, ctx) -> dict:
             "halo_samples": H if world > 1 else 0,
             "partition": ("single stream" + (" (self-ring RCCL exchange every step)" if self_ring else "")) if world == 1
                          else f"block-cyclic time chunks over {world} ranks, ring halo over RCCL",
+            **({"channels": w["nchan"], "out_row_stride": nout + CHAN_ROW_PAD} if is_chan else {}),
         },
         "roofline": {
             "bound": "hbm",
@@ -488,7 +493,7 @@ def block_call(name: str, ctx) -> dict:
     op = make_op(ops, name, ctx["local_rank"])
     x = ops.synth_iq(n, seed=4321, device=ctx["local_rank"])
     nout = n // w["decim"] * w.get("interp", 1)
-    out = torch.empty((w["nchan"], nout) if name in ("chan64", "chan64m8") else nout + 8, dtype=torch.complex64, device=ctx["dev"])
+    out = torch.empty((w["nchan"], nout + CHAN_ROW_PAD) if name in ("chan64", "chan64m8") else nout + 8, dtype=torch.complex64, device=ctx["dev"])
     op.process(x, out)
     torch.cuda.synchronize()
     ms = min(op.time_dev(x, out, 200) for _ in range(3))

@@ -37,6 +37,7 @@
 #include "chan.hip.h"
 #include "cfft.hip.h"
 #include "cpk.hip.h"
+#include "ldsdma.hip.h"
 #include <type_traits>
 
 namespace qk {
@@ -74,11 +75,13 @@ __device__ __forceinline__ v2f bperm_pair(int src, v2f v) {
 // output time that the DFT does not cover: its tile part rides in A_c, its in-tile part depends on
 // (c0, n') only and is applied with the wave twiddle.
 // (M = 8: its 40-value window takes 80 VGPRs; 2 waves/SIMD without spills measured 10 % faster than 3 with a few)
-template <bool INV, int M>
-__global__ __launch_bounds__(256, (M == 8) ? 2 : 3) void chan_uniform_kernel(const ChanArgs a) {
+// ABL (diagnostic builds, profiles/r03_ablate_chan64m8.txt): 1 = no global stores, 2 = no DMA (tiles are whatever lies in LDS), 4 = no finish arithmetic
+// QF: 4 = all four tap rows present (193..256 taps: no per-row test in the accumulation), 0 = a.Q rows (run-time)
+template <bool INV, int M, int QF = 0, int ABL = 0>
+__global__ __launch_bounds__(256, 3) void chan_uniform_kernel(const ChanArgs a) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int t = threadIdx.x;
-    const int P = a.P, Q = a.Q;
+    const int P = a.P, Q = QF ? QF : a.Q;
     const v2f* __restrict__ in = reinterpret_cast<const v2f*>(a.in);
     const v2f* __restrict__ hist = reinterpret_cast<const v2f*>(a.hist);
 
@@ -93,52 +96,49 @@ __global__ __launch_bounds__(256, (M == 8) ? 2 : 3) void chan_uniform_kernel(con
 
     const int l = t & 63, wv = t >> 6;
     v2f* T = reinterpret_cast<v2f*>(lds + wv * kChWaveLds);                   // [16][68]
-    float4* tab = reinterpret_cast<float4*>(lds + wv * kChWaveLds + kChT * kChRowT);   // [64] {A_c, j A_c} of this tile
-    // Tables indexed by channel c = c0 + 16 c1 are stored at slot 4 c0 + c1 (kSlot): the four lanes of a quad
-    // read c1 = 0..3 of one c0 in the same instruction, and entries 16 apart would share their banks.
-    float4* twl = reinterpret_cast<float4*>(lds + 4 * kChWaveLds);             // [c0][sub] {w, j w}, w = exp(+-j 2pi c0 sub / 64)
-    float2* cst = lds + 4 * kChWaveLds + 128;                                  // [kSlot(c)] {theta_c, gm1_c}
-    float4* rootl = reinterpret_cast<float4*>(lds + 4 * kChWaveLds + 192);     // [i < 64/M] {w, j w}, w = exp(+-j 2pi i M / 64)   (M < 64)
+    // Per channel c (slot 4 c0 + c1, kSlot: the four lanes of a quad read c1 = 0..3 of one c0 in the same instruction, and
+    // entries 16 apart would share their banks): {A_c of this tile, theta_c, gm1_c} -- one 16-byte read per output.
+    float4* tab = reinterpret_cast<float4*>(lds + wv * kChWaveLds + kChT * kChRowT);   // [64]
+    // Round 3: ONE twiddle per (c0, lane) instead of three factors: exp(+-j 2pi c0 sub / 64) (the split of the 64-point DFT),
+    // exp(+-j 2pi c0 M n'/64) (oversampled plans) -- both 64th roots of unity, so their product is one entry of tw64 -- and
+    // W(n') = exp(j M n' dphi_0), common to the four lanes of a quad and therefore free to move in front of the butterfly.
+    v2f* ptw = reinterpret_cast<v2f*>(lds + 4 * kChWaveLds);                  // [c0][lane], shared by the four waves
     auto kSlot = [](int c) { return ((c & 15) << 2) | (c >> 4); };
-    if (t < 64) {
-        float2 w = a.tw64[((t >> 2) * (t & 3)) & 63];    // exp(-j 2pi m / 64); conjugated when INV
-        if (INV) w.y = -w.y;
-        twl[t] = make_float4(w.x, w.y, -w.y, w.x);
-        cst[kSlot(t)] = make_float2((float)((double)(a.ddelta[t] * (long long)M) * 3.4061215800865545e-19), a.gm1[t]);   // 2pi / 2^64
-        float2 r = a.tw64[(t * M) & 63];
-        if (INV) r.y = -r.y;
-        rootl[t] = make_float4(r.x, r.y, -r.y, r.x);     // only the first 64/M entries are distinct / used
+    {
+        const int ln = t & 63, nql = ln >> 2, subl = ln & 3;
+        const double2 wd = fx_phasor((unsigned long long)(M * nql) * a.dphase0);
+        const v2f W = mk2((float)wd.x, (float)wd.y);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int c0 = (t >> 6) * 4 + k;
+            float2 w = a.tw64[(c0 * (subl + M * nql)) & 63];    // exp(-j 2pi m / 64); conjugated when INV
+            if (INV) w.y = -w.y;
+            ptw[c0 * 64 + ln] = pk_cmul2<false>(mk2(w.x, w.y), W);
+        }
     }
     __syncthreads();                                 // the only workgroup barrier: once per launch
 
     // (workgroup -> tile in launch order: dealing consecutive tiles to the same XCD, so that neighbours'
     // 3 shared rows meet in one L2, measured 8 % SLOWER -- the 64 output rows are then written at 8
     // distant fronts instead of one)
-    const int gw = (int)blockIdx.x * 4 + wv, nwaves = a.nwg * 4;
+    const int gw = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wv), nwaves = a.nwg * 4;   // (scalar: the tile index feeds SGPR operands)
     const long long tile_pos = (long long)kChT * M;                       // stream positions per tile
 
     // ---- branch role: lane = staged column p ------------------------------------------------------
-    v2f g[4], gj[4];                                 // complex taps 64q + p and j * taps
+    v2f g[4];                                        // complex taps 64q + p
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const float2 gq = q < Q ? a.gtaps[64 * q + l] : make_float2(0.0f, 0.0f);
         g[q] = mk2(gq.x, gq.y);
-        gj[q] = jtimes(g[q]);
     }
     const int mu = (l - P) & 63;
     // ---- DFT role: lane = (n' = l >> 2, sub = l & 3) ------------------------------------------------
     const int nq = l >> 2, sub = l & 3;
-    const float4* __restrict__ tw = twl + sub;          // entry c0 at tw[4 c0]
+    const v2f* __restrict__ tw = ptw + l;               // entry c0 at tw[64 c0]
     const int c1 = ((sub & 1) << 1) | (sub >> 1);    // radix-4 output this lane keeps (bit-reversed quad index)
     const v2f sA = (sub & 2) ? mk2(-1.0f, -1.0f) : mk2(1.0f, 1.0f), sB = (sub & 1) ? mk2(-1.0f, -1.0f) : mk2(1.0f, 1.0f);
-    // between the two radix-2 stages lane 3 takes the -+j twiddle; W(n') = exp(j 64 n' dphi_0) rides along
-    v2f Mq, Mqj;
-    {
-        const double2 w = fx_phasor((unsigned long long)(M * nq) * a.dphase0);
-        const v2f W = mk2((float)w.x, (float)w.y);
-        Mq = sub == 3 ? pk_mulj<INV>(W) : W;
-        Mqj = jtimes(Mq);
-    }
+    // between the two radix-2 stages lane 3 takes the -+j twiddle (the other lanes multiply by 1)
+    const v2f Mq = sub == 3 ? (INV ? mk2(0.0f, 1.0f) : mk2(0.0f, -1.0f)) : mk2(1.0f, 0.0f);
     // ---- channel role: lane = channel c ----------------------------------------------------------
     double2 corr, corr_step;
     {
@@ -152,6 +152,8 @@ __global__ __launch_bounds__(256, (M == 8) ? 2 : 3) void chan_uniform_kernel(con
                          ((unsigned long long)(sc * P) << 58));
         corr_step = fx_phasor((unsigned long long)(tile_pos * nwaves) * inc);
     }
+    const float theta_c = (float)((double)(a.ddelta[l] * (long long)M) * 3.4061215800865545e-19);   // 2pi / 2^64: exp(j theta_c) per output time
+    const float gm1_c = a.gm1[l];
 
     const v2f* __restrict__ in_or_hist = a.count > 0 ? in : hist;   // any readable address (P >= 1)
     constexpr int kSpan = (kChT - 1) * M + 64 * 4;   // input samples a tile's windows cover (1216 at M = 64)
@@ -169,26 +171,39 @@ __global__ __launch_bounds__(256, (M == 8) ? 2 : 3) void chan_uniform_kernel(con
     // ahead so the latency hides behind the previous tile's DFT), parked in the T region and the sliding windows
     // are read from LDS.
     constexpr bool kStaged = M != 64;
-    constexpr int kStRows = (kSpan + 63) / 64;
-    v2f pre[kStaged ? kStRows : 1];
-    auto load_rows = [&](int wt) {
-        const long long jb = (long long)wt * kChT * M - P + l;
-        if (jb - l >= 0 && jb - l + 64 * kStRows <= a.count) {
-#pragma unroll
-            for (int k = 0; k < kStRows; k++) pre[k] = in[jb + 64 * k];
-        } else {
-#pragma unroll
-            for (int k = 0; k < kStRows; k++) pre[k] = sample(jb, 64 * k);
-        }
+    // Round 3: the next tile's span is requested by LDS-DMA (ldsdma.hip.h) straight into the T region as soon as this tile's
+    // DFT inputs have been read out of it -- no staging registers (the 6 / 8 / 12 prefetched rows cost 12 / 16 / 24 VGPRs and
+    // the third wave per SIMD) -- and lands under the finish loop and its sixteen stores.  A request moves 128 samples
+    // (lanes x 16 bytes, contiguous in memory and in LDS); it starts on the 16-byte boundary at or below the span
+    // (`soff` = 0 or 1 samples of lead) and kStChunks of them cover the span + 1.  Tiles that touch the history or the end
+    // of the input are staged by guarded loads when they start (no prefetch: first and last tiles of a call only).
+    constexpr int kStChunks = (kSpan + 1 + 127) / 128;
+    static_assert(!kStaged || 128 * kStChunks <= kChT * kChRowT, "the staged span fits the T region");
+    const unsigned lds_T = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)T);
+    const unsigned voff = (unsigned)l * 16u;
+    auto span_start = [&](int wt) { return (long long)wt * kChT * M - P; };                 // stream position of the tile's first sample
+    auto lead = [&](int wt) { return (int)(((reinterpret_cast<uintptr_t>(in) >> 3) + (unsigned long long)span_start(wt)) & 1); };
+    auto dma_ok = [&](int wt) {
+        const long long s0 = span_start(wt) - lead(wt);
+        return wt < a.ntiles && s0 >= 0 && s0 + 128 * kStChunks <= a.count;
     };
-    if (kStaged && gw < a.ntiles) load_rows(gw);
+    auto request = [&](int wt) {
+        const v2f* src = in + (span_start(wt) - lead(wt));
+#pragma unroll
+        for (int k = 0; k < kStChunks; k++)
+            if (!(ABL & 2)) dma16_to_lds(src + 128 * k, voff, lds_T + (unsigned)(128 * k) * 8u);
+    };
+    bool requested = false, sixteen_younger = false;
+    if (kStaged && gw < a.ntiles && dma_ok(gw)) {
+        request(gw);
+        requested = true;
+    }
     for (int wt = gw; wt < a.ntiles; wt += nwaves) {
         const long long n0 = (long long)wt * kChT;            // first output time of the tile
         const long long jb = n0 * M - P + l;                   // stream position of this lane's column in row 0
         const bool interior = jb - l >= 0 && jb - l + kSpan <= a.count;
         {
-            const float cx = (float)corr.x, cy = (float)corr.y;
-            tab[kSlot(l)] = make_float4(cx, cy, -cy, cx);
+            tab[kSlot(l)] = make_float4((float)corr.x, (float)corr.y, theta_c, gm1_c);
             corr = dcmul(corr, corr_step);
         }
         // ---- branch sums: U[n'][mu] = sum_q g[64q + p] x[M n' + 64 q + p] --------------------------------
@@ -198,33 +213,59 @@ __global__ __launch_bounds__(256, (M == 8) ? 2 : 3) void chan_uniform_kernel(con
         {
             constexpr int RQ = 64 / M;
             constexpr int NX = kChT + 3 * RQ;
-            v2f x[NX];
             if constexpr (kStaged) {
+                int soff = 0;
+                if (requested) {
+                    soff = lead(wt);
+                    if (sixteen_younger) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // the DMA is older than the last tile's 16 stores
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else {
+                    constexpr int kStRows = (kSpan + 63) / 64;
+                    int lv = l;
+                    asm volatile("" : "+v"(lv));   // opaque: no per-lane 64-bit addresses hoisted out of the tile loop
 #pragma unroll
-                for (int k = 0; k < kStRows; k++) T[64 * k + l] = pre[k];
+                    for (int k = 0; k < kStRows; k++) T[64 * k + l] = sample(jb - l + lv, 64 * k);
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const v2f* __restrict__ col = T + l + soff;
+                // Round 3: the window is no longer held in registers (NX = 40 values = 80 VGPRs at M = 8).  The staged column is
+                // walked from its LAST value down; value r feeds the outputs n = r - RQ q, so 3 RQ + 1 accumulators are live at a
+                // time, and output n is complete once value r = n has been added: it goes to row n of T right away, IN PLACE --
+                // what is still to be read then lies below element M (n - 1) + 64 <= 68 n, the start of row n (the wave runs in
+                // lockstep and its LDS operations execute in order).
+                v2f acc[kChT];
 #pragma unroll
-                for (int r = 0; r < NX; r++) x[r] = T[l + M * r];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (wt + nwaves < a.ntiles) load_rows(wt + nwaves);
-            } else if (interior) {
+                for (int r = NX - 1; r >= 0; r--) {
+                    const v2f xr = col[M * r];
 #pragma unroll
-                for (int r = 0; r < NX; r++) x[r] = in[jb + M * r];
+                    for (int q = 3; q >= 0; q--) {
+                        const int n = r - RQ * q;
+                        if (n >= 0 && n < kChT) {
+                            if (q == 3) acc[n] = mk2(0.0f, 0.0f);     // first touch of output n (r = n + 3 RQ)
+                            if (q < Q) acc[n] = pk_cmac2(xr, g[q], acc[n]);
+                        }
+                    }
+                    if (r < kChT) T[r * kChRowT + mu] = acc[r];
+                }
             } else {
+                v2f x[NX];
+                if (interior) {
 #pragma unroll
-                for (int r = 0; r < NX; r++) x[r] = sample(jb, M * r);
-            }
+                    for (int r = 0; r < NX; r++) x[r] = in[jb + M * r];
+                } else {
 #pragma unroll
-            for (int n = 0; n < kChT; n++) {
-                v2f acc = mk2(0.0f, 0.0f);
+                    for (int r = 0; r < NX; r++) x[r] = sample(jb, M * r);
+                }
 #pragma unroll
-                for (int q = 0; q < 4; q++)
-                    if (q < Q) acc = pk_cmac(x[n + RQ * q], g[q], gj[q], acc);
-                T[n * kChRowT + mu] = acc;
+                for (int n = 0; n < kChT; n++) {
+                    v2f acc = mk2(0.0f, 0.0f);
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (q < Q) acc = pk_cmac2(x[n + RQ * q], g[q], acc);
+                    T[n * kChRowT + mu] = acc;
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -234,6 +275,15 @@ __global__ __launch_bounds__(256, (M == 8) ? 2 : 3) void chan_uniform_kernel(con
         v2f U[16];
 #pragma unroll
         for (int i = 0; i < 16; i++) U[i] = T[nq * kChRowT + sub + 4 * i];
+        if constexpr (kStaged) {
+            // T is free once every lane's reads above have returned: request the next tile's span into it
+            requested = dma_ok(wt + nwaves);
+            if (requested) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                request(wt + nwaves);
+            }
+        }
         pk_fft16<INV>(U);                            // over i -> group c0 at U[rev16(c0)]
         const long long nn = n0 + nq;
         const long long j = nn * M - P + a.kcentre;                  // window-centre position of this output
@@ -249,50 +299,74 @@ __global__ __launch_bounds__(256, (M == 8) ? 2 : 3) void chan_uniform_kernel(con
         const bool live = n0 + (l & 15) < a.nout;
         // (two copies of the loop: in the full-tile one nothing depends on `live`, so the compiler keeps
         // it one basic block and overlaps the table reads / DPP hazards of neighbouring groups)
-        auto finish = [&](auto guarded) {
+        // `quad`: keep the -ang^2/2 term of B_c(n') = exp(j n' theta_c) (host: only when 15 max|theta_c| > 1e-4: float-rounded
+        // uniform plans have theta ~ 1e-7 and the term is < 1e-12)
+        auto finish = [&](auto guarded, auto quad) {
 #pragma unroll
             for (int c0 = 0; c0 < 16; c0++) {
                 v2f z = U[rev16(c0)];
-                if (c0 != 0) {
-                    const float4 w = tw[4 * c0];
-                    z = pk_cmul(z, mk2(w.x, w.y), mk2(w.z, w.w));
-                    if constexpr (M != 64) {   // exp(+-j 2pi c0 M n'/64) (c1 drops out: 16 M is a multiple of 64)
-                        const float4 r = rootl[(c0 * nq) & (64 / M - 1)];
-                        z = pk_cmul(z, mk2(r.x, r.y), mk2(r.z, r.w));
-                    }
-                }
-                // stage A: pairs (sub, sub^2), then lane 3's -+j twiddle (and W) ; stage B: pairs (sub, sub^1)
+                z = pk_cmul2<false>(z, tw[64 * c0]);
+                // stage A: pairs (sub, sub^2), then lane 3's -+j twiddle ; stage B: pairs (sub, sub^1)
                 v2f ta = pk_fma(z, sA, dpp_quad<0x4E>(z));
-                ta = pk_cmul(ta, Mq, Mqj);
+                ta = pk_cmul2<false>(ta, Mq);
                 const v2f y = pk_fma(ta, sB, dpp_quad<0xB1>(ta));
                 // A_c(tile), B_c(n') and VOLK's magnitude sawtooth
                 const float4 A = tab[4 * c0 + c1];
-                const float2 tg = cst[4 * c0 + c1];
-                const v2f v = pk_cmul(y, mk2(A.x, A.y), mk2(A.z, A.w));
-                const float ang = fl * tg.x;
-                const float gain = fmaf(jm, tg.y, 1.0f);
-                const float brg = fmaf(ang * ang, -0.5f, 1.0f) * gain;
-                const v2f r = pk_fma(v.yx, mk2(-ang * gain, ang * gain), v * mk2(brg, brg));
+                const v2f v = pk_cmul2<false>(y, mk2(A.x, A.y));
+                v2f r;
+                if constexpr (decltype(quad)::value) {
+                    const float ang = fl * A.z;
+                    const float gain = fmaf(jm, A.w, 1.0f);
+                    const float ag = ang * gain;
+                    const float brg = fmaf(ang * ang, -0.5f, 1.0f) * gain;
+                    r = pk_fma(v.yx, mk2(-ag, ag), v * mk2(brg, brg));
+                } else {
+                    // v (1 + g1) (1 + j ang) with the second-order terms (ang^2 / 2 < 1e-8 / 2 by the host's test, ang g1 < 1e-8) left out:
+                    // v + g1 v + ang (j v) -- one packed multiply for (ang, g1) and two packed FMAs
+                    const v2f t2 = mk2(fl, jm) * mk2(A.z, A.w);                      // (ang, g1)
+                    r = pk_fma(v, t2.yy, v);
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[1,0,0]" : "+v"(r) : "v"(v), "v"(t2));
+                }
                 const v2f rt = bperm_pair(tsrc, r);
-                if (!decltype(guarded)::value || live) o[(size_t)c0 * a.out_stride] = rt;
+                if (ABL & 1) { if (rt.x == 1.2345e30f) o[(size_t)c0 * a.out_stride] = rt; }
+                else if (!decltype(guarded)::value || live) o[(size_t)c0 * a.out_stride] = rt;
             }
         };
-        if (n0 + kChT <= a.nout) finish(std::false_type{});
-        else finish(std::true_type{});
+        if (n0 + kChT <= a.nout) {
+            if (a.quad) finish(std::false_type{}, std::true_type{});
+            else finish(std::false_type{}, std::false_type{});
+            sixteen_younger = true;
+        } else {
+            finish(std::true_type{}, std::true_type{});
+            sixteen_younger = false;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-size_t chan_uniform_lds_bytes() { return (size_t)(4 * kChWaveLds + 128 + 64 + 128) * sizeof(float2); }
+size_t chan_uniform_lds_bytes() { return (size_t)(4 * kChWaveLds + 16 * 64) * sizeof(float2); }   // + the [c0][lane] twiddles
 
 int launch_chan_uniform(const ChanArgs& a, int grid, hipStream_t stream) {
     const size_t lds_bytes = chan_uniform_lds_bytes();
-#define QK_CHAN(m)                                                                                              \
-    case m:                                                                                                     \
-        if (a.inv) hipLaunchKernelGGL((chan_uniform_kernel<true, m>), dim3(grid), dim3(256), lds_bytes, stream, a);  \
-        else hipLaunchKernelGGL((chan_uniform_kernel<false, m>), dim3(grid), dim3(256), lds_bytes, stream, a);       \
+#define QK_CHAN(m)                                                                                                     \
+    case m:                                                                                                            \
+        if (a.Q == 4) {                                                                                                \
+            if (a.inv) hipLaunchKernelGGL((chan_uniform_kernel<true, m, 4>), dim3(grid), dim3(256), lds_bytes, stream, a);   \
+            else hipLaunchKernelGGL((chan_uniform_kernel<false, m, 4>), dim3(grid), dim3(256), lds_bytes, stream, a);        \
+        } else {                                                                                                       \
+            if (a.inv) hipLaunchKernelGGL((chan_uniform_kernel<true, m, 0>), dim3(grid), dim3(256), lds_bytes, stream, a);   \
+            else hipLaunchKernelGGL((chan_uniform_kernel<false, m, 0>), dim3(grid), dim3(256), lds_bytes, stream, a);        \
+        }                                                                                                              \
         break;
+    if (a.abl && a.M == 8 && !a.inv && a.Q == 4) {
+        if (a.abl == 1) hipLaunchKernelGGL((chan_uniform_kernel<false, 8, 4, 1>), dim3(grid), dim3(256), lds_bytes, stream, a);
+        else if (a.abl == 2) hipLaunchKernelGGL((chan_uniform_kernel<false, 8, 4, 2>), dim3(grid), dim3(256), lds_bytes, stream, a);
+        else hipLaunchKernelGGL((chan_uniform_kernel<false, 8, 4, 3>), dim3(grid), dim3(256), lds_bytes, stream, a);
+        const hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : -(int)e;
+    }
     switch (a.M) {
         QK_CHAN(64) QK_CHAN(32) QK_CHAN(16) QK_CHAN(8)
         default: return -1;

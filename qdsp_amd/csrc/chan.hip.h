@@ -20,6 +20,8 @@ struct ChanArgs {
     int ntiles;                // wave tiles of 16 output times: ceil(nout / 16)
     int nwg;                   // persistent workgroups of 4 independent waves (grid = nwg + 1: the last hands over history)
     int kcentre;               // tap index the per-channel deviation is evaluated at ((ntaps-1)/2)
+    int abl;                   // diagnostic builds only (QDSP_HIP_CHAN_ABL): ablation mask, 0 = the product
+    int quad;                  // 1: keep the second-order term of the per-output deviation rotation (15 max|theta_c| > 1e-4)
     int inv;                   // 1: channel spacing +1/64 turn/sample, 0: -1/64
     unsigned long long phase0, dphase0;   // channel 0's NCO (fixed point, 2^64 = one turn)
     unsigned long long dphi[64];   // phi_c - phi_0 at the first sample of this call

@@ -40,6 +40,28 @@ template <bool CONJ> __device__ __forceinline__ v2f pk_cmulc(v2f a, v2f b) {
     return pk_fma(b.yy * a.yx, CONJ ? mk2(1.0f, -1.0f) : mk2(-1.0f, 1.0f), b.xx * a);
 }
 
+// a * b (CONJ: a * conj(b)) in TWO packed instructions and without a companion operand: v_pk_mul_f32 + v_pk_fma_f32 with the lane
+// swap on op_sel and the ONE-lane sign on neg_lo / neg_hi -- modifiers the ISA has but hipcc does not select (it folds
+// whole-vector negation only), hence inline asm.  (Round 3; fir_fft_dmapk_kernel, chan_uniform_kernel.)
+template <bool CONJ> __device__ __forceinline__ v2f pk_cmul2(v2f a, v2f b) {   // a * b, CONJ: a * conj(b)
+    v2f r;
+    if (!CONJ)
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+            : "=&v"(r) : "v"(a), "v"(b));
+    else
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+            : "=&v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// a * b + c, companion-free (two packed FMAs)
+__device__ __forceinline__ v2f pk_cmac2(v2f a, v2f b, v2f c) {
+    v2f r = c;
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+        : "+v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 template <bool INV> __device__ __forceinline__ void pk_fft4(v2f& a0, v2f& a1, v2f& a2, v2f& a3) {
     const v2f t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, d = a1 - a3;
     a0 = t0 + t2;

@@ -42,6 +42,7 @@
 #include "fft_fir.hip.h"
 #include "cfft.hip.h"
 #include "cpk.hip.h"
+#include "ldsdma.hip.h"
 
 namespace qk {
 
@@ -428,16 +429,6 @@ __global__ __launch_bounds__(kFftNT, (DEC == 1 && !ROT && !REAL) ? 4 : 3) void f
 // Segments that touch the history or the end of the input take guarded loads into registers as in fir_fft_kernel.
 // The DMA instruction is inline asm (it must not enter hipcc's own vmcnt bookkeeping, which would drain it together with
 // the stores at the next barrier): M0 is saved and restored inside the statement (cdna_hip_programming.md 5.7).
-__device__ __forceinline__ void dma16_to_lds(const void* sbase, unsigned voff, unsigned lds_byte) {   // sbase, lds_byte wave-uniform
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
-}
-__device__ __forceinline__ void dma16_to_lds_nt(const void* sbase, unsigned voff, unsigned lds_byte) {   // the same, non-temporal
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
-}
 #define QK_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 __global__ __launch_bounds__(kFftNT, 4) void fir_fft_dma_kernel(const FftArgs a) {
@@ -618,17 +609,6 @@ __global__ __launch_bounds__(kFftNT, 4) void fir_fft_dma_kernel(const FftArgs a)
 // Packed instructions do two lanes' worth per issue: v_pk_add_f32 for the butterflies' adds, and a complex product is two
 // instructions -- v_pk_mul_f32 + v_pk_fma_f32 with the swap on op_sel and the ONE-lane sign on neg_lo / neg_hi (inline asm:
 // hipcc folds whole-vector negation only) -- instead of 2 v_mul + 2 v_fmac.
-template <bool CONJ> __device__ __forceinline__ v2f pk_cmul2(v2f a, v2f b) {   // a * b, CONJ: a * conj(b)
-    v2f r;
-    if (!CONJ)
-        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
-            : "=&v"(r) : "v"(a), "v"(b));
-    else
-        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
-            : "=&v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
 // STAMPS: diagnostic build (never shipped to a caller: launch_fir_fft takes it only when FftArgs::stamps is set, which only
 // scripts/stamp_fir_fft.py does): every wave sums, per phase of the segment loop, the shader-clock ticks (s_memtime) it
 // spent there; wave 0 of each workgroup writes its sixteen sums to stamps[blockIdx.x * 16 ..].  Nothing is computed from them.

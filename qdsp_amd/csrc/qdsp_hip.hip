@@ -2133,7 +2133,7 @@ int chan_launch_uniform(Chan* c, const void* d_in, int64_t count, int64_t nout, 
     a.Q = (c->ntaps + 63) / 64;
     a.M = c->decim;
     a.ntiles = (int)((nout + 15) / 16);
-    int nwg = 256 * env_int("QDSP_HIP_CHAN_WG_PER_CU", 12);  // 3 resident per CU, 4 rounds
+    int nwg = 256 * env_int("QDSP_HIP_CHAN_WG_PER_CU", 48);  // 3 resident per CU, 16 rounds (round 3: 12 -> 48: -2 %, profiles/r03_chan_tuning.txt)
     if (nwg > (a.ntiles + 3) / 4) nwg = (a.ntiles + 3) / 4;
     if (nwg < 1) nwg = 1;
     a.nwg = nwg;
@@ -2144,6 +2144,12 @@ int chan_launch_uniform(Chan* c, const void* d_in, int64_t count, int64_t nout, 
         a.dphi[i] = c->vfo[i]->phase - c->vfo[0]->phase;
         a.gm1[i] = c->volk_gain ? c->vfo[i]->gm1 : 0.0f;
     }
+    {   // second-order term of the per-output deviation rotation: only when 15 output times turn a channel by more than 1e-4 rad
+        long long dmax = 0;
+        for (int i = 0; i < 64; i++) dmax = std::max(dmax, a.ddelta[i] < 0 ? -a.ddelta[i] : a.ddelta[i]);
+        a.quad = 15.0 * (double)dmax * (double)a.M * 3.4061215800865545e-19 > 1e-4 || env_int("QDSP_HIP_CHAN_QUAD", 0);
+    }
+    a.abl = env_int("QDSP_HIP_CHAN_ABL", 0);
     const size_t lds = qk::chan_uniform_lds_bytes();
     int rc = qk::launch_chan_uniform(a, nwg + 1, s);
     if (rc) return rc;

@@ -44,7 +44,7 @@ def main():
     if a.zeros:
         x.zero_()
     nout = n // w["decim"] * w.get("interp", 1)
-    out = torch.empty((w["nchan"], nout) if "nchan" in w else nout, dtype=torch.complex64, device="cuda")
+    out = torch.empty((w["nchan"], nout + bench.CHAN_ROW_PAD) if "nchan" in w else nout, dtype=torch.complex64, device="cuda")
     op = bench.make_op(ops, a.workload, 0)
     apply(a.settings[0], names)
     for _ in range(5):   # settle the clocks
