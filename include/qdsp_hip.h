@@ -57,6 +57,11 @@ int qdsp_hip_device_count(int* count);
 /* Name / gcnArchName of a device into caller buffers (may be NULL). */
 int qdsp_hip_device_info(int device, char* name, int name_len, char* arch, int arch_len,
                          int* compute_units);
+/* The QDSP_HIP_* tuning / experiment variables are read ONCE, when the library first needs one, into an
+ * immutable table -- no getenv on the call path (the reference blocks hand over <= 1e6 samples per call, src/dsp/stream.h:7:
+ * a call lasts 3-8 us).  A process that changes its environment afterwards (tests, tuning scripts) calls this to have the
+ * table rebuilt; calls already running keep the table they started with.  Returns 0. */
+int qdsp_hip_reload_env(void);
 
 /* Link codes of the *_process_ex / sine generate `*_on_device` arguments (the device-resident companion of
  * dsp::stream<T>, src/dsp/stream.h:21-125): 0 = host buffer; 1 = device buffer, complete on entry / on return;

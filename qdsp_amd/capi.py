@@ -68,6 +68,7 @@ def load():
 
     sig("qdsp_hip_abi_version", i32)
     sig("qdsp_hip_error_string", C.c_char_p, i32)
+    sig("qdsp_hip_reload_env", i32)
     sig("qdsp_hip_device_count", i32, C.POINTER(i32))
     sig("qdsp_hip_device_info", i32, i32, C.c_char_p, i32, C.c_char_p, i32, C.POINTER(i32))
     sig("qdsp_hip_host_alloc", i32, pvp, C.c_size_t)
@@ -158,6 +159,20 @@ def load():
         raise QdspHipError("libqdsp_hip.so ABI version mismatch")
     _lib = L
     return L
+
+
+def reload_env() -> None:
+    """Have the library re-read its QDSP_HIP_* variables (they are snapshotted once: include/qdsp_hip.h, qdsp_hip_reload_env)."""
+    load().qdsp_hip_reload_env()
+
+
+def setenv(name: str, value) -> None:
+    """Set (value None: remove) one QDSP_HIP_* variable of this process AND make the library see it."""
+    if value is None:
+        os.environ.pop(name, None)
+    else:
+        os.environ[name] = str(value)
+    reload_env()
 
 
 def check(rc: int, what: str = "qdsp_hip") -> int:

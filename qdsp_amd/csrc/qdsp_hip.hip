@@ -9,6 +9,7 @@
 #include "mf_dec.hip.h"
 #include "rm_resamp.hip.h"
 #include "fir_lat.hip.h"
+#include "knobs.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -127,16 +128,11 @@ Engine* as_engine(void* h, Kind k) {
     return e;
 }
 
-int env_int(const char* name, int dflt) {
-    const char* s = getenv(name);
-    return (s && *s) ? atoi(s) : dflt;
-}
-
 // End-of-call wait of the host-pointer paths.  hipStreamSynchronize sleeps on an interrupt (~20 us to wake up),
 // longer than the kernels of a reference-sized block take: poll the stream for a bounded time first
 // (QDSP_HIP_SYNC_SPIN_US, default 200; 0 = always block).
 hipError_t wait_stream(hipStream_t s) {
-    static const int spin_us = env_int("QDSP_HIP_SYNC_SPIN_US", 200);
+    static const int spin_us = qk::knob(qk::K_SYNC_SPIN_US, 200);
     if (spin_us > 0) {
         const auto t0 = std::chrono::steady_clock::now();
         do {
@@ -153,7 +149,7 @@ hipError_t wait_stream(hipStream_t s) {
 hipError_t wait_event(hipEvent_t ev, hipStream_t s) {
     hipError_t rc = hipEventRecord(ev, s);
     if (rc != hipSuccess) return rc;
-    static const int spin_us = env_int("QDSP_HIP_SYNC_SPIN_US", 200);
+    static const int spin_us = qk::knob(qk::K_SYNC_SPIN_US, 200);
     if (spin_us > 0) {
         const auto t0 = std::chrono::steady_clock::now();
         do {
@@ -237,13 +233,13 @@ int64_t out_size(const Engine* e, int64_t count) {
 // fir_core_kernel (de-interleaved tile): FIR and decimations up to 8.  From 9 on the general kernel with its
 // staged-as-it-lies tile is 2-3x faster (scripts/tune_large_decim.py: M = 9..16, 31-255 taps: 0.12-0.38 ms per
 // 2^26 samples against 0.26-0.54).
-bool use_core(const Engine* e) { return e->L == 1 && e->M <= env_int("QDSP_HIP_CORE_MAX_DECIM", 8) && !env_int("QDSP_HIP_FORCE_ANY", 0); }
+bool use_core(const Engine* e) { return e->L == 1 && e->M <= qk::knob(qk::K_CORE_MAX_DECIM, 8) && !qk::knob(qk::K_FORCE_ANY, 0); }
 
 // decimators served by decim_win_kernel (kernels.hip.h): interp 1, short filters.  Outputs per lane and the
 // tap limit from scripts/tune_win.py / tune_small.py (2^26 samples): chunks of M*R <= 10 samples are the sweet
 // spot; past ~100-128 taps the overlap-save kernels take over (their pruned forms at M = 4, 8, 16 earlier).
 int win_R(int M, int P) {
-    const int r = env_int("QDSP_HIP_WIN_R", 0);      // experiments: 1, 2, 4 or 8 where instantiated
+    const int r = qk::knob(qk::K_WIN_R, 0);      // experiments: 1, 2, 4 or 8 where instantiated
     if (r == 1 || r == 2 || r == 4 || r == 8) return r;
     if (M == 1) return 8;
     if (M <= 3) return 4;
@@ -260,15 +256,15 @@ bool use_win(const Engine* e) {
     // 2 / 4 / 8 / 16 -- pruned inverse -- and 0.20-0.21 ms at every other decimation: full inverse, strided store)
     // ([1] = FIR<T> and equal-rate resamplers below the overlap-save threshold: 0.22 ms against 0.25 de-interleaved)
     static const int limit[17] = {0, 7, 150, 150, 160, 200, 256, 160, 200, 0, 192, 0, 224, 0, 0, 0, 256};
-    const int max_taps = env_int("QDSP_HIP_WIN_MAX_TAPS", limit[M]);
-    return e->P <= max_taps && env_int("QDSP_HIP_NO_WIN", 0) == 0;
+    const int max_taps = qk::knob(qk::K_WIN_MAX_TAPS, limit[M]);
+    return e->P <= max_taps && qk::knob(qk::K_NO_WIN, 0) == 0;
 }
 
 // interp / decim pairs served by resamp_lm_kernel (kernels.hip.h)
 bool use_lm(const Engine* e) {
     if (e->kind == KIND_FIR || !e->has_filter) return false;
     if (!(e->L == 2 || e->L == 3 || e->L == 4 || e->L == 5 || e->L == 10)) return false;
-    return e->M >= 1 && e->M <= 8 && env_int("QDSP_HIP_NO_LM", 0) == 0;
+    return e->M >= 1 && e->M <= 8 && qk::knob(qk::K_NO_LM, 0) == 0;
 }
 
 // Shapes the MFMA decimator (mf_dec.hip.h) serves: complex data, interp 1, at most 16 taps per polyphase column (the 16
@@ -279,14 +275,14 @@ bool use_lm(const Engine* e) {
 bool mf_plan(const Engine* e, int* KJ, int* QS, int* keep2) {
     if (e->ch != 2 || e->L != 1 || !e->has_filter || e->kind == KIND_FIR) return false;
     const int M = e->M, P = e->P;
-    if (M < env_int("QDSP_HIP_MF_MIN_DECIM", 9)) return false;
+    if (M < qk::knob(qk::K_MF_MIN_DECIM, 9)) return false;
     // decimations 130-256 (even): the kernel runs rows of M / 2 samples -- the decimator by M / 2 with the same taps -- and
     // keeps every other output; twice the matrix work for the outputs that count, on a unit that has the room
-    const int k2 = (M > 8 * qk::kMfMaxKJ && M <= 16 * qk::kMfMaxKJ && M % 2 == 0 && !env_int("QDSP_HIP_MF_NO_KEEP2", 0)) ? 1 : 0;
+    const int k2 = (M > 8 * qk::kMfMaxKJ && M <= 16 * qk::kMfMaxKJ && M % 2 == 0 && !qk::knob(qk::K_MF_NO_KEEP2, 0)) ? 1 : 0;
     const int Mk = k2 ? M / 2 : M;
     if (Mk > 8 * qk::kMfMaxKJ) return false;
     const int Q = (P + Mk - 1) / Mk;                  // taps per column: one set of 16 rows of the A operand, or two
-    if (Q > qk::kMfMaxQ || (Q > 16 && env_int("QDSP_HIP_MF_NO_QS2", 0))) return false;
+    if (Q > qk::kMfMaxQ || (Q > 16 && qk::knob(qk::K_MF_NO_QS2, 0))) return false;
     if (M < 14 && P < 12 * M) return false;
     if (use_win(e) && P < 6 * M) return false;
     *KJ = (Mk + 7) / 8;
@@ -376,8 +372,8 @@ int upload_taps(Engine* e, const float* taps, int ntaps) {
     // resamp_lm_kernel serves (decim >= 5, and 10/3: 1.2-2.2x at up to ~24 taps per phase).  Other short periods share a step
     // between period quads and run within +-15 % of the general kernel, which keeps them (QDSP_HIP_RM_MIN_INTERP lowers
     // the bar).
-    bool rm_wanted = e->L >= env_int("QDSP_HIP_RM_MIN_INTERP", 33) || (e->M == 1 && e->L >= 6 && !use_lm(e));
-    if (use_lm(e) && e->L >= 2 && !env_int("QDSP_HIP_NO_RM_SMALL", 0))
+    bool rm_wanted = e->L >= qk::knob(qk::K_RM_MIN_INTERP, 33) || (e->M == 1 && e->L >= 6 && !use_lm(e));
+    if (use_lm(e) && e->L >= 2 && !qk::knob(qk::K_NO_RM_SMALL, 0))
         rm_wanted = rm_wanted || (e->M >= 5 && e->P <= (e->L == 10 ? 36 : 24)) || (e->L == 10 && e->M >= 3 && e->P <= 24);
     if (e->ch == 2 && rm_wanted && e->has_filter && e->kind != KIND_FIR && !use_core(e) && e->M < (1 << 16)) {
         const int L0 = e->L, M0 = e->M, P = e->P;
@@ -539,8 +535,8 @@ int create(void** h, Kind kind, int device, int ch, bool rotate, bool has_filter
     e->ch = ch;
     e->rotate = rotate;
     e->has_filter = has_filter;
-    e->R = env_int("QDSP_HIP_R", 0);
-    e->NT = env_int("QDSP_HIP_NT", 0);
+    e->R = qk::knob(qk::K_R, 0);
+    e->NT = qk::knob(qk::K_NT, 0);
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (err == hipSuccess) err = hipEventCreate(&e->ev0);
     if (err == hipSuccess) err = hipEventCreate(&e->ev1);
@@ -627,7 +623,7 @@ int nco_tables(Engine* e, long long S, int NT, int na, const double2** tab) {
 template <class ARGS> int fill_stage_rot(Engine* e, ARGS& a, int NT, long long S, long long first, long long ntiles) {
     fill_stage_rot(a, NT);
     a.nco_tab = nullptr;
-    if (!e->rotate || env_int("QDSP_HIP_NO_NCO_TABLES", 0)) return 0;
+    if (!e->rotate || qk::knob(qk::K_NO_NCO_TABLES, 0)) return 0;
     const int na = (int)((ntiles + 255) / 256) + 1;
     if (na > 65536) return 0;
     int rc = nco_tables(e, S, NT, na, &a.nco_tab);
@@ -811,14 +807,14 @@ AnyPlan any_plan(int L, int M, int P, int ch, long long nout = -1) {
     p.Pp = (P + 3) & ~3;
     if (((p.Pp >> 2) & 1) == 0) p.Pp += 4;
     const long long tap_bytes = (long long)L * p.Pp * (long long)sizeof(float);
-    const bool lt = tap_bytes <= kMaxDynLds / 2 && env_int("QDSP_HIP_ANY_NO_LDS_TAPS", 0) == 0;
+    const bool lt = tap_bytes <= kMaxDynLds / 2 && qk::knob(qk::K_ANY_NO_LDS_TAPS, 0) == 0;
     p.tap_bytes = lt ? (int)tap_bytes : 0;
     // Tile = as many outputs as keep the staged input span inside what is left of the LDS budget.
     const long long max_elems = (kMaxDynLds - p.tap_bytes) / (ch * (int)sizeof(float));
-    long long tile = (long long)env_int("QDSP_HIP_ANY_TILE", 8) * NT;
+    long long tile = (long long)qk::knob(qk::K_ANY_TILE, 8) * NT;
     // interp 1 with a decimation that is a multiple of 4: lane windows M samples apart share LDS banks (4-way and
     // worse) -> one pad element per M samples
-    p.pad = L == 1 && (M & 3) == 0 && M <= 65536 && env_int("QDSP_HIP_ANY_NO_PAD", 0) == 0;
+    p.pad = L == 1 && (M & 3) == 0 && M <= 65536 && qk::knob(qk::K_ANY_NO_PAD, 0) == 0;
     auto span_of = [&](long long t) {
         const long long sp = ((t - 1) * M) / L + P + 2;
         return p.pad ? sp + sp / M + 1 : sp;
@@ -827,13 +823,13 @@ AnyPlan any_plan(int L, int M, int P, int ch, long long nout = -1) {
     // sums behind the samples).  Two lanes per output (tile 128) measured no better than one: the extra barrier
     // and LDS round trip cost what the halved tap loop saves (M = 50, 201 taps: 0.162 vs 0.145 ms).
     constexpr int kSplitTile = NT / 4;
-    const bool ks_ok = L == 1 && P >= 64 && env_int("QDSP_HIP_ANY_NO_SPLIT", 0) == 0;
+    const bool ks_ok = L == 1 && P >= 64 && qk::knob(qk::K_ANY_NO_SPLIT, 0) == 0;
     auto need = [&](long long t) { return span_of(t) + ((ks_ok && t <= kSplitTile) ? NT : 0); };
     while (tile > 1 && need(tile) > max_elems) tile /= 2;
     // reference-sized calls (nout known): 2048 outputs per tile leave a 1e6-sample block of a 24/125 audio resampler on 94
     // workgroups and a 16 384-sample one on 2 (10.3 us per call whatever the size); one to four outputs per lane spread it
     if (nout >= 0) {
-        const long long want = env_int("QDSP_HIP_ANY_SMALL_CALL_TILES", 512);   // (256 .. 4096 measured: 147/160 at 1e6 samples 9.5 / 9.1 / 10.0 / 11.2 us)
+        const long long want = qk::knob(qk::K_ANY_SMALL_CALL_TILES, 512);   // (256 .. 4096 measured: 147/160 at 1e6 samples 9.5 / 9.1 / 10.0 / 11.2 us)
         while (tile > NT && (nout + tile - 1) / tile < want) tile /= 2;
         // large decimations (taps split over the lanes of an output): down to 16 outputs per tile = 16 lanes per output, as long
         // as a lane keeps 16 taps -- the VFO's 401 taps / 50 on a 1e6-sample block: 100 dependent MACs per lane -> 25
@@ -842,7 +838,7 @@ AnyPlan any_plan(int L, int M, int P, int ch, long long nout = -1) {
             // (... and as long as the halved tiles still fit one round of the chip: the NCO variant keeps 3 workgroups per CU
             // resident, and a 769th workgroup waits for a whole round -- 401-513 taps / 40-64 on 1e6 samples: 9.4-9.5 us with
             // 783-978 tiles against 7.3-7.4 with 392-490)
-            const long long tmin = env_int("QDSP_HIP_ANY_MIN_SPLIT_TILE", 16);
+            const long long tmin = qk::knob(qk::K_ANY_MIN_SPLIT_TILE, 16);
             while (tile > tmin && tile <= kSplitTile && (nout + tile - 1) / tile < want && (nout + tile / 2 - 1) / (tile / 2) <= 768 &&
                    P / (2 * NT / tile) >= 16)
                 tile /= 2;
@@ -850,7 +846,7 @@ AnyPlan any_plan(int L, int M, int P, int ch, long long nout = -1) {
     }
     // a half-workgroup tile with a long tap loop: the quarter tile with four lanes per output is faster (M = 50,
     // 401 taps: 0.24 -> 0.17 ms) unless it stages too little per lane (M = 32: 9 samples in batches of 8)
-    if (ks_ok && tile == 2 * kSplitTile && P >= env_int("QDSP_HIP_ANY_SPLIT_MIN_TAPS", 192) && M >= 40) tile = kSplitTile;
+    if (ks_ok && tile == 2 * kSplitTile && P >= qk::knob(qk::K_ANY_SPLIT_MIN_TAPS, 192) && M >= 40) tile = kSplitTile;
     p.tile = need(tile) > max_elems ? 0 : tile;
     p.span = span_of(tile);
     p.ks_lanes = p.ks_shift = p.ks_chunk = 0;
@@ -892,12 +888,12 @@ template <int CH, bool ROT> int launch_any(Engine* e, qk::AnyArgs& a, hipStream_
     if (lds == 0) return QDSP_HIP_EINVAL;  // taps per phase beyond LDS
     // persistent workgroups, 8 per CU (measured on the M = 50, 401-tap VFO, 32 KB of LDS each: 5 per CU -- what is
     // resident at once -- 0.41 ms per 2^27 samples, 8 .. 64 per CU 0.345-0.358)
-    int nwg = 256 * env_int("QDSP_HIP_ANY_WG_PER_CU", 8);
+    int nwg = 256 * qk::knob(qk::K_ANY_WG_PER_CU, 8);
     if (nwg > a.nblocks) nwg = a.nblocks;
     if (nwg < 1) nwg = 1;
     a.nwg = nwg;
     // full persistent grids only: a contiguous tile range per XCD (kernels.hip.h)
-    a.xcd_tiles = (nwg >= 2048 && (nwg & 7) == 0 && !env_int("QDSP_HIP_ANY_NO_XCD", 0)) ? (a.nblocks + 7) / 8 : 0;
+    a.xcd_tiles = (nwg >= 2048 && (nwg & 7) == 0 && !qk::knob(qk::K_ANY_NO_XCD, 0)) ? (a.nblocks + 7) / 8 : 0;
     fill_stage_rot(a, NT);
     if (pad) {
         if (lt) hipLaunchKernelGGL((qk::resamp_any_kernel<CH, NT, ROT, true, true>), dim3(nwg + 1), dim3(NT), lds, s, a);
@@ -935,7 +931,7 @@ int fft_dec(const Engine* e) {
     return 0;
 }
 
-int mode_of(const Engine* e) { return e->fir_mode ? e->fir_mode : env_int("QDSP_HIP_FIR_MODE", 0); }
+int mode_of(const Engine* e) { return e->fir_mode ? e->fir_mode : qk::knob(qk::K_FIR_MODE, 0); }
 
 // Large decimations (the VFO's usual job: 2.4 Msps -> 48 kHz is M = 50) with the few taps per output such
 // filters have: the general direct kernel streams the input once and does P/M MACs per input sample, while the
@@ -945,7 +941,7 @@ int mode_of(const Engine* e) { return e->fir_mode ? e->fir_mode : env_int("QDSP_
 // tile * M samples), and the NCO costs it 0.015 ms instead of 0.055; 2-way bank conflicts (M = 2 mod 4) move
 // the crossover down.
 bool any_direct_wins(const Engine* e) {
-    if (e->L != 1 || e->ch != 2 || env_int("QDSP_HIP_NO_ANY_POLICY", 0)) return false;
+    if (e->L != 1 || e->ch != 2 || qk::knob(qk::K_NO_ANY_POLICY, 0)) return false;
     const AnyPlan pl = any_plan(1, e->M, e->P, e->ch);
     if (pl.tile == 0) return false;
     // tiles of 64 outputs and fewer (M >= 64 or so) split every output's taps over 4-16 lanes: 0.12-0.26 ms up to
@@ -960,7 +956,7 @@ bool fft1k_eligible(const Engine* e, int64_t count);
 
 bool fft_eligible(const Engine* e, int64_t count) {
     if (!fft_dec(e)) return false;
-    int mode = e->fir_mode ? e->fir_mode : env_int("QDSP_HIP_FIR_MODE", 0);
+    int mode = e->fir_mode ? e->fir_mode : qk::knob(qk::K_FIR_MODE, 0);
     if (mode == 1) return false;
     if (mode == 2) return true;
     // auto: calls big enough to fill the chip with 4096-point segments, and filters past the measured
@@ -971,21 +967,21 @@ bool fft_eligible(const Engine* e, int64_t count) {
     // (decimate-by-8, 256 taps: 324 vs 321 Gs/s)
     int min_taps;
     if (e->ch == 1) {
-        min_taps = env_int("QDSP_HIP_FFT_MIN_TAPS_REAL", 96);
+        min_taps = qk::knob(qk::K_FFT_MIN_TAPS_REAL, 96);
         if (e->M > 1 && min_taps < 32 * e->M) min_taps = 32 * e->M;
     } else if (e->M == 1 && e->kind != KIND_FIR) {
         // equal-rate resampler / pure xlating FIR: full inverse + per-element store (0.52 ms per 2^27 samples)
         // against the tile-per-block direct form (0.51 ms at 7 taps, 0.63 at 63)
-        min_taps = env_int("QDSP_HIP_FFT_MIN_TAPS", 24);
+        min_taps = qk::knob(qk::K_FFT_MIN_TAPS, 24);
     } else if (e->M == 1) {
         // FIR: the overlap-save kernel (a copy-speed 4.8 TB/s whatever the taps) beats the tile-per-block
         // direct form from 8 taps on (2^26 samples: 0.222 vs 0.256 ms at 7 taps, 0.225 vs 0.394 at 127)
-        min_taps = env_int("QDSP_HIP_FFT_MIN_TAPS", 8);
+        min_taps = qk::knob(qk::K_FFT_MIN_TAPS, 8);
         // reference-sized calls (<= 1e6 samples, stream.h:7) are latency-bound: one 4096-point segment takes ~9 us
         // whatever the taps, the direct form 4.7 / 5.7 us at 31 / 63 taps (8.3 at 1e6 samples) and 11-16 us at 256
         // (round 2: with one-wave 1024-point segments -- fft1k_fir.hip -- the small calls cross over at ~24 taps:
         // 31 taps x 1e6 samples 6.8 us against 7.2, 95 taps x 262144 5.7 against 6.9; profiles/r02_tune_fft1k.txt)
-        if (count < (1 << 21) && min_taps < 96) min_taps = env_int("QDSP_HIP_FFT_MIN_TAPS_SMALL", fft1k_eligible(e, count) ? 24 : 96);
+        if (count < (1 << 21) && min_taps < 96) min_taps = qk::knob(qk::K_FFT_MIN_TAPS_SMALL, fft1k_eligible(e, count) ? 24 : 96);
     } else {
         if (e->M >= 9 && !use_win(e) && any_direct_wins(e)) return false;
         // decimators (scripts/tune_small.py, profiles/r01_tune_small.txt): the direct form slows down with the
@@ -993,7 +989,7 @@ bool fft_eligible(const Engine* e, int64_t count) {
         // (0.20 / 0.16 / 0.18 ms vs 0.24 / 0.18 / 0.22), from M = 7 the overlap-save form wins at any length
         // (M = 8: 0.16 vs 0.25-0.29 ms; M = 16: 0.17 vs 0.45-0.49 ms)
         const int dflt = e->M >= 7 ? 2 : 112;
-        min_taps = env_int("QDSP_HIP_FFT_MIN_TAPS_DECIM", dflt);
+        min_taps = qk::knob(qk::K_FFT_MIN_TAPS_DECIM, dflt);
     }
     // (below 2^16 samples a 4096-point segment per workgroup leaves most of the chip idle; one-wave segments go down to 2^14)
     // (... and further where the alternative is fir_core_kernel on a long filter: 256-400 taps at decimation 3 / 8, 2048-16 000
@@ -1013,7 +1009,7 @@ bool fft_eligible(const Engine* e, int64_t count) {
         const int64_t by_work = (1 << 21) / e->ntaps;
         min_count = by_work < 1024 ? 1024 : by_work;
     }
-    return e->ntaps >= min_taps && count >= env_int("QDSP_HIP_FFT_MIN_COUNT", (int)min_count);
+    return e->ntaps >= min_taps && count >= qk::knob(qk::K_FFT_MIN_COUNT, (int)min_count);
 }
 
 // Spectrum of a short sequence zero-padded to F = 2^m points, FP64 radix-2 (twiddles from sincosl, rounded once): what the
@@ -1115,10 +1111,10 @@ int fft_prepare(Engine* e) {
 bool fft1k_eligible(const Engine* e, int64_t count) {
     if (e->L != 1 || e->ntaps < 2 || e->ntaps > 769) return false;   // (769 taps: a quarter of every segment is new)
     if (e->kind != KIND_FIR && e->kind != KIND_DECIM && e->kind != KIND_VFO) return false;
-    if (e->ch != 2 && (e->kind == KIND_VFO || e->rotate || env_int("QDSP_HIP_NO_FFT1K_REAL", 0))) return false;   // real data: two real segments per wave
-    const int mode = e->fir_mode ? e->fir_mode : env_int("QDSP_HIP_FIR_MODE", 0);
-    if (mode != 0 || env_int("QDSP_HIP_NO_FFT1K", 0)) return false;
-    const int forced = env_int("QDSP_HIP_FFT1K_MAX_COUNT", -1);
+    if (e->ch != 2 && (e->kind == KIND_VFO || e->rotate || qk::knob(qk::K_NO_FFT1K_REAL, 0))) return false;   // real data: two real segments per wave
+    const int mode = e->fir_mode ? e->fir_mode : qk::knob(qk::K_FIR_MODE, 0);
+    if (mode != 0 || qk::knob(qk::K_NO_FFT1K, 0)) return false;
+    const int forced = qk::knob(qk::K_FFT1K_MAX_COUNT, -1);
     if (forced >= 0) return count <= forced;
     // measured crossovers against the 4096-point kernels (scripts/tune_fft1k.py, profiles/r02_tune_fft1k.txt): the
     // overlap grows with the taps (1024 - ntaps + 1 new points per segment), decimations 2 / 4 / 8 / 16 have the
@@ -1277,13 +1273,13 @@ bool pfb_eligible(const Engine* e, int64_t count) {
     if (e->ch != 2 || e->L != 1 || e->M != qk::kPfbD || e->ntaps < 2) return false;
     if (e->kind != KIND_DECIM && e->kind != KIND_VFO) return false;
     if ((e->ntaps + qk::kPfbD - 1) / qk::kPfbD > qk::kPfbMaxQ) return false;
-    if (env_int("QDSP_HIP_NO_PFB", 0)) return false;
+    if (qk::knob(qk::K_NO_PFB, 0)) return false;
     // measured crossover (scripts/tune_pfb_threshold.py, 256 taps): a lone segment takes a wave ~7 us (15 us per call
     // with the table load) where fir_fft_kernel<8> needs 8 us, so the per-segment kernels keep the reference-sized
     // calls; from 2^23 samples (decimator) / 2^24 (fused VFO) on this form is ahead, 1.2x at 2^27
     // (never below one segment: the kernel's prefetch reads whole 4096-sample segments from a clamped in-range start)
     if (count < qk::kPfbSeg) return false;
-    return count >= (int64_t)env_int("QDSP_HIP_PFB_MIN_COUNT", e->rotate ? 1 << 24 : 1 << 23);
+    return count >= (int64_t)qk::knob(qk::K_PFB_MIN_COUNT, e->rotate ? 1 << 24 : 1 << 23);
 }
 
 int pfb_prepare(Engine* e) {
@@ -1367,7 +1363,7 @@ int raw_history(Engine* e, hipStream_t s, const float2** hist, float2** hist_raw
         e->hist_raw_cap = e->H;
         e->raw_valid = false;
     }
-    if (!e->raw_valid || env_int("QDSP_HIP_NO_RAW_CARRY", 0)) {
+    if (!e->raw_valid || qk::knob(qk::K_NO_RAW_CARRY, 0)) {
         const unsigned long long ph_first = e->phase - (unsigned long long)e->H * e->dphase;   // phase of history sample 0
         const Launch keep = e->last;
         const int rc = launch_xlate_inc(e, e->d_hist[e->cur], e->H, e->d_hist_raw[e->cur], 0ULL - ph_first, 0ULL - e->dphase, 0.0f, s);
@@ -1400,7 +1396,7 @@ int launch_pfb(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
     a.nseg = (int)((nout + a.Lo - 1) / a.Lo);
     // persistent workgroups of 4 waves, one segment per wave at a time; 2 workgroups resident per CU (72 KB of LDS,
     // ~220 VGPRs), QDSP_HIP_PFB_WG_PER_CU queued per CU
-    int nwg = 256 * env_int("QDSP_HIP_PFB_WG_PER_CU", 2);
+    int nwg = 256 * qk::knob(qk::K_PFB_WG_PER_CU, 2);
     if (nwg > 1024) nwg = 1024;
     const int need = (a.nseg + 3) / 4;
     if (nwg > need) nwg = need;
@@ -1465,10 +1461,10 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
         a.seg_shift = a.ov + 2;
         a.L = qk::kFftN - a.ov;
         a.nblocks = (int)((count + 2 + a.L - 1) / a.L);
-        a.vec = (((uintptr_t)d_in) & 15) == 0 && !env_int("QDSP_HIP_FFT_NOVEC", 0);
+        a.vec = (((uintptr_t)d_in) & 15) == 0 && !qk::knob(qk::K_FFT_NOVEC, 0);
     } else if (a.dec == 1) {
         a.ov = (e->ntaps - 1 + 1) & ~1;   // FIR: out index == stream position; even so segments stay 16-byte aligned
-        a.vec = ((((uintptr_t)d_in) | ((uintptr_t)d_out)) & 15) == 0 && !env_int("QDSP_HIP_FFT_NOVEC", 0);
+        a.vec = ((((uintptr_t)d_in) | ((uintptr_t)d_out)) & 15) == 0 && !qk::knob(qk::K_FFT_NOVEC, 0);
         a.seg_shift = a.ov;
         a.L = qk::kFftN - a.ov;
         a.nblocks = (int)((count + a.L - 1) / a.L);
@@ -1483,7 +1479,7 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
     if (e->ch == 1) {   // real data: one workgroup iteration = a PAIR of real segments
         a.real2 = 1;
         // 8-byte pair accesses: segments start on even samples (L, ov, seg_shift are even) of 8-byte aligned buffers
-        a.vec = ((((uintptr_t)d_in) | ((uintptr_t)d_out)) & 7) == 0 && !env_int("QDSP_HIP_FFT_NOVEC", 0);
+        a.vec = ((((uintptr_t)d_in) | ((uintptr_t)d_out)) & 7) == 0 && !qk::knob(qk::K_FFT_NOVEC, 0);
         a.nblocks = (a.nblocks + 1) / 2;
     }
     // FIR: 4 workgroups resident per CU (124 VGPRs, 37 KB LDS), 16 queued per CU for balance.
@@ -1491,13 +1487,13 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
     // (grouped only when the groups fill the chip -- measured crossover ~1000 groups, 2^25 samples at decimation 8 --
     // below that the segments run one per workgroup: a 1e6-sample block 10 us instead of 28)
     // FIR<complex_t> on aligned buffers: the LDS-DMA form (fir_fft_dma_kernel, fft_fir.hip)
-    a.nt = env_int("QDSP_HIP_FFT_NT", 0);
-    a.abl = env_int("QDSP_HIP_FFT_ABL", 0);
-    if (const char* st = getenv("QDSP_HIP_FFT_STAMPS")) a.stamps = reinterpret_cast<unsigned*>(strtoull(st, nullptr, 0));   // diagnostic: scripts/stamp_fir_fft.py
-    a.dma = (a.dec == 1 && !a.strided && !a.rot && e->ch == 2 && a.vec && a.ov <= 2048) ? env_int("QDSP_HIP_FFT_DMA", 1) : 0;   // 1: scalar arithmetic, 2: packed
-    const bool grouped = a.dec >= 4 && (a.nblocks + a.dec - 1) / a.dec >= env_int("QDSP_HIP_FFT_GROUP_MIN_UNITS", 1024);
+    a.nt = qk::knob(qk::K_FFT_NT, 0);
+    a.abl = qk::knob(qk::K_FFT_ABL, 0);
+    a.stamps = reinterpret_cast<unsigned*>(qk::knobs_snapshot()->fft_stamps);   // diagnostic: scripts/stamp_fir_fft.py
+    a.dma = (a.dec == 1 && !a.strided && !a.rot && e->ch == 2 && a.vec && a.ov <= 2048) ? qk::knob(qk::K_FFT_DMA, 1) : 0;   // 1: scalar arithmetic, 2: packed
+    const bool grouped = a.dec >= 4 && (a.nblocks + a.dec - 1) / a.dec >= qk::knob(qk::K_FFT_GROUP_MIN_UNITS, 1024);
     a.grouped = grouped ? 1 : 0;
-    const int per_cu = env_int("QDSP_HIP_FFT_WG_PER_CU", grouped ? 4 : 16);
+    const int per_cu = qk::knob(qk::K_FFT_WG_PER_CU, grouped ? 4 : 16);
     const int units = grouped ? (a.nblocks + a.dec - 1) / a.dec : a.nblocks;
     int nwg = 256 * per_cu;
     if (nwg > units) nwg = units;
@@ -1561,7 +1557,7 @@ int launch_xlate_inc(Engine* e, const void* d_in, int64_t count, void* d_out, un
     long long grid = (npairs + NT - 1) / NT;
     // one pair per lane up to 2^27 samples: measured 0.345 ms per 2^27 samples against 0.46 ms with 16 blocks per CU
     // looping 64 times (the per-lane FP64 sincos is cheaper than the lost memory-level parallelism)
-    { const long long cap = 256LL * env_int("QDSP_HIP_XLATE_WG_PER_CU", 1024); if (grid > cap) grid = cap; }
+    { const long long cap = 256LL * qk::knob(qk::K_XLATE_WG_PER_CU, 1024); if (grid > cap) grid = cap; }
     unit_of_fx_c(dphase, 1.0L, &a.rot_one.x, &a.rot_one.y);
     unit_of_fx_c(dphase, (long double)(2 * grid * NT), &a.rot_stride.x, &a.rot_stride.y);
     a.vec = (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0;   // d_in == nullptr (SineSource) counts as aligned
@@ -1578,9 +1574,9 @@ int launch_xlate_inc(Engine* e, const void* d_in, int64_t count, void* d_out, un
 // outputs per wave task: a task reads one tile of 16 rows beyond its own (T = 256: 6 %); small calls take shorter
 // tasks so that a reference-sized block still spreads over the chip (1e6 samples at decimation 50: 20 000 outputs)
 void mf_tasks(qk::MfArgs& a, int64_t nout, int nchan, bool rot) {
-    long long T = nout * nchan / env_int("QDSP_HIP_MF_TASKS", 2048);      // (one round of the chip: 3072 wave slots; 8192 left a 4M-sample call at T = 16 -- half of every task's reads its neighbour's -- and 18 us instead of 14)
+    long long T = nout * nchan / qk::knob(qk::K_MF_TASKS, 2048);      // (one round of the chip: 3072 wave slots; 8192 left a 4M-sample call at T = 16 -- half of every task's reads its neighbour's -- and 18 us instead of 14)
     T = (T + 15) / 16 * 16;
-    const long long tmax = env_int("QDSP_HIP_MF_TASK_MAX", rot ? 256 : 128);
+    const long long tmax = qk::knob(qk::K_MF_TASK_MAX, rot ? 256 : 128);
     if (T > tmax) T = tmax;
     if (T < 16) T = 16;
     a.T = (int)T;
@@ -1602,13 +1598,13 @@ void mf_rot_tables(unsigned long long dphase, int M, int KJ, double2* step, floa
 // fir_core_kernel 11.3+ (profiles/r02_tune_call_size.txt).
 bool fir_lat_eligible(const Engine* e, int64_t count) {
     if (e->kind != KIND_FIR || e->ch != 2 || !e->has_filter || e->L != 1 || e->M != 1) return false;
-    if (e->ntaps > 1024 || env_int("QDSP_HIP_NO_FIR_LAT", 0)) return false;
+    if (e->ntaps > 1024 || qk::knob(qk::K_NO_FIR_LAT, 0)) return false;
     // (a wave walks all taps of its 64 outputs: 600 taps take 9.3 us on 4096 samples, the one-wave overlap-save kernel 5.6)
     if (e->ntaps > 320 && fft1k_eligible(e, count)) return false;
     // measured: 2.5 us + 1.7e-7 us per tap and sample (63 / 127 / 256 taps at 65 536 samples: 2.9 / 3.6 / 5.3 us); what it
     // competes with is the overlap-save kernel (~9 us up to 262 144 samples) from 96 taps on, fir_core_kernel (5.7-6.1 us) below
     // -- and, for up to 769 taps, the one-wave-per-segment overlap-save kernel (5.2-5.9 us up to 262 144 samples whatever the taps)
-    const int64_t limit = env_int("QDSP_HIP_FIR_LAT_MAX_WORK", e->ntaps > 769 ? 1 << 25 : 1 << 24);
+    const int64_t limit = qk::knob(qk::K_FIR_LAT_MAX_WORK, e->ntaps > 769 ? 1 << 25 : 1 << 24);
     return count > 0 && count * (int64_t)e->ntaps <= limit;
 }
 int launch_fir_lat(Engine* e, const void* d_in, int64_t count, void* d_out, hipStream_t s) {
@@ -1655,7 +1651,7 @@ int launch_rm(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d_
     a.total = 4 * a.G * a.M + a.ext;
     const long long nper = (nout + a.L - 1) / a.L;
     a.ntiles = (int)((nper + 4 * a.G - 1) / (4 * a.G));
-    int nwaves = 1024 * env_int("QDSP_HIP_RM_WAVES_PER_SIMD", 3);
+    int nwaves = 1024 * qk::knob(qk::K_RM_WAVES_PER_SIMD, 3);
     if (nwaves > a.ntiles) nwaves = a.ntiles;
     if (nwaves < 1) nwaves = 1;
     a.nwaves = nwaves;
@@ -1700,7 +1696,7 @@ int launch_mf(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d_
         a.gm1 = e->volk_gain ? e->gm1 : 0.0f;
         mf_rot_tables(e->dphase, a.M, e->mf_KJ, &a.rot_step, a.rot_k);
     }
-    const int rc = qk::launch_mf_dec(a, e->mf_KJ, e->rotate, env_int("QDSP_HIP_MF_DEPTH", e->mf_KJ <= 8 ? 2 : 1), e->mf_QS, s);
+    const int rc = qk::launch_mf_dec(a, e->mf_KJ, e->rotate, qk::knob(qk::K_MF_DEPTH, e->mf_KJ <= 8 ? 2 : 1), e->mf_QS, s);
     if (rc) return rc < 0 && rc != -1 ? rc : QDSP_HIP_EINVAL;
     e->last.name = "decim_mfma_kernel";
     e->last.grid = (a.ntasks + 3) / 4 + 1;
@@ -1724,7 +1720,7 @@ int launch_mf(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d_
 // decimation 5, 2.5x at decimation 1-2, never beyond 2^20 outputs; filters under 16 taps per phase stay (3.8-4.5 us).
 // (interp 10, decim 7 past the MFMA kernel's tap range: the general kernel at every size -- 0.58 against 0.74 ms per 2^26)
 bool lm_yields_to_any(const Engine* e, int64_t nout) {
-    if (env_int("QDSP_HIP_NO_LM_SMALL_CALL_RULE", 0)) return false;
+    if (qk::knob(qk::K_NO_LM_SMALL_CALL_RULE, 0)) return false;
     if (e->L == 10 && e->M == 7) return true;
     if (e->P < 16) return false;
     int64_t lim = (int64_t)e->P * (e->M >= 5 ? 32768 : e->M >= 3 ? 16384 : 40960);
@@ -1736,19 +1732,19 @@ bool lm_yields_to_any(const Engine* e, int64_t nout) {
 // the one-wave overlap-save kernel takes 5.5 whatever the taps; from ~1e6 samples on the window kernel is ahead again
 // (profiles/r02_tune_fft1k.txt).
 bool win_yields_to_fft1k(const Engine* e, int64_t count) {
-    if (e->ch != 2 || e->ntaps < 96 || count > (1 << 19) || env_int("QDSP_HIP_NO_WIN_SMALL_CALL_RULE", 0)) return false;   // (real data: 5.6-6.8 us against 7.1-8.3)
+    if (e->ch != 2 || e->ntaps < 96 || count > (1 << 19) || qk::knob(qk::K_NO_WIN_SMALL_CALL_RULE, 0)) return false;   // (real data: 5.6-6.8 us against 7.1-8.3)
     return fft1k_eligible(e, count);
 }
 
 int64_t mf_min_count(const Engine* e) {
-    const int v = env_int("QDSP_HIP_MF_MIN_COUNT", -1);
+    const int v = qk::knob(qk::K_MF_MIN_COUNT, -1);
     if (v >= 0) return v;
     if (e->mf_keep2) return 1 << 24;
     if (e->mf_QS == 2 || e->mf_KJ > 4) return 3 << 20;
     return 0;
 }
 int64_t rm_min_count(const Engine* e) {
-    const int v = env_int("QDSP_HIP_RM_MIN_COUNT", -1);
+    const int v = qk::knob(qk::K_RM_MIN_COUNT, -1);
     if (v >= 0) return v;
     return e->L >= 33 ? 6 << 20 : 0;
 }
@@ -1767,7 +1763,7 @@ int64_t process_dev(Engine* e, const void* d_in, int64_t count, void* d_out, voi
     } else if (mode_of(e) == 0 && fir_lat_eligible(e, count)) {
         rc = launch_fir_lat(e, d_in, count, d_out, s);
         if (rc == 0) e->cur ^= 1;
-    } else if (e->d_taps_mf && mode_of(e) == 0 && nout > 0 && count >= mf_min_count(e) && !env_int("QDSP_HIP_NO_MF", 0)) {
+    } else if (e->d_taps_mf && mode_of(e) == 0 && nout > 0 && count >= mf_min_count(e) && !qk::knob(qk::K_NO_MF, 0)) {
         // large integer decimations (the VFO's usual job) as an FP32 matrix product on the MFMA units (mf_dec.hip.h)
         rc = launch_mf(e, d_in, count, nout, d_out, s);
         if (rc == 0) e->cur ^= 1;
@@ -1800,7 +1796,7 @@ int64_t process_dev(Engine* e, const void* d_in, int64_t count, void* d_out, voi
         if (e->ch == 2) rc = e->rotate ? launch_core<2, true>(e, a, s) : launch_core<2, false>(e, a, s);
         else rc = launch_core<1, false>(e, a, s);
         if (rc == 0) e->cur ^= 1;
-    } else if (e->d_taps_rm && e->rm_ngrp && mode_of(e) == 0 && nout > 0 && count >= rm_min_count(e) && !env_int("QDSP_HIP_NO_RM", 0)) {
+    } else if (e->d_taps_rm && e->rm_ngrp && mode_of(e) == 0 && nout > 0 && count >= rm_min_count(e) && !qk::knob(qk::K_NO_RM, 0)) {
         // rational ratios with interp >= 6 (48 kHz <-> 44.1 kHz is 147 / 160) on the MFMA units (rm_resamp.hip.h)
         rc = launch_rm(e, d_in, count, nout, d_out, s);
         if (rc == 0) e->cur ^= 1;
@@ -1899,7 +1895,7 @@ int64_t process_ex(Engine* e, const void* in, int in_dev, int count, void* out, 
     bool direct_out = false;
     if (!out_dev && count > 0) {
         const size_t out_bytes = (size_t)out_size(e, count) * e->ch * sizeof(float);
-        if (out_bytes > 0 && out_bytes <= (size_t)env_int("QDSP_HIP_DIRECT_OUT_MAX_BYTES", 1 << 20)) {
+        if (out_bytes > 0 && out_bytes <= (size_t)qk::knob(qk::K_DIRECT_OUT_MAX_BYTES, 1 << 20)) {
             void* mapped = mapped_host_ptr(out);
             if (mapped) { dst = mapped; direct_out = true; }
         }
@@ -2133,7 +2129,7 @@ int chan_launch_uniform(Chan* c, const void* d_in, int64_t count, int64_t nout, 
     a.Q = (c->ntaps + 63) / 64;
     a.M = c->decim;
     a.ntiles = (int)((nout + 15) / 16);
-    int nwg = 256 * env_int("QDSP_HIP_CHAN_WG_PER_CU", 48);  // 3 resident per CU, 16 rounds (round 3: 12 -> 48: -2 %, profiles/r03_chan_tuning.txt)
+    int nwg = 256 * qk::knob(qk::K_CHAN_WG_PER_CU, 48);  // 3 resident per CU, 16 rounds (round 3: 12 -> 48: -2 %, profiles/r03_chan_tuning.txt)
     if (nwg > (a.ntiles + 3) / 4) nwg = (a.ntiles + 3) / 4;
     if (nwg < 1) nwg = 1;
     a.nwg = nwg;
@@ -2147,9 +2143,9 @@ int chan_launch_uniform(Chan* c, const void* d_in, int64_t count, int64_t nout, 
     {   // second-order term of the per-output deviation rotation: only when 15 output times turn a channel by more than 1e-4 rad
         long long dmax = 0;
         for (int i = 0; i < 64; i++) dmax = std::max(dmax, a.ddelta[i] < 0 ? -a.ddelta[i] : a.ddelta[i]);
-        a.quad = 15.0 * (double)dmax * (double)a.M * 3.4061215800865545e-19 > 1e-4 || env_int("QDSP_HIP_CHAN_QUAD", 0);
+        a.quad = 15.0 * (double)dmax * (double)a.M * 3.4061215800865545e-19 > 1e-4 || qk::knob(qk::K_CHAN_QUAD, 0);
     }
-    a.abl = env_int("QDSP_HIP_CHAN_ABL", 0);
+    a.abl = qk::knob(qk::K_CHAN_ABL, 0);
     const size_t lds = qk::chan_uniform_lds_bytes();
     int rc = qk::launch_chan_uniform(a, nwg + 1, s);
     if (rc) return rc;
@@ -2167,10 +2163,10 @@ int chan_launch_uniform(Chan* c, const void* d_in, int64_t count, int64_t nout, 
 int chan_launch_batch_mf(Chan* c, const void* d_in, int64_t count, int64_t nout, void* d_out, int64_t out_stride, hipStream_t s,
                          void* const* out_ptrs) {
     Engine* e0 = c->vfo[0];
-    if (!e0->d_taps_mf || nout <= 0 || env_int("QDSP_HIP_NO_MF", 0) || env_int("QDSP_HIP_NO_MF_BATCH", 0)) return 1;
+    if (!e0->d_taps_mf || nout <= 0 || qk::knob(qk::K_NO_MF, 0) || qk::knob(qk::K_NO_MF_BATCH, 0)) return 1;
     // per wave: taps, slot table and an FP64 sincos before the first tile -- small launches are quicker on the general
     // direct kernel (profiles/r02_tune_chan_batch.txt: even at 4 channels x 1e6 samples, 16 x 1e6: 36 against 55 us)
-    if (count * c->nchan < (int64_t)env_int("QDSP_HIP_MF_BATCH_MIN_WORK", 1 << 22)) return 1;
+    if (count * c->nchan < (int64_t)qk::knob(qk::K_MF_BATCH_MIN_WORK, 1 << 22)) return 1;
     for (Engine* e : c->vfo)
         if (e->cur != e0->cur || !e->rotate || e->ch != 2 || !e->d_taps_mf || e->mf_KJ != e0->mf_KJ || e->mf_QS != 1 || e->mf_keep2) return 1;
     std::vector<qk::MfChanConst> key((size_t)c->nchan);
@@ -2207,7 +2203,7 @@ int chan_launch_batch_mf(Chan* c, const void* d_in, int64_t count, int64_t nout,
     mf_tasks(a, nout, c->nchan, true);
     b.out_stride = out_stride;
     b.cur = e0->cur;
-    const int depth = env_int("QDSP_HIP_MF_DEPTH", e0->mf_KJ <= 8 ? 2 : 1);
+    const int depth = qk::knob(qk::K_MF_DEPTH, e0->mf_KJ <= 8 ? 2 : 1);
     for (int base = 0; base < c->nchan; base += qk::kMfBatchMax) {
         const int nb = (c->nchan - base < qk::kMfBatchMax) ? c->nchan - base : qk::kMfBatchMax;
         b.tab = c->d_batch_mf + base;
@@ -2301,7 +2297,7 @@ int chan_launch_batch(Chan* c, const void* d_in, int64_t count, int64_t nout, vo
     a.in = d_in;
     a.phases = c->d_phases;
     // persistent workgroups per channel: the grid's x extent times the channels should fill the chip a few times over
-    int nwg = (256 * env_int("QDSP_HIP_ANY_WG_PER_CU", 8) + c->nchan - 1) / c->nchan;
+    int nwg = (256 * qk::knob(qk::K_ANY_WG_PER_CU, 8) + c->nchan - 1) / c->nchan;
     if (nwg > a.nblocks) nwg = a.nblocks;
     if (nwg < 1) nwg = 1;
     a.nwg = nwg;
@@ -2342,10 +2338,10 @@ int chan_launch_batch(Chan* c, const void* d_in, int64_t count, int64_t nout, vo
 // 16 channels of a 1e6-sample block 403 us as 16 launches) and wherever resamp_any_kernel is what a channel would run
 // anyway; chip-filling calls of plans that have a faster dedicated kernel (overlap-save, strided-window) keep it.
 bool chan_batch_wins(const Chan* c, int64_t count) {
-    if (c->nchan < 2 || env_int("QDSP_HIP_NO_CHAN_BATCH", 0)) return false;
+    if (c->nchan < 2 || qk::knob(qk::K_NO_CHAN_BATCH, 0)) return false;
     const Engine* e = c->vfo[0];
-    if (count <= (int64_t)env_int("QDSP_HIP_CHAN_BATCH_MAX_COUNT", 1 << 22)) return true;
-    if (e->d_taps_mf && !env_int("QDSP_HIP_NO_MF", 0) && !env_int("QDSP_HIP_NO_MF_BATCH", 0)) return true;   // what each channel would run anyway
+    if (count <= (int64_t)qk::knob(qk::K_CHAN_BATCH_MAX_COUNT, 1 << 22)) return true;
+    if (e->d_taps_mf && !qk::knob(qk::K_NO_MF, 0) && !qk::knob(qk::K_NO_MF_BATCH, 0)) return true;   // what each channel would run anyway
     const bool dedicated = (fft_eligible(e, count) || use_win(e) || use_core(e) || use_lm(e));
     return !dedicated;
 }
@@ -2358,14 +2354,14 @@ int64_t chan_process_dev(Chan* c, const void* d_in, int64_t count, void* d_out, 
     {
         int inv;
         long long dd[64];
-        const int mode = c->mode ? c->mode : env_int("QDSP_HIP_FIR_MODE", 0);
+        const int mode = c->mode ? c->mode : qk::knob(qk::K_FIR_MODE, 0);
         if (mode != 1 && chan_uniform_plan(c, &inv, dd)) {
             int rc = chan_launch_uniform(c, d_in, count, nout, d_out, out_stride, static_cast<hipStream_t>(stream));
             return rc ? rc : nout;
         }
     }
     {
-        const int mode = c->mode ? c->mode : env_int("QDSP_HIP_FIR_MODE", 0);
+        const int mode = c->mode ? c->mode : qk::knob(qk::K_FIR_MODE, 0);
         if (mode == 0 && count > 0 && chan_batch_wins(c, count)) {
             const int rc = chan_launch_batch(c, d_in, count, nout, d_out, out_stride, static_cast<hipStream_t>(stream));
             if (rc == 0) return nout;
@@ -2918,7 +2914,7 @@ int64_t qdsp_hip_chan_cf32_process_links(void* h, const void* in, int in_link, i
     const size_t out_bytes = (size_t)nout * sizeof(float2);
     for (int i = 0; i < c->nchan; i++) {
         if (out_links[i] == QDSP_HIP_LINK_HOST_DEFERRED || out_links[i] == QDSP_HIP_LINK_HOST) {
-            if (out_bytes > (size_t)env_int("QDSP_HIP_DIRECT_OUT_MAX_BYTES", 1 << 20)) return QDSP_HIP_ESIZE;
+            if (out_bytes > (size_t)qk::knob(qk::K_DIRECT_OUT_MAX_BYTES, 1 << 20)) return QDSP_HIP_ESIZE;
             void* m = out_bytes ? mapped_host_ptr(outs[i]) : outs[i];
             if (!m) return QDSP_HIP_ESIZE;
             dst[i] = m;
@@ -3018,7 +3014,7 @@ int qdsp_hip_chan_cf32_set_history_dev(void* h, const void* d_hist, void* s) {
         HIPCHK(hipMemcpyAsync(c->d_hist[c->cur], d_hist, (size_t)c->ntaps * sizeof(float2), hipMemcpyDeviceToDevice,
                               static_cast<hipStream_t>(s)));
     }
-    const int mode = c->mode ? c->mode : env_int("QDSP_HIP_FIR_MODE", 0);
+    const int mode = c->mode ? c->mode : qk::knob(qk::K_FIR_MODE, 0);
     if (mode == 1 || !chan_uniform_plan(c, &inv, dd))
         for (Engine* e : c->vfo) { int rc = set_history_dev(e, d_hist, s); if (rc) return rc; }
     return 0;
@@ -3126,7 +3122,7 @@ int qdsp_hip_event_destroy(void* ev) {
 int qdsp_hip_event_wait(void* ev) {
     if (!ev) return QDSP_HIP_EINVAL;
     hipEvent_t e = static_cast<hipEvent_t>(ev);
-    static const int spin_us = env_int("QDSP_HIP_SYNC_SPIN_US", 200);
+    static const int spin_us = qk::knob(qk::K_SYNC_SPIN_US, 200);
     if (spin_us > 0) {
         const auto t0 = std::chrono::steady_clock::now();
         do {

@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import bench  # noqa: E402
-from qdsp_amd import ops  # noqa: E402
+from qdsp_amd import capi, ops  # noqa: E402
 
 GEOMS = {
     "fir256": [(8, 256), (16, 256), (4, 256)],
@@ -29,7 +29,7 @@ def main():
         w = bench.WORKLOADS[name]
         out = torch.empty(n // w["decim"], dtype=torch.complex64, device="cuda")
         for (r, nt) in GEOMS[name]:
-            os.environ["QDSP_HIP_R"], os.environ["QDSP_HIP_NT"] = str(r), str(nt)
+            capi.setenv("QDSP_HIP_R", r); capi.setenv("QDSP_HIP_NT", nt)
             try:
                 op = bench.make_op(ops, name, 0)
                 op.process(x, out)
@@ -41,8 +41,8 @@ def main():
                 op.close()
             except Exception as e:  # noqa: BLE001
                 print(f"{name} R={r} NT={nt}: {e}", flush=True)
-    os.environ.pop("QDSP_HIP_R", None)
-    os.environ.pop("QDSP_HIP_NT", None)
+    capi.setenv("QDSP_HIP_R", None)
+    capi.setenv("QDSP_HIP_NT", None)
     # any-decimation VFO (the reference's typical 2.4 MHz -> 240 kHz): direct vs overlap-save + strided store
     for (dec, ntaps) in ((10, 97), (10, 256), (3, 63), (5, 128), (2, 256), (64, 256)):
         taps = bench.lowpass_taps(ntaps, 0.4 / dec)
@@ -72,9 +72,9 @@ def main():
         taps = bench.lowpass_taps(ntaps, 1.0 / 16.0)
         out = torch.empty(n, dtype=torch.complex64, device="cuda")
         for mode, wg, nt in ((1, 0, 0), (2, 8, 0), (2, 16, 0)):
-            os.environ["QDSP_HIP_FFT_NT"] = str(nt)
+            capi.setenv("QDSP_HIP_FFT_NT", str(nt))
             if wg:
-                os.environ["QDSP_HIP_FFT_WG_PER_CU"] = str(wg)
+                capi.setenv("QDSP_HIP_FFT_WG_PER_CU", str(wg))
             op = ops.Fir(taps, max_block=0)
             op.set_mode(mode)
             op.process(x, out)

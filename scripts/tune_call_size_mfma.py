@@ -4,9 +4,9 @@ import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import oracle as O
-from qdsp_amd import ops
-os.environ["QDSP_HIP_MF_MIN_COUNT"] = "0"
-os.environ["QDSP_HIP_RM_MIN_COUNT"] = "0"
+from qdsp_amd import capi, ops
+capi.setenv("QDSP_HIP_MF_MIN_COUNT", "0")
+capi.setenv("QDSP_HIP_RM_MIN_COUNT", "0")
 shapes = [(1, 50, 401), (1, 16, 129), (1, 25, 201), (1, 100, 801), (1, 200, 1601), (1, 50, 1201), (147, 160, 2349), (160, 147, 2557), (10, 7, 77), (3, 8, 57)]
 for L, M, ntaps in shapes:
     taps = (O.lowpass_taps_f64(ntaps, 0.4 / max(L, M)) * L).astype(np.float32)
@@ -18,8 +18,8 @@ for L, M, ntaps in shapes:
             out = torch.empty(n // M * L + 8, dtype=torch.complex64, device="cuda")
             t = []
             for off in ("0", "1"):
-                os.environ["QDSP_HIP_NO_MF"] = off
-                os.environ["QDSP_HIP_NO_RM"] = off
+                capi.setenv("QDSP_HIP_NO_MF", off)
+                capi.setenv("QDSP_HIP_NO_RM", off)
                 op = ops.Vfo(taps, L, M, ops.phase_delta(1.0, 0.1234), max_block=0) if vfo else ops.Resampler(taps, L, M, max_block=0)
                 for _ in range(10): op.process(x, out=out)
                 torch.cuda.synchronize()

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from bench import lowpass_taps
-from qdsp_amd import ops
+from qdsp_amd import capi, ops
 
 for (M, ntaps, nch) in ((50, 401, 4), (50, 401, 16), (50, 401, 64), (10, 97, 16), (8, 256, 16), (64, 256, 64)):
     taps = lowpass_taps(ntaps, 0.4 / M)
@@ -19,8 +19,8 @@ for (M, ntaps, nch) in ((50, 401, 4), (50, 401, 16), (50, 401, 64), (10, 97, 16)
         out = torch.empty((nch, n // M), dtype=torch.complex64, device="cuda")
         row = [f"M {M:3d} taps {ntaps:4d} ch {nch:3d} n {n:8d}"]
         for batch in (2, 1, 0):
-            os.environ["QDSP_HIP_NO_CHAN_BATCH"] = "0" if batch else "1"
-            os.environ["QDSP_HIP_NO_MF_BATCH"] = "0" if batch == 2 else "1"
+            capi.setenv("QDSP_HIP_NO_CHAN_BATCH", "0" if batch else "1")
+            capi.setenv("QDSP_HIP_NO_MF_BATCH", "0" if batch == 2 else "1")
             ch = ops.Channelizer(taps, 1, M, incs, max_block=0)
             for _ in range(10):
                 ch.process(x, out)

@@ -6,14 +6,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import bench
-from qdsp_amd import ops
+from qdsp_amd import capi, ops
 
 def t(mk, x, out, env):
-    for k, v in env.items(): os.environ[k] = v
+    for k, v in env.items(): capi.setenv(k, v)
     op = mk(); op.process(x, out); torch.cuda.synchronize()
     us = min(op.time_dev(x, out, 100) for _ in range(3)) * 1e3
     name = op.last_kernel()["name"]; op.close()
-    for k in env: os.environ.pop(k)
+    for k in env: capi.setenv(k, None)
     return us, name
 
 sizes = (131072, 262144, 524288, 1_000_000, 2 << 20, 3 << 20, 4 << 20, 6 << 20)

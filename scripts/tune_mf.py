@@ -4,7 +4,7 @@ import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import oracle as O
-from qdsp_amd import ops
+from qdsp_amd import capi, ops
 
 def run(M, ntaps, vfo, n, reps=10):
     taps = O.lowpass_taps_f64(ntaps, 0.4 / M).astype(np.float32)
@@ -21,15 +21,15 @@ def run(M, ntaps, vfo, n, reps=10):
     return ms * 1e3, (n * 8 * (1 + 1 / M)) / ms / 1e6 / 8000, op.last_kernel()["name"]
 
 if __name__ == "__main__":
-    os.environ["QDSP_HIP_MF_MIN_DECIM"] = "9"
+    capi.setenv("QDSP_HIP_MF_MIN_DECIM", "9")
     n = 1 << 27
     if "knobs" in sys.argv:
         for M, ntaps in [(50, 401), (64, 513), (40, 321), (16, 129), (100, 801)]:
             for vfo in (True, False):
                 for depth in ("1", "2"):
                     for tmax in ("128", "256", "512"):
-                        os.environ["QDSP_HIP_MF_DEPTH"] = depth
-                        os.environ["QDSP_HIP_MF_TASK_MAX"] = tmax
+                        capi.setenv("QDSP_HIP_MF_DEPTH", depth)
+                        capi.setenv("QDSP_HIP_MF_TASK_MAX", tmax)
                         us, frac, name = run(M, ntaps, vfo, n)
                         print(f"M={M} ntaps={ntaps} vfo={vfo} depth={depth} T={tmax} {name} {us:.1f} us frac={frac:.3f}", flush=True)
         sys.exit(0)
@@ -42,7 +42,7 @@ if __name__ == "__main__":
             taps = O.lowpass_taps_f64(ntaps, 0.4 / M).astype(np.float32)
             xs = O.synth_iq(0, M * 4000 + 17, seed=M)
             for vfo in (True, False):
-                os.environ["QDSP_HIP_NO_MF"] = "0"
+                capi.setenv("QDSP_HIP_NO_MF", "0")
                 op = ops.Vfo(taps, 1, M, ops.phase_delta(1.0, 0.2345), max_block=0) if vfo else ops.Resampler(taps, 1, M, max_block=0)
                 got = np.concatenate([op.process(torch.from_numpy(b).cuda()).cpu().numpy() for b in (xs[:M * 1500 + 5], xs[M * 1500 + 5:])])
                 if vfo:
@@ -53,7 +53,7 @@ if __name__ == "__main__":
                     want = np.concatenate([rs.process(b) for b in (xs[:M * 1500 + 5], xs[M * 1500 + 5:])])
                 err = rel_rms(got, want) if got.shape == want.shape else float("inf")
                 us, frac, name = run(M, ntaps, vfo, n)
-                os.environ["QDSP_HIP_NO_MF"] = "1"
+                capi.setenv("QDSP_HIP_NO_MF", "1")
                 us0, frac0, name0 = run(M, ntaps, vfo, n)
                 print(f"| {M} | {ntaps} | {'vfo' if vfo else 'decim'} | {name} {us:.0f} ({frac:.2f}) | {name0} | {us0:.0f} ({frac0:.2f}) | {err:.2g} |", flush=True)
         sys.exit(0)
@@ -63,8 +63,8 @@ if __name__ == "__main__":
         for tpm in (1, 2, 4, 8, 16):
             ntaps = M * tpm - (tpm > 1)
             for vfo in (True, False):
-                os.environ["QDSP_HIP_NO_MF"] = "0"
+                capi.setenv("QDSP_HIP_NO_MF", "0")
                 us, frac, name = run(M, ntaps, vfo, n)
-                os.environ["QDSP_HIP_NO_MF"] = "1"
+                capi.setenv("QDSP_HIP_NO_MF", "1")
                 us0, frac0, name0 = run(M, ntaps, vfo, n)
                 print(f"| {M} | {ntaps} | {'vfo' if vfo else 'decim'} | {us:.0f} ({frac:.2f}) | {name0} | {us0:.0f} ({frac0:.2f}) |", flush=True)

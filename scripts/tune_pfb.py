@@ -10,7 +10,7 @@ import torch
 
 import oracle as O
 from bench import lowpass_taps
-from qdsp_amd import ops
+from qdsp_amd import capi, ops
 
 
 def rms(a, b):
@@ -18,7 +18,7 @@ def rms(a, b):
 
 
 def check():
-    os.environ["QDSP_HIP_PFB_MIN_COUNT"] = "0"
+    capi.setenv("QDSP_HIP_PFB_MIN_COUNT", "0")
     x = O.synth_iq(0, 400_000, seed=5)
     xd = torch.from_numpy(x).cuda()
     inc = ops.phase_delta(1.0, 0.1234)
@@ -49,10 +49,10 @@ def timeit():
     taps = lowpass_taps(256, 1 / 16)
     for rot in (False, True):
         for pfb in (0, 1):
-            os.environ["QDSP_HIP_NO_PFB"] = "0" if pfb else "1"
+            capi.setenv("QDSP_HIP_NO_PFB", "0" if pfb else "1")
             for wg in ((2, 3, 4, 8) if pfb else (0,)):
                 if wg:
-                    os.environ["QDSP_HIP_PFB_WG_PER_CU"] = str(wg)
+                    capi.setenv("QDSP_HIP_PFB_WG_PER_CU", str(wg))
                 op = ops.Vfo(taps, 1, 8, inc, max_block=0) if rot else ops.Resampler(taps, 1, 8, max_block=0)
                 for _ in range(30):
                     op.process(x, out)

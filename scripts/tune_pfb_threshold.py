@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from bench import lowpass_taps
-from qdsp_amd import ops
+from qdsp_amd import capi, ops
 
 taps = lowpass_taps(256, 1 / 16)
 inc = ops.phase_delta(1.0, 0.1234)
@@ -18,8 +18,8 @@ for log2n in (16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 27):
     row = [f"2^{log2n}"]
     for rot in (False, True):
         for pfb in (0, 1):
-            os.environ["QDSP_HIP_NO_PFB"] = "0" if pfb else "1"
-            os.environ["QDSP_HIP_PFB_MIN_COUNT"] = "0"
+            capi.setenv("QDSP_HIP_NO_PFB", "0" if pfb else "1")
+            capi.setenv("QDSP_HIP_PFB_MIN_COUNT", "0")
             op = ops.Vfo(taps, 1, 8, inc, max_block=0) if rot else ops.Resampler(taps, 1, 8, max_block=0)
             op.set_mode(op.FFT)
             for _ in range(20):

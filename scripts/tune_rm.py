@@ -4,7 +4,7 @@ import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import oracle as O
-from qdsp_amd import ops
+from qdsp_amd import capi, ops
 
 def dev(a): return torch.from_numpy(a).cuda()
 def rel_rms(a, b): return float(np.sqrt(np.mean(np.abs(a - b) ** 2) / max(np.mean(np.abs(b) ** 2), 1e-30)))
@@ -50,8 +50,8 @@ def timing():
         for vfo in (False, True):
             row = []
             for norm in ("0", "1"):
-                os.environ["QDSP_HIP_NO_RM"] = norm
-                os.environ["QDSP_HIP_NO_LM"] = "0" if norm == "1" else "1"      # (column 1: resamp_mfma_kernel also where resamp_lm_kernel would be picked)
+                capi.setenv("QDSP_HIP_NO_RM", norm)
+                capi.setenv("QDSP_HIP_NO_LM", "0" if norm == "1" else "1")      # (column 1: resamp_mfma_kernel also where resamp_lm_kernel would be picked)
                 op = ops.Vfo(taps, L, M, ops.phase_delta(1.0, 0.2345), max_block=0) if vfo else ops.Resampler(taps, L, M, max_block=0)
                 nout = nin * L // M
                 out = torch.empty(nout + 8, dtype=torch.complex64, device="cuda")

@@ -6,14 +6,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import bench
-from qdsp_amd import ops
+from qdsp_amd import capi, ops
 
 def t(mk, x, out, env, iters):
-    for k, v in env.items(): os.environ[k] = v
+    for k, v in env.items(): capi.setenv(k, v)
     op = mk(); op.process(x, out); torch.cuda.synchronize()
     us = min(op.time_dev(x, out, iters) for _ in range(3)) * 1e3
     nm = op.last_kernel()["name"]; op.close()
-    for k in env: os.environ.pop(k)
+    for k in env: capi.setenv(k, None)
     return us, nm
 
 shapes = ((3, 7, 200), (2, 3, 64), (5, 2, 81), (10, 1, 160), (2, 1, 63), (3, 2, 100), (4, 5, 127), (10, 7, 400), (2, 1, 15), (5, 8, 640), (3, 1, 31), (24, 125, 1001), (147, 160, 2048))

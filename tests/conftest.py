@@ -13,6 +13,45 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "default_dispatch: runs under the library's own size thresholds (no overrides)")
 
 
+class _EnvPatch:
+    """pytest's monkeypatch with one addition: after a QDSP_HIP_* variable changes, the library is told to re-read its
+    environment (qdsp_hip_reload_env) -- it snapshots the variables once instead of calling getenv on every call."""
+
+    def __init__(self, mp):
+        self._mp = mp
+
+    def __getattr__(self, name):
+        return getattr(self._mp, name)
+
+    @staticmethod
+    def _reload():
+        from qdsp_amd import capi
+
+        if capi._lib is not None or os.path.exists(capi.LIB_PATH):
+            try:
+                capi.reload_env()
+            except Exception:  # noqa: BLE001  (no library on a CPU-only box without a build: nothing to tell)
+                pass
+
+    def setenv(self, name, value, *a, **k):
+        self._mp.setenv(name, value, *a, **k)
+        if name.startswith("QDSP_HIP_"):
+            self._reload()
+
+    def delenv(self, name, *a, **k):
+        self._mp.delenv(name, *a, **k)
+        if name.startswith("QDSP_HIP_"):
+            self._reload()
+
+
+@pytest.fixture
+def monkeypatch(monkeypatch):
+    p = _EnvPatch(monkeypatch)
+    yield p
+    monkeypatch.undo()
+    p._reload()
+
+
 @pytest.fixture(autouse=True)
 def _mfma_kernels_on_small_inputs(request, monkeypatch):
     """test_gpu_parity / test_gpu_ring drive the kernels with inputs of 10^4-10^6 samples so that the oracle finishes in

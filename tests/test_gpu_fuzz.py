@@ -1,0 +1,148 @@
+"""The SHIPPED dispatch under the driver's eyes: the library's own size thresholds, no overrides.
+
+Most of tests/test_gpu_parity.py lifts or lowers call-size thresholds (tests/conftest.py) so that oracle-sized inputs reach
+the kernels the bench-sized calls run.  This module does the opposite: every operator is created and called the way a user
+calls it -- no QDSP_HIP_* variable set -- and judged against the FP64-accumulating oracle (oracle/qdsp_oracle.c, restating
+src/dsp/filter.h:51-74, src/dsp/resampling.h:99-132, src/dsp/processing.h:55-70):
+
+  * directed plans, one per kernel family `process_dev` can pick, each at a call size on the side of its crossover where that
+    family is the default, plus the same plan on the OTHER side of the crossover where the rule is a call-size rule;
+  * a fixed-seed, time-boxed slice of scripts/fuzz_dispatch.py in default_only mode.
+The union of the kernel families seen must cover all of them."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+
+pytestmark = [pytest.mark.gpu, pytest.mark.default_dispatch]
+
+TOL = 3e-6
+_SEEN = set()          # kernel families reached so far by this module (one process, tests in file order)
+_NOT_DISPATCH = ("QDSP_HIP_LIB", "QDSP_HIP_NO_AUTOBUILD", "QDSP_HIP_DEVICE")
+
+
+def _no_overrides():
+    return not any(k.startswith("QDSP_HIP_") and k not in _NOT_DISPATCH for k in os.environ)
+
+FAMILIES = {"fir_core_kernel", "fir_lat_kernel", "fir_fft1k_kernel", "fir_fft_dma_kernel", "pfb_dec8_kernel", "decim_win_kernel",
+            "decim_mfma_kernel", "decim_mfma_batch_kernel", "resamp_lm_kernel", "resamp_mfma_kernel", "resamp_any_kernel",
+            "resamp_any_batch_kernel", "chan_uniform_kernel"}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from qdsp_amd import ops as _ops
+
+    return _ops
+
+
+def _rel(a, b, floor=0.0):
+    return float(np.sqrt(np.mean(np.abs(a - b) ** 2) / max(np.mean(np.abs(b) ** 2), floor ** 2, 1e-30)))
+
+
+def _lp(ntaps, fc, gain=1.0):
+    return (O.lowpass_taps_f64(ntaps, fc) * gain).astype(np.float32)
+
+
+def _dev(x):
+    import torch
+
+    return torch.from_numpy(x).cuda()
+
+
+# (what, interp, decim, ntaps, nco, call sizes and the kernel family each call must land on)
+DIRECTED = [
+    ("fir", 1, 1, 63, False, [(65_536, "fir_lat_kernel")]),
+    ("fir", 1, 1, 15, False, [(2_000_000, "fir_core_kernel")]),
+    ("fir", 1, 1, 256, False, [(16_384, "fir_lat_kernel"), (1_000_000, "fir_fft1k_kernel"), (5 << 20, "fir_fft_dma_kernel")]),
+    ("res", 1, 8, 256, False, [(1_000_000, "fir_fft1k_kernel"), ((1 << 23) + 8, "pfb_dec8_kernel")]),
+    ("res", 1, 8, 256, True, [((1 << 24) + 16, "pfb_dec8_kernel")]),
+    ("res", 1, 4, 63, False, [(200_000, "decim_win_kernel")]),
+    ("res", 1, 16, 129, True, [(300_000, "decim_mfma_kernel")]),
+    ("res", 1, 50, 401, True, [(100_000, "resamp_any_kernel"), (3_200_000, "decim_mfma_kernel")]),
+    ("res", 3, 2, 36, False, [(100_000, "resamp_lm_kernel")]),
+    ("res", 10, 7, 160, False, [(100_000, "resamp_mfma_kernel")]),
+    ("res", 7, 5, 140, True, [(100_000, "resamp_any_kernel")]),
+    ("res", 147, 160, 147 * 16 - 3, False, [(200_000, "resamp_any_kernel"), (6_400_000, "resamp_mfma_kernel")]),
+]
+
+
+@pytest.mark.parametrize("plan", DIRECTED, ids=lambda p: f"{p[0]}_{p[1]}_{p[2]}_{p[3]}{'_nco' if p[4] else ''}")
+def test_directed_plans_default_thresholds(ops, plan):
+    what, L, M, ntaps, nco, calls = plan
+    assert _no_overrides(), "this module runs under the library's own thresholds"
+    taps = _lp(ntaps, 0.45 / max(L, M), L)
+    f = 0.1234
+    if what == "fir":
+        op, orc = ops.Fir(taps, max_block=0), O.Fir(taps, acc=O.ACC_F64)
+        ref = orc.process
+    elif nco:
+        op = ops.Vfo(taps, L, M, ops.phase_delta(1.0, f), max_block=0)
+        xl, rs = O.Xlator(1.0, f, exact=True, volk_gain=True), O.Resampler(taps, L, M, acc=O.ACC_F64)
+        ref = lambda b: rs.process(xl.process(b))   # noqa: E731
+    else:
+        op, rs = ops.Resampler(taps, L, M, max_block=0), O.Resampler(taps, L, M, acc=O.ACC_F64)
+        ref = rs.process
+    pos = 0
+    for count, family in calls:      # one continuous stream: the handle's history crosses the kernel families
+        x = O.synth_iq(pos, count, seed=ntaps + M)
+        pos += count
+        got = op.process(_dev(x)).cpu().numpy()
+        name = op.last_kernel()["name"]
+        assert name == family, (plan, count, name)
+        want = ref(x)
+        assert got.shape == want.shape and _rel(got, want) < TOL, (plan, count, name)
+        _SEEN.add(name)
+
+
+def test_directed_channel_banks_default_thresholds(ops):
+    """Splitter -> N x VFO (src/dsp/routing.h:47-57 + src/dsp/vfo.h:19-36): the uniform 64-channel plan, and arbitrary offsets on
+    both sides of the batch kernels' work threshold."""
+    # uniform plan: (c - 31.5) fs / 64, decimation 64
+    taps = _lp(256, 1.0 / 16.0)       # (the parity tests' 256 taps: FP32 rounding is relative to what goes IN, so a 1/128-band filter,
+                                      # whose output is 18 dB below its input, would need the input-referred floor fuzz_dispatch uses)
+    incs = [ops.phase_delta(1.0, -(c - 31.5) / 64.0) for c in range(64)]
+    ch = ops.Channelizer(taps, 1, 64, incs, max_block=0)
+    x = O.synth_iq(0, 64 * 3000, seed=9)
+    y = ch.process(_dev(x)).cpu().numpy()
+    assert ch.last_kernel()["name"] == "chan_uniform_kernel"
+    _SEEN.add("chan_uniform_kernel")
+    for c in (0, 17, 63):
+        want = O.Resampler(taps, 1, 64, acc=O.ACC_F64).process(O.Xlator(1.0, -(c - 31.5) / 64.0, exact=True, volk_gain=True).process(x))
+        assert _rel(y[c], want) < 4e-6, c
+    # arbitrary offsets, 401 taps / 50: 4 channels x 100 000 samples (general batch kernel), 8 x 600 000 (MFMA batch kernel)
+    taps = _lp(401, 0.45 / 50)
+    for nch, count, family in ((4, 100_000, "resamp_any_batch_kernel"), (8, 600_000, "decim_mfma_batch_kernel")):
+        freqs = [(-0.4 + 0.8 * c / nch) for c in range(nch)]
+        ch = ops.Channelizer(taps, 1, 50, [ops.phase_delta(1.0, f) for f in freqs], max_block=0)
+        x = O.synth_iq(0, count, seed=nch)
+        y = ch.process(_dev(x)).cpu().numpy()
+        assert ch.last_kernel()["name"] == family, (nch, count, ch.last_kernel()["name"])
+        _SEEN.add(family)
+        for c in (0, nch - 1):
+            want = O.Resampler(taps, 1, 50, acc=O.ACC_F64).process(O.Xlator(1.0, freqs[c], exact=True, volk_gain=True).process(x))
+            assert y[c].shape == want.shape and _rel(y[c], want) < TOL, (nch, c)
+
+
+def test_random_slice_default_thresholds_covers_every_family(ops):
+    """60 s of scripts/fuzz_dispatch.py (seed fixed) with no threshold touched, then: every kernel family of the dispatch has
+    been exercised by this module."""
+    import fuzz_dispatch
+
+    assert _no_overrides()
+    n, worst, kernels = fuzz_dispatch.run(float(os.environ.get("QDSP_TEST_FUZZ_SECONDS", "60")), 20260403, default_only=True, verbose=False)
+    assert n >= 20 and worst < TOL, (n, worst, kernels)
+    seen = _SEEN | set(kernels)
+    print(f"fuzz slice: {n} cases, worst {worst:.2e}; families seen by this module: {sorted(seen)}")
+    missing = FAMILIES - seen
+    assert not missing, f"kernel families never reached under the default thresholds: {sorted(missing)}"
