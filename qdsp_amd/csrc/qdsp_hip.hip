@@ -91,6 +91,7 @@ struct Engine {
     float2* d_fft_TA = nullptr;
     float2* d_fft_TB = nullptr;
     int fft_ntaps = -1;         // tap count d_fft_H was built for (-1: not built)
+    bool fft_tw_ready = false, f1k_tw_ready = false;   // twiddle tables allocated AND uploaded (set last: a failed first call retries them)
     // 1024-point segments, one wave each (fft1k_fir.hip): spectrum in that kernel's pass-C order + its twiddles
     float2* d_f1k_H = nullptr;
     float2* d_f1k_T = nullptr;  // [16][64] W1024^(l ka), then [16][4] W64^(j kb1)
@@ -1051,11 +1052,12 @@ void host_spectrum(const std::vector<long double>& gr, const std::vector<long do
 int fft_prepare(Engine* e) {
     // fused VFO: the spectrum is that of taps[k] * exp(j k dphase) (fft_fir.hip.h), so it follows the NCO
     const unsigned long long key_dphase = e->rotate ? e->dphase : 0;
-    if (e->fft_ntaps == e->ntaps && e->d_fft_H && e->fft_dphase == key_dphase) return 0;
+    if (e->fft_ntaps == e->ntaps && e->fft_tw_ready && e->fft_dphase == key_dphase) return 0;
     constexpr int F = qk::kFftN;
     const long double two_pi = 6.283185307179586476925286766559005768L;
     std::vector<long double> cs, sn;
-    if (!e->d_fft_H) {   // (the twiddle tables below: once per handle)
+    if (!e->fft_tw_ready) {   // (the twiddle tables below: once per handle -- the flag, not a pointer: it is set only after every
+                              // allocation and upload of the first-time block has succeeded)
         cs.resize(F);
         sn.resize(F);
         for (int i = 0; i < F; i++) {
@@ -1085,16 +1087,17 @@ int fft_prepare(Engine* e) {
         const int k0 = k & 15, k1 = (k >> 4) & 15, k2 = k >> 8;
         Hp[(k0 * 16 + k1) * 16 + k2] = make_float2((float)(sre[k] / F), (float)(sim[k] / F));
     }
-    if (!e->d_fft_H) {
+    if (!e->fft_tw_ready) {
         for (int t = 0; t < 256; t++)
             for (int k = 0; k < 16; k++) TA[t * 16 + k] = make_float2((float)cs[(t * k) % F], (float)(-sn[(t * k) % F]));
         for (int lo = 0; lo < 16; lo++)
             for (int k = 0; k < 16; k++) TB[lo * 16 + k] = make_float2((float)cs[(16 * lo * k) % F], (float)(-sn[(16 * lo * k) % F]));
-        HIPCHK(hipMalloc(&e->d_fft_H, sizeof(float2) * F));
-        HIPCHK(hipMalloc(&e->d_fft_TA, sizeof(float2) * 256 * 16));
-        HIPCHK(hipMalloc(&e->d_fft_TB, sizeof(float2) * 16 * 16));
+        if (!e->d_fft_H) HIPCHK(hipMalloc(&e->d_fft_H, sizeof(float2) * F));
+        if (!e->d_fft_TA) HIPCHK(hipMalloc(&e->d_fft_TA, sizeof(float2) * 256 * 16));
+        if (!e->d_fft_TB) HIPCHK(hipMalloc(&e->d_fft_TB, sizeof(float2) * 16 * 16));
         HIPCHK(hipMemcpy(e->d_fft_TA, TA.data(), sizeof(float2) * TA.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(e->d_fft_TB, TB.data(), sizeof(float2) * TB.size(), hipMemcpyHostToDevice));
+        e->fft_tw_ready = true;
     }
     HIPCHK(hipDeviceSynchronize());   // (retune / new taps: nothing in flight may still read the old spectrum)
     HIPCHK(hipMemcpy(e->d_fft_H, Hp.data(), sizeof(float2) * F, hipMemcpyHostToDevice));
@@ -1135,11 +1138,11 @@ bool fft1k_eligible(const Engine* e, int64_t count) {
 
 int fft1k_prepare(Engine* e) {
     const unsigned long long key_dphase = e->rotate ? e->dphase : 0;
-    if (e->f1k_ntaps == e->ntaps && e->d_f1k_H && e->f1k_dphase == key_dphase) return 0;
+    if (e->f1k_ntaps == e->ntaps && e->f1k_tw_ready && e->f1k_dphase == key_dphase) return 0;
     constexpr int F = qk::kFft1kN;
     const long double two_pi = 6.283185307179586476925286766559005768L;
     std::vector<long double> cs, sn;
-    if (!e->d_f1k_H) {   // (the twiddle tables below: once per handle)
+    if (!e->f1k_tw_ready) {   // (the twiddle tables below: once per handle; see fft_prepare for the flag)
         cs.resize(F);
         sn.resize(F);
         for (int i = 0; i < F; i++) {
@@ -1171,18 +1174,15 @@ int fft1k_prepare(Engine* e) {
         const int ka = k & 15, kb1 = (k >> 4) & 15, kb0 = k >> 8;
         Hp[(4 * (kb1 & 3) + kb0) * 64 + ((ka << 2) | (kb1 >> 2))] = make_float2((float)(re / F), (float)(im / F));
     }
-    if (!e->d_f1k_H) {
+    if (!e->f1k_tw_ready) {
         for (int l = 0; l < 64; l++)
             for (int k = 0; k < 16; k++) T[k * 64 + l] = make_float2((float)cs[(l * k) % F], (float)(-sn[(l * k) % F]));
         for (int j = 0; j < 4; j++)
             for (int k = 0; k < 16; k++) T[1024 + k * 4 + j] = make_float2((float)cs[(16 * j * k) % F], (float)(-sn[(16 * j * k) % F]));
-        HIPCHK(hipMalloc(&e->d_f1k_H, sizeof(float2) * F));
-        if (hipMalloc(&e->d_f1k_T, sizeof(float2) * T.size()) != hipSuccess) {
-            (void)hipFree(e->d_f1k_H);
-            e->d_f1k_H = nullptr;
-            return QDSP_HIP_ENOMEM;
-        }
+        if (!e->d_f1k_H) HIPCHK(hipMalloc(&e->d_f1k_H, sizeof(float2) * F));
+        if (!e->d_f1k_T) HIPCHK(hipMalloc(&e->d_f1k_T, sizeof(float2) * T.size()));
         HIPCHK(hipMemcpy(e->d_f1k_T, T.data(), sizeof(float2) * T.size(), hipMemcpyHostToDevice));
+        e->f1k_tw_ready = true;
     }
     HIPCHK(hipDeviceSynchronize());   // (retune / new taps: nothing in flight may still read the old spectrum)
     HIPCHK(hipMemcpy(e->d_f1k_H, Hp.data(), sizeof(float2) * F, hipMemcpyHostToDevice));
@@ -2013,6 +2013,7 @@ struct Chan {
     void* d_in = nullptr;
     void* d_out = nullptr;
     int max_block = 0;
+    size_t d_in_cap = 0;           // samples d_in holds (>= max_block; grown by process_links for host inputs)
     size_t out_cap = 0;            // samples per channel
     // uniform polyphase fast path (chan.hip): 64 channels spaced +-1/64 turn/sample, decim 64
     int mode = 0;                  // QDSP_HIP_FIR_AUTO / _DIRECT (one fused VFO kernel per channel) / _FFT (= fast path if the plan allows)
@@ -2856,6 +2857,7 @@ int qdsp_hip_chan_cf32_create(void** h, int device, const float* taps, int ntaps
         const size_t oc = (size_t)out_size(c->vfo[0], max_block) + 1;
         if (hipMalloc(&c->d_in, (size_t)max_block * 8) != hipSuccess || hipMalloc(&c->d_out, oc * 8 * nchan) != hipSuccess) rc = QDSP_HIP_ENOMEM;
         c->max_block = max_block;
+        c->d_in_cap = (size_t)max_block;
         c->out_cap = oc;
     }
     if (rc) { chan_destroy(c); return rc; }
@@ -2924,11 +2926,14 @@ int64_t qdsp_hip_chan_cf32_process_links(void* h, const void* in, int in_link, i
     }
     const void* src = in;
     if (in_link == QDSP_HIP_LINK_HOST) {
-        if (count > c->max_block || !c->d_in) {
+        // the staging buffer of THIS entry point has its own capacity: max_block stays what d_out (sized at creation) can hold,
+        // so a later qdsp_hip_chan_cf32_process(count <= max_block) never writes past d_out
+        if ((size_t)count > c->d_in_cap || !c->d_in) {
             if (c->d_in) HIPCHK(hipFree(c->d_in));
             c->d_in = nullptr;
+            c->d_in_cap = 0;
             HIPCHK(hipMalloc(&c->d_in, (size_t)count * sizeof(float2)));
-            if (count > c->max_block) c->max_block = count;
+            c->d_in_cap = (size_t)count;
         }
         HIPCHK(hipMemcpyAsync(c->d_in, in, (size_t)count * sizeof(float2), hipMemcpyHostToDevice, st));
         src = c->d_in;

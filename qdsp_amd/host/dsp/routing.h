@@ -75,6 +75,7 @@ private:
         // every running VFO gets its channel's NCO phase and filter history back: it carries on without a glitch
         if (ctl && ctl->bank) {
             for (auto& m : members) {
+                std::lock_guard<std::mutex> lk(m->designMtx);       // (a VFO being destroyed clears `handle` under this mutex)
                 if (m->alive.load() && m->handle) { qdsp_hip_chan_cf32_move_channel_state(ctl->bank, m->index, m->handle, 1); }
             }
         }
@@ -127,7 +128,8 @@ private:
         }
         // a bank built mid-stream continues where the VFOs' own kernels stopped
         for (size_t i = 0; i < ms.size(); i++) {
-            if (ms[i]->handle) { qdsp_hip_chan_cf32_move_channel_state(h, (int)i, ms[i]->handle, 0); }
+            std::lock_guard<std::mutex> lk(ms[i]->designMtx);
+            if (ms[i]->alive.load() && ms[i]->handle) { qdsp_hip_chan_cf32_move_channel_state(h, (int)i, ms[i]->handle, 0); }
         }
         ctl = std::make_shared<detail::vfo_bank_ctl>();
         ctl->bank = h;
@@ -148,7 +150,13 @@ private:
     // as the reference does.  -1 in `stop`: a link is being stopped.
     bool runBank(int count, bool& stop) {
         stop = false;
-        if (bankOff) { return false; }
+        if (bankOff) {
+            // not sticky for good: a member that was mid-configure, or whose design only matched the others' a
+            // little later, gets another look every kBankRetryBlocks blocks
+            if (++bankOffBlocks < kBankRetryBlocks) { return false; }
+            bankOff = false;
+            bankOffBlocks = 0;
+        }
         if (ctl && ctl->broken.load()) {
             for (stream<T>* s : out) { if (!s->waitFlushed()) { stop = true; return false; } }
             dropBank();
@@ -166,7 +174,15 @@ private:
             // member i has finished the previous block -- flushed its token AFTER swapping its output -- so the write
             // buffer of its out stream is free
             if (!out[i]->waitFlushed()) { stop = true; return false; }
-            stream<complex_t>* o = members[i]->out;
+            stream<complex_t>* o = nullptr;
+            {
+                std::lock_guard<std::mutex> lk(members[i]->designMtx);
+                o = members[i]->alive.load() ? members[i]->out : nullptr;
+            }
+            if (!o) {               // destroyed between the `broken` test above and here: every link is idle up to i, none has a token yet
+                dropBank();
+                return false;
+            }
             const bool outDev = o->consumerTakesDevice && o->ensureDevice(dev);
             outs[i] = outDev ? static_cast<void*>(o->devWriteBuf) : static_cast<void*>(o->writeBuf);
             links[i] = outDev ? o->linkOut(true) : QDSP_HIP_LINK_HOST_DEFERRED;
@@ -187,7 +203,8 @@ private:
         blockNo++;
         for (stream<T>* s : out) {
             s->markWritten(QDSP_HIP_LINK_HOST);
-            if (!s->swap(count)) { stop = true; return true; }     // token block: the count, no samples
+            s->markToken();                                         // token block: the count, no samples
+            if (!s->swap(count)) { stop = true; return true; }
         }
         return true;
     }
@@ -240,7 +257,9 @@ private:
     std::vector<std::shared_ptr<detail::vfo_bank_member>> members;
     void* bankEvt[2] = {nullptr, nullptr};
     unsigned blockNo = 0;
-    bool bankOff = false;     // decided: these consumers cannot be banked
+    bool bankOff = false;     // decided for now: these consumers cannot be banked
+    unsigned bankOffBlocks = 0;
+    static constexpr unsigned kBankRetryBlocks = 64;
 };
 
 }  // namespace dsp

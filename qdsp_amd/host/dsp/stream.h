@@ -111,6 +111,8 @@ public:
         writePipelined = false;
         readDoneEvt = writeDoneEvt;
         writeDoneEvt = nullptr;
+        readIsToken = writeIsToken;
+        writeIsToken = false;
         pending = size;
         slotFree = false;
         hasData = true;
@@ -194,6 +196,12 @@ public:
     // Deferred completion of a host block: set by the producer, waited for inside read()
     void* writeDoneEvt = nullptr;
     void* readDoneEvt = nullptr;
+    // A block that carries a count and no samples (Splitter -> banked VFO, vfo_bank.h).  The mark travels WITH the block, like the
+    // link codes above: a consumer recognises a token whatever has happened to the bank between the producer's swap() and its
+    // own read() (the Splitter may have been re-plumbed or destroyed in between -- ADVICE round 2).
+    bool writeIsToken = false;
+    bool readIsToken = false;
+    void markToken() { writeIsToken = true; }
 
 private:
     // A GPU-backed neighbour answers within tens of microseconds, less than a futex sleep and wake-up costs:

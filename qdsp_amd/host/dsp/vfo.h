@@ -33,7 +33,14 @@ public:
     ~XlatingResampler() {
         const bool live = base::running;
         base::stop();
-        member->alive.store(false);
+        {
+            // under designMtx: the Splitter's dropBank / buildBank test `alive` and use `handle` / `out` under the same mutex, so they
+            // never hand a destroyed engine to qdsp_hip_chan_cf32_move_channel_state
+            std::lock_guard<std::mutex> lk(member->designMtx);
+            member->alive.store(false);
+            member->handle = nullptr;
+            member->out = nullptr;
+        }
         if (auto ctl = std::atomic_load(&member->ctl)) { ctl->broken.store(true); }
         if (live && _in) { _in->releaseConsumer(); }
         if (handle) { qdsp_hip_xlate_fir_decim_cf32_destroy(handle); }
@@ -94,10 +101,13 @@ public:
         const int count = _in->read();
         if (count < 0) { return -1; }
         if (!handle) { return -1; }
-        if (std::atomic_load(&member->ctl)) {
+        if (_in->readIsToken) {
             // banked (Splitter -> N x identical VFO): the block is a token, the Splitter's batched launch has already put
             // this channel's samples into out's write buffer.  Flush AFTER the swap: the Splitter takes the flush as
-            // "this member's write buffer is free again".
+            // "this member's write buffer is free again".  The test is the mark on the BLOCK, not the state of the bank: a
+            // Splitter that is re-plumbed (bindStream / unbindStream) or destroyed takes its bank down -- moving the channel
+            // state, already past this block, back into `handle` -- while this token may still be waiting in the link; running
+            // the core's own kernel on it would filter a never-written buffer and advance the NCO a second time.
             out.markWritten(member->outLink, member->evt);
             const bool ok = out.swap(member->outCount);
             _in->flush();

@@ -510,16 +510,32 @@ int main(int argc, char** argv) {
         const long K = atol(argv[9]);
         const float newOff = (float)atof(argv[10]);
         const bool reconf = argc >= 12 && std::string(argv[11]) == "reconf";
+        // "rebind": an extra leg (link + VFO + sink, created up front) is bound to the LIVE Splitter right before block K is fed
+        // and unbound again before block K + 3 -- without waiting for the graph to go idle, so tokens of the banked blocks
+        // K - 1 / K + 2 may still sit in the links when the bank is taken down (they must still be read as tokens)
+        const bool rebind = argc >= 12 && std::string(argv[11]) == "rebind";
         struct Gate {
             Feed<complex_t> feed;
             std::vector<Collect<complex_t>*>* cols = nullptr;
             std::vector<VFO*>* vfos = nullptr;
             long K = 0, fed = 0;
             float newOff = 0, bw2 = 0;
-            bool reconf = false;
+            bool reconf = false, rebind = false;
+            Splitter<complex_t>* split = nullptr;
+            stream<complex_t>* extra = nullptr;
+            stream<complex_t>* srcOut = nullptr;
             static int pull(complex_t* dst, void* ctx) {
                 Gate* g = static_cast<Gate*>(ctx);
-                if (g->fed == g->K) {
+                if (g->rebind) {
+                    if (g->fed == g->K || g->fed == g->K + 3) {
+                        // the Splitter has taken the previous block (it flushed its input: tokens are in the links, the worker is back
+                        // in read()) -- a stop in the middle of a block would drop that block, as in the reference -- but the VFOs
+                        // have not necessarily read their tokens yet: that is the window the re-plumbing must survive
+                        (void)g->srcOut->waitFlushed();
+                        if (g->fed == g->K) { g->split->bindStream(g->extra); }
+                        else { g->split->unbindStream(g->extra); }
+                    }
+                } else if (g->fed == g->K) {
                     // every block fed so far has come out of every sink: the graph is idle, the change lands exactly here
                     for (auto* c : *g->cols) {
                         while (c->blocks.load() < g->K) { std::this_thread::sleep_for(std::chrono::microseconds(200)); }
@@ -538,6 +554,7 @@ int main(int argc, char** argv) {
         gate.newOff = newOff;
         gate.bw2 = bw * 0.5f;
         gate.reconf = reconf;
+        gate.rebind = rebind;
         const long nblocks = (long)((gate.feed.data.size() + block - 1) / block);
         HandlerSource<complex_t> src(Gate::pull, &gate);
         Splitter<complex_t> split(&src.out);
@@ -545,23 +562,26 @@ int main(int argc, char** argv) {
         std::vector<VFO*> vfos;
         std::vector<Collect<complex_t>*> cols;
         std::vector<HandlerSink<complex_t>*> sinks;
-        for (int i = 0; i < n; i++) {
+        for (int i = 0; i < n + (rebind ? 1 : 0); i++) {
             links.push_back(new stream<complex_t>());
-            const float off = ((float)i - (float)(n - 1) / 2.0f) * inSR / (float)n;
+            const float off = i < n ? ((float)i - (float)(n - 1) / 2.0f) * inSR / (float)n : 0.125f * inSR;
             vfos.push_back(new VFO(links[i], off, inSR, outSR, bw));
-            split.bindStream(links[i]);
+            if (i < n) { split.bindStream(links[i]); }
             cols.push_back(new Collect<complex_t>());
             sinks.push_back(new HandlerSink<complex_t>(vfos[i]->out, Collect<complex_t>::push, cols[i]));
         }
         gate.cols = &cols;
         gate.vfos = &vfos;
+        gate.split = &split;
+        gate.extra = rebind ? links[n] : nullptr;
+        gate.srcOut = &src.out;
         for (auto* s : sinks) { s->start(); }
         for (auto* v : vfos) { v->start(); }
         split.start();
         src.start();
         const auto t0 = std::chrono::steady_clock::now();
-        for (int i = 0; i < n; i++) {
-            while (cols[i]->blocks.load() < nblocks) {
+        for (int i = 0; i < n + (rebind ? 1 : 0); i++) {
+            while (cols[i]->blocks.load() < (i < n ? nblocks : 3)) {
                 std::this_thread::sleep_for(std::chrono::milliseconds(1));
                 if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) { fprintf(stderr, "splitretune graph timed out\n"); return 3; }
             }
@@ -570,7 +590,7 @@ int main(int argc, char** argv) {
         split.stop();
         for (auto* v : vfos) { v->stop(); }
         for (auto* s : sinks) { s->stop(); }
-        for (int i = 0; i < n; i++) {
+        for (int i = 0; i < n + (rebind ? 1 : 0); i++) {
             std::ofstream o(std::string(out) + "." + std::to_string(i) + ".cf32", std::ios::binary);
             o.write(reinterpret_cast<const char*>(cols[i]->data.data()), (std::streamsize)(cols[i]->data.size() * sizeof(complex_t)));
         }

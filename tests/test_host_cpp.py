@@ -280,6 +280,28 @@ def test_graph_bank_retune_and_reconfigure(harness, data):
 
 
 @gpu
+def test_graph_bank_rebind_on_a_live_splitter(harness, data):
+    """bindStream / unbindStream on a Splitter whose outputs run as a bank (how VFOs are added to a running graph,
+    src/dsp/routing.h:27-45): the bank is taken down while token blocks of the last banked block may still be waiting in the
+    links.  A token carries its mark with it (stream<T>::readIsToken), so every VFO passes the bank's output on instead of
+    filtering a never-written buffer and advancing its NCO twice: the four original channels stay exact against the oracle
+    across both re-plumbings, the leg that was bound at block K produces blocks K .. K+2 of a VFO started there."""
+    d, x = data
+    b, n, K = 20_000, 4, 3
+    offs = [np.float32((np.float32(i) - np.float32(n - 1) / np.float32(2.0)) * np.float32(2.4e6) / np.float32(n)) for i in range(n)]
+    run([harness, "splitretune", str(d / "x.cf32"), str(d / "yrb"), str(b), str(n), "2400000", "240000", "200000", str(K), "0", "rebind"])
+    for i in range(n):
+        y = np.fromfile(str(d / "yrb") + f".{i}.cf32", dtype=np.complex64)
+        v = O.Vfo(float(offs[i]), 2.4e6, 240e3, 200e3, exact_nco=True, volk_gain=True)
+        want = np.concatenate([v.process(x[j:j + b]) for j in range(0, len(x), b)])
+        assert len(y) == len(want) and rel_rms(y, want) < 3e-6, i
+    y = np.fromfile(str(d / "yrb") + f".{n}.cf32", dtype=np.complex64)
+    v = O.Vfo(float(np.float32(0.125) * np.float32(2.4e6)), 2.4e6, 240e3, 200e3, exact_nco=True, volk_gain=True)
+    want = np.concatenate([v.process(x[j:j + b]) for j in range(K * b, (K + 3) * b, b)])
+    assert len(y) == len(want) and rel_rms(y, want) < 3e-6
+
+
+@gpu
 def test_graph_multiply_into_splitter_to_vfos(harness, data):
     """source -> Splitter -> Multiply(x, x) -> Splitter -> 8 x VFO -> sinks.  The second Splitter's input is a
     device-resident block from a producer that does not launch into the library's pipelined stream (the math block has
