@@ -396,12 +396,15 @@ __global__ __launch_bounds__(kFftNT, (DEC == 1 && !ROT && !REAL) ? 4 : 3) void f
                     v[k] = (k == 0) ? e : cmulc<true>(e, ta2[k]);
                 }
                 fft16<true>(v);
+                // (32-bit lane offsets from a wave-uniform base: sixteen 64-bit per-lane indices cost the ROT variants two spilled VGPRs)
                 const long long nb = ((long long)b * a.L - a.ov) / DEC;  // (b*L + i - ov)/DEC at i = 0
+                float2* __restrict__ seg_out = a.out + nb;
+                const long long left = a.nout - nb;
+                const int end_out = left < kFftN ? (int)left : kFftN;      // (i / DEC < 4096 / DEC)
 #pragma unroll
                 for (int n2 = 0; n2 < 16; n2++) {
                     const int i = n2 * 256 + e0;
-                    const long long n = nb + i / DEC;
-                    if (i >= a.ov && n < a.nout) a.out[n] = rot_out(n2, v[rev16(n2)]);
+                    if (i >= a.ov && i / DEC < end_out) seg_out[i / DEC] = rot_out(n2, v[rev16(n2)]);
                 }
             }
         }

@@ -259,14 +259,27 @@ __global__ __launch_bounds__(256, KJ * DEPTH <= 8 ? 4 : (KJ * DEPTH <= 12 ? 3 : 
     decim_mfma_body<KJ, true, DEPTH, 1>(a, c.rot_k);
 }
 
+// Two tiles in flight (DEPTH 2) is instantiated up to KJ = 12 only: at KJ = 16 the 2 x 16 prefetch registers push the kernel to
+// 256 VGPRs plus scratch (round 2: 28-32 bytes per lane).  AUTO asks for DEPTH 2 up to KJ = 8 (qdsp_hip.hip); QDSP_HIP_MF_DEPTH = 2 on
+// longer rows gets DEPTH 1 beyond 12.
+constexpr int kMfDepth2MaxKJ = 12;
+
+template <int K> static int launch_mf_batch_k(const MfBatchArgs& b, dim3 grid, int depth, hipStream_t stream) {
+    const dim3 block(256);
+    if constexpr (K <= kMfDepth2MaxKJ) {
+        if (depth == 2) { hipLaunchKernelGGL((decim_mfma_batch_kernel<K, 2>), grid, block, 0, stream, b); return 0; }
+    }
+    hipLaunchKernelGGL((decim_mfma_batch_kernel<K, 1>), grid, block, 0, stream, b);
+    return 0;
+}
+
 int launch_mf_dec_batch(const MfBatchArgs& b, int nchan, int KJ, int depth, hipStream_t stream) {
-    const dim3 grid((b.a.ntasks + 3) / 4 + 1, nchan), block(256);
-#define QK_MFB(k)                                                                                          \
-    if (KJ == k) {                                                                                         \
-        if (depth == 2) hipLaunchKernelGGL((decim_mfma_batch_kernel<k, 2>), grid, block, 0, stream, b);    \
-        else hipLaunchKernelGGL((decim_mfma_batch_kernel<k, 1>), grid, block, 0, stream, b);               \
-        const hipError_t e = hipGetLastError();                                                            \
-        return e == hipSuccess ? 0 : -(int)e;                                                              \
+    const dim3 grid((b.a.ntasks + 3) / 4 + 1, nchan);
+#define QK_MFB(k)                                           \
+    if (KJ == k) {                                          \
+        launch_mf_batch_k<k>(b, grid, depth, stream);       \
+        const hipError_t e = hipGetLastError();             \
+        return e == hipSuccess ? 0 : -(int)e;               \
     }
     QK_MFB(2) QK_MFB(3) QK_MFB(4) QK_MFB(5) QK_MFB(6) QK_MFB(7) QK_MFB(8)
     QK_MFB(9) QK_MFB(10) QK_MFB(11) QK_MFB(12) QK_MFB(13) QK_MFB(14) QK_MFB(15) QK_MFB(16)
@@ -274,18 +287,25 @@ int launch_mf_dec_batch(const MfBatchArgs& b, int nchan, int KJ, int depth, hipS
     return -1;
 }
 
+template <int K> static void launch_mf_k(const MfArgs& a, dim3 grid, bool rot, int depth, int qs, hipStream_t stream) {
+    const dim3 block(256);
+    if (qs == 2 && rot) { hipLaunchKernelGGL((decim_mfma_kernel<K, true, 1, 2>), grid, block, 0, stream, a); return; }
+    if (qs == 2) { hipLaunchKernelGGL((decim_mfma_kernel<K, false, 1, 2>), grid, block, 0, stream, a); return; }
+    if constexpr (K <= kMfDepth2MaxKJ) {
+        if (depth == 2 && rot) { hipLaunchKernelGGL((decim_mfma_kernel<K, true, 2, 1>), grid, block, 0, stream, a); return; }
+        if (depth == 2) { hipLaunchKernelGGL((decim_mfma_kernel<K, false, 2, 1>), grid, block, 0, stream, a); return; }
+    }
+    if (rot) hipLaunchKernelGGL((decim_mfma_kernel<K, true, 1, 1>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((decim_mfma_kernel<K, false, 1, 1>), grid, block, 0, stream, a);
+}
+
 int launch_mf_dec(const MfArgs& a, int KJ, bool rot, int depth, int qs, hipStream_t stream) {
-    const dim3 grid((a.ntasks + 3) / 4 + 1), block(256);
-#define QK_MF(k)                                                                                                    \
-    if (KJ == k) {                                                                                                  \
-        if (qs == 2 && rot) hipLaunchKernelGGL((decim_mfma_kernel<k, true, 1, 2>), grid, block, 0, stream, a);     \
-        else if (qs == 2) hipLaunchKernelGGL((decim_mfma_kernel<k, false, 1, 2>), grid, block, 0, stream, a);       \
-        else if (rot && depth == 2) hipLaunchKernelGGL((decim_mfma_kernel<k, true, 2, 1>), grid, block, 0, stream, a);   \
-        else if (rot) hipLaunchKernelGGL((decim_mfma_kernel<k, true, 1, 1>), grid, block, 0, stream, a);           \
-        else if (depth == 2) hipLaunchKernelGGL((decim_mfma_kernel<k, false, 2, 1>), grid, block, 0, stream, a);    \
-        else hipLaunchKernelGGL((decim_mfma_kernel<k, false, 1, 1>), grid, block, 0, stream, a);                   \
-        const hipError_t e = hipGetLastError();                                                                     \
-        return e == hipSuccess ? 0 : -(int)e;                                                                       \
+    const dim3 grid((a.ntasks + 3) / 4 + 1);
+#define QK_MF(k)                                            \
+    if (KJ == k) {                                          \
+        launch_mf_k<k>(a, grid, rot, depth, qs, stream);    \
+        const hipError_t e = hipGetLastError();             \
+        return e == hipSuccess ? 0 : -(int)e;               \
     }
     QK_MF(2) QK_MF(3) QK_MF(4) QK_MF(5) QK_MF(6) QK_MF(7) QK_MF(8)
     QK_MF(9) QK_MF(10) QK_MF(11) QK_MF(12) QK_MF(13) QK_MF(14) QK_MF(15) QK_MF(16)

@@ -9,7 +9,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 }
 
 template <bool ROT> __global__ __launch_bounds__(256, 3) void resamp_mfma_kernel(const RmArgs a) {
-    constexpr int NE = kRmNE, GM = kRmMaxGrp, KM = kRmMaxKB;
+    constexpr int NE = kRmNE, GM = kRmMaxGrp;
     const int t = threadIdx.x, l = t & 63;
     const int P = a.P, M = a.M, L = a.L;
     if ((int)blockIdx.x == (a.nwaves + 3) / 4) {
@@ -126,14 +126,25 @@ template <bool ROT> __global__ __launch_bounds__(256, 3) void resamp_mfma_kernel
                     const float2* bp = tile + 4 * lq * a.pitch + brow + cb[g];
                     const float* ap = atab + g * a.KB * 64 + l;
                     f32x4 zr = {0.0f, 0.0f, 0.0f, 0.0f}, zi = {0.0f, 0.0f, 0.0f, 0.0f};
+                    // Band columns in chunks of eight: a run-time loop over the chunks, the steps of a full chunk unrolled without a test
+                    // (round 3: the fully unrolled form tested `k < KB` at each of its KM steps and kept the KM wave-uniform results
+                    // alive -- 109 / 166 SGPRs spilled to VGPR lanes, 211 v_readlane in the loop), the last partial chunk rolled.
+                    int k0 = 0;
+#pragma unroll 1
+                    for (; k0 + 8 <= a.KB; k0 += 8) {
 #pragma unroll
-                    for (int k = 0; k < KM; k++) {
-                        if (k < a.KB) {
-                            const float2 bv = bp[k];
-                            zr = __builtin_amdgcn_mfma_f32_4x4x1f32(ap[k * 64], bv.x, zr, 0, 0, 0);
-                            zi = __builtin_amdgcn_mfma_f32_4x4x1f32(ap[k * 64], bv.y, zi, 0, 0, 0);
+                        for (int k = 0; k < 8; k++) {
+                            const float2 bv = bp[k0 + k];
+                            zr = __builtin_amdgcn_mfma_f32_4x4x1f32(ap[(k0 + k) * 64], bv.x, zr, 0, 0, 0);
+                            zi = __builtin_amdgcn_mfma_f32_4x4x1f32(ap[(k0 + k) * 64], bv.y, zi, 0, 0, 0);
                         }
-                        if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);      // reads run at most 8 steps ahead (16 VGPRs)
+                        __builtin_amdgcn_sched_barrier(0);      // reads run at most 8 steps ahead (16 VGPRs)
+                    }
+#pragma unroll 1
+                    for (; k0 < a.KB; k0++) {
+                        const float2 bv = bp[k0];
+                        zr = __builtin_amdgcn_mfma_f32_4x4x1f32(ap[k0 * 64], bv.x, zr, 0, 0, 0);
+                        zi = __builtin_amdgcn_mfma_f32_4x4x1f32(ap[k0 * 64], bv.y, zi, 0, 0, 0);
                     }
                     // lane = (block l / 4, period l % 4 of the quad): outputs o .. o + 3 of that period, 32 bytes
                     const int o = 4 * (meta[g] & 0xffff);

@@ -40,11 +40,13 @@ def main():
     names = sorted({kv.split("=")[0] for s in a.settings for kv in filter(None, s.split(","))})
     n = 1 << a.log2n
     w = bench.WORKLOADS[a.workload]
+    if w.get("interp", 1) > 1:
+        n -= n % w["decim"]
     x = ops.synth_iq(n, seed=1234)
     if a.zeros:
         x.zero_()
     nout = n // w["decim"] * w.get("interp", 1)
-    out = torch.empty((w["nchan"], nout + bench.CHAN_ROW_PAD) if "nchan" in w else nout, dtype=torch.complex64, device="cuda")
+    out = torch.empty((w["nchan"], nout + bench.CHAN_ROW_PAD) if "nchan" in w else nout + 8, dtype=torch.complex64, device="cuda")
     op = bench.make_op(ops, a.workload, 0)
     apply(a.settings[0], names)
     for _ in range(5):   # settle the clocks

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Register / scratch usage of every gfx950 kernel the library ships, from hipcc's own remarks.
+
+    python scripts/resource_usage.py            # writes profiles/r03_resource_usage.txt
+
+Each translation unit of qdsp_amd/csrc is compiled (device side only, no GPU needed) with
+-Rpass-analysis=kernel-resource-usage and the flags the Makefile builds it with; the table lists, per kernel instantiation:
+VGPRs, SGPRs, SGPRs spilled (to VGPR lanes), VGPRs spilled, scratch bytes per lane, waves per SIMD.  The header records a hash
+of the sources the table was made from: tests/test_capi_cpu.py::test_no_kernel_uses_scratch fails when the table is stale or any
+kernel has scratch > 0."""
+import hashlib
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "qdsp_amd", "csrc")
+OUT = os.path.join(ROOT, "profiles", "r03_resource_usage.txt")
+UNITS = {"qdsp_hip": "", "fft_fir": "-fno-slp-vectorize", "fft1k_fir": "-fno-slp-vectorize", "chan": "-fno-slp-vectorize",
+         "pfb_dec": "-fno-slp-vectorize", "mf_dec": "", "rm_resamp": "", "fir_lat": ""}
+
+
+def source_hash() -> str:
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".h")) or f == "Makefile":
+            h.update(f.encode())
+            h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def demangle(names):
+    try:
+        out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True, check=True).stdout
+        return [re.sub(r"^void ", "", n).split("(")[0] for n in out.strip().split("\n")]
+    except Exception:  # noqa: BLE001
+        return names
+
+
+def main():
+    rows = []
+    for unit, extra in UNITS.items():
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", *extra.split(), "-S", "--cuda-device-only",
+               "-Rpass-analysis=kernel-resource-usage", "-o", "/dev/null", f"{unit}.hip"]
+        err = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True).stderr
+        cur = None
+        for line in err.splitlines():
+            m = re.search(r"remark: (?:Function Name: (\S+)|\s+(\S[^:]*): (\d+))", line)
+            if not m:
+                continue
+            if m.group(1):
+                cur = {"unit": unit, "name": m.group(1)}
+                rows.append(cur)
+            elif cur is not None:
+                cur[m.group(2).strip()] = int(m.group(3))
+    names = demangle([r["name"] for r in rows])
+    with open(OUT, "w") as f:
+        f.write(f"# sources {source_hash()}  (qdsp_amd/csrc: *.hip, *.h, Makefile)  -- scripts/resource_usage.py, hipcc -Rpass-analysis=kernel-resource-usage, gfx950\n")
+        f.write(f"# {len(rows)} kernel instantiations; columns: unit, VGPRs, SGPRs, SGPRs spilled (to VGPR lanes), VGPRs spilled, scratch bytes/lane, waves/SIMD, LDS bytes (static), kernel\n")
+        for r, n in zip(rows, names):
+            f.write(f"{r['unit']:10s} {r.get('VGPRs', -1):4d} {r.get('TotalSGPRs', -1):4d} {r.get('SGPRs Spill', -1):4d} {r.get('VGPRs Spill', -1):4d} "
+                    f"{r.get('ScratchSize [bytes/lane]', -1):5d} {r.get('Occupancy [waves/SIMD]', -1):2d} {r.get('LDS Size [bytes/block]', -1):6d}  {n}\n")
+    bad = [n for r, n in zip(rows, names) if r.get("ScratchSize [bytes/lane]", 1) != 0 or r.get("VGPRs Spill", 1) != 0]
+    print(f"{len(rows)} kernels -> {OUT}; with scratch or spilled VGPRs: {len(bad)}")
+    for n in bad:
+        print("  ", n)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -101,3 +101,24 @@ def test_bench_starts_its_own_ranks_before_touching_the_gpu(monkeypatch):
     src = open(os.path.join(ROOT, "bench.py")).read()
     body = src[src.index("def main():"):]
     assert body.index("launch_ranks(args)") < body.index("import torch")     # nothing GPU-related runs first
+
+
+def test_no_kernel_uses_scratch():
+    """profiles/r03_resource_usage.txt (scripts/resource_usage.py: hipcc's kernel-resource-usage remarks for every kernel instantiation
+    of the shipped library) was made from the sources as they are now, and no kernel has scratch memory or spilled VGPRs
+    (ten instantiations spilled)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("resource_usage", os.path.join(ROOT, "scripts", "resource_usage.py"))
+    ru = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ru)
+    lines = open(ru.OUT).read().splitlines()
+    assert lines[0].split()[2] == ru.source_hash(), "qdsp_amd/csrc changed: run `python scripts/resource_usage.py` and commit the table"
+    rows = [ln.split(None, 8) for ln in lines if ln and not ln.startswith("#")]
+    assert len(rows) > 300
+    bad = [r[8] for r in rows if int(r[4]) != 0 or int(r[5]) != 0]
+    assert not bad, f"kernels with spilled VGPRs / scratch: {bad}"
+    # the kernels of the bench legs keep the occupancy DESIGN.md quotes
+    occ = {r[8]: int(r[6]) for r in rows}
+    assert occ["qk::fir_fft_dma_kernel"] == 4 and occ["qk::pfb_dec8_kernel<true>"] == 2
+    assert all(v == 3 for k, v in occ.items() if k.startswith("qk::chan_uniform_kernel<") and ", 0>" in k and "64" not in k)
