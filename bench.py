@@ -521,6 +521,11 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args))
 
+    # RCCL between processes needs dmabuf IPC on this platform (the host driver supports nothing else): without this setting the
+    # first send / recv between two ranks fails with `hipIpcGetMemHandle: invalid argument`.  It is exported by the image already;
+    # set here as well -- before anything initialises HIP -- so that a launcher with a scrubbed environment still works.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
     import torch
     import torch.distributed as dist
 

@@ -49,6 +49,7 @@ extern "C" {
 #define QDSP_HIP_ENOMEM (-10002)  /* host allocation failed                          */
 #define QDSP_HIP_ESIZE (-10003)   /* count exceeds the handle's max_block            */
 #define QDSP_HIP_ENODEV (-10004)  /* no usable gfx950 device / device index invalid  */
+#define QDSP_HIP_ERCCL (-10005)   /* RCCL not loadable, or an RCCL call failed (ring)  */
 
 /* ---- library ------------------------------------------------------------------------- */
 int qdsp_hip_abi_version(void);
@@ -361,6 +362,30 @@ int qdsp_hip_last_kernel(void* h, char* name, int name_len, int* grid, int* bloc
  * State advances as for `iters` ordinary calls. */
 int qdsp_hip_time_process_dev(void* h, const void* d_in, int64_t count, void* d_out,
                               void* hip_stream, int iters, float* ms);
+
+/* ---- ring: the halo exchange of the time-sharded path over RCCL / xGMI ----------------------------------
+ * The reference has no multi-device path (one thread per block: src/dsp/block.h:83-85).  A long stream is cut into time chunks over
+ * the GPUs of a node, one process per GPU; a chunk's filter needs the last H INPUT samples of the chunk before it in the stream --
+ * the samples src/dsp/filter.h:71 / src/dsp/resampling.h:129 carry from one run() to the next.  Every step each rank posts
+ *     ncclGroupStart(); ncclSend(my tail -> rank + 1); ncclRecv(rank - 1's tail); ncclGroupEnd();
+ * on the ring's own HIP stream and installs what arrives with <op>_set_history_dev.  A C++ graph (qdsp_amd/host/examples/
+ * graph_check.cpp `shard`) and qdsp_amd/sharding.py RingStream call the same five entry points.
+ *   unique_id  one rank (rank 0) obtains the 128-byte id; the caller carries it to every rank (file, socket, MPI, a torch store)
+ *   create     collective: every rank of the ring calls it with the same id; world 1 = the rank is its own neighbour
+ *   post       my tail (halo_bytes at d_tail, as of what `producer_stream` has queued so far) -> rank + 1, and rank - 1's tail ->
+ *              the next of three receive buffers; returns at once.  At most two posts may be outstanding.
+ *   complete   `consumer_stream` waits for the oldest outstanding post; *d_halo = what arrived with it, *d_prev_halo = what
+ *              arrived with the post before it (zeros before the first): in a block-cyclic cut rank 0's predecessor is the LAST
+ *              rank of the step before.  Either pointer may be NULL.
+ *   drain      host-side wait for everything posted (end of stream: every rank has one exchange in flight that no step reads)
+ * Errors: QDSP_HIP_ERCCL when librccl.so.1 cannot be loaded or an RCCL call fails (its message goes to stderr). */
+#define QDSP_HIP_RING_ID_BYTES 128
+int qdsp_hip_ring_unique_id(void* id);
+int qdsp_hip_ring_create(void** ring, int device, int rank, int world, const void* id, int halo_bytes);
+int qdsp_hip_ring_post(void* ring, const void* d_tail, void* producer_stream);
+int qdsp_hip_ring_complete(void* ring, void* consumer_stream, const void** d_halo, const void** d_prev_halo);
+int qdsp_hip_ring_drain(void* ring);
+void qdsp_hip_ring_destroy(void* ring);
 
 #ifdef __cplusplus
 }

@@ -2443,6 +2443,7 @@ const char* qdsp_hip_error_string(int code) {
         case QDSP_HIP_ENOMEM: return "qdsp_hip: out of host memory";
         case QDSP_HIP_ESIZE: return "qdsp_hip: block larger than max_block";
         case QDSP_HIP_ENODEV: return "qdsp_hip: no usable HIP device";
+        case QDSP_HIP_ERCCL: return "qdsp_hip: RCCL unavailable or an RCCL call failed (ring)";
         default: return hipGetErrorString((hipError_t)(-code));
     }
 }

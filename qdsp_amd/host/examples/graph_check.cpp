@@ -32,6 +32,11 @@
 //                      source -> Splitter (host-fed) -> Multiply(x, x) -> Splitter -> n x VFO -> sinks: the second
 //                      Splitter's input comes from a producer OUTSIDE the library's pipelined stream, so its
 //                      device-to-device copies must have read the block before it is flushed
+//   graph_check shard  <in.cf32> <out.cf32> <chunk> <taps.f32> [<rank> <world> <idfile>]
+//                      the time-sharded path from C++ (include/qdsp_hip.h "ring"): this rank filters chunks rank, rank + world,
+//                      ... of the stream with FIR<complex_t>'s engine, every chunk's history = the tail of the chunk before it,
+//                      delivered by qdsp_hip_ring_post / _complete (RCCL send / recv, posted one step ahead); rank 0 writes the
+//                      RCCL id to <idfile>, the others wait for it.  Default: one rank, its own ring neighbour.
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -670,6 +675,60 @@ int main(int argc, char** argv) {
         { std::ofstream o(tmp, std::ios::binary); o.write(reinterpret_cast<const char*>(iq.data()), (std::streamsize)(iq.size() * 8)); }
         filter_window::BlackmanWindow win(0.1f * rd.getSampleRate(), 4.0f * rd.getSampleRate() / 63.0f, (float)rd.getSampleRate());
         return runGraph<complex_t>(tmp.c_str(), out, block, [&](stream<complex_t>* s) { return new FIR<complex_t>(s, &win); });
+    }
+    if (mode == "shard" && argc >= 6) {
+        const std::vector<complex_t> x = readAll<complex_t>(in);
+        const std::vector<float> taps = readAll<float>(argv[5]);
+        const int rank = argc >= 9 ? atoi(argv[6]) : 0, world = argc >= 9 ? atoi(argv[7]) : 1;
+        const int n = block, H = (int)taps.size() - 1;
+        const long steps = (long)(x.size() / ((size_t)n * world));
+        if (steps < 1 || H < 1 || n < H) { fprintf(stderr, "shard: need at least one chunk of >= ntaps - 1 samples per rank\n"); return 2; }
+        unsigned char id[QDSP_HIP_RING_ID_BYTES];
+        if (rank == 0) {
+            if (qdsp_hip_ring_unique_id(id) != 0) { fprintf(stderr, "shard: no RCCL\n"); return 3; }
+            if (argc >= 9) { std::ofstream o(std::string(argv[8]) + ".tmp", std::ios::binary); o.write((const char*)id, sizeof(id)); o.close(); rename((std::string(argv[8]) + ".tmp").c_str(), argv[8]); }
+        } else {
+            for (int tries = 0;; tries++) {
+                std::ifstream f(argv[8], std::ios::binary);
+                if (f && f.read((char*)id, sizeof(id))) { break; }
+                if (tries > 3000) { fprintf(stderr, "shard: no id file\n"); return 3; }
+                std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            }
+        }
+        const int dev = detail::hipDeviceForBlocks();
+        void *ring = nullptr, *fir = nullptr, *d_in[2] = {nullptr, nullptr}, *d_out = nullptr;
+        int rc = qdsp_hip_ring_create(&ring, dev, rank, world, id, H * (int)sizeof(complex_t));
+        if (rc == 0) { rc = qdsp_hip_fir_cf32_create(&fir, dev, taps.data(), (int)taps.size(), 0); }
+        for (int i = 0; i < 2 && rc == 0; i++) { rc = qdsp_hip_dev_alloc(dev, &d_in[i], (size_t)n * sizeof(complex_t)); }
+        if (rc == 0) { rc = qdsp_hip_dev_alloc(dev, &d_out, (size_t)n * sizeof(complex_t)); }
+        if (rc != 0) { fprintf(stderr, "shard: setup failed: %s\n", qdsp_hip_error_string(rc)); return 3; }
+        auto chunk = [&](long s) { return x.data() + ((size_t)s * world + rank) * n; };
+        std::vector<complex_t> y((size_t)steps * n);
+        // step s: [upload s + 1] -> complete(s) -> history -> post(s + 1) -> kernel(s): the exchange of the next step runs under this kernel
+        rc = qdsp_hip_memcpy_h2d(dev, d_in[0], chunk(0), (size_t)n * sizeof(complex_t));
+        if (rc == 0) { rc = qdsp_hip_ring_post(ring, static_cast<complex_t*>(d_in[0]) + (n - H), nullptr); }
+        for (long s = 0; s < steps && rc == 0; s++) {
+            void* cur = d_in[s & 1];
+            void* nxt = d_in[(s + 1) & 1];
+            if (s + 1 < steps) { rc = qdsp_hip_memcpy_h2d(dev, nxt, chunk(s + 1), (size_t)n * sizeof(complex_t)); }
+            const void *halo = nullptr, *prev = nullptr;
+            if (rc == 0) { rc = qdsp_hip_ring_complete(ring, nullptr, &halo, &prev); }
+            // ranks > 0: the predecessor's tail of THIS step; rank 0: the last rank's tail of the step before (zeros at the start)
+            if (rc == 0) { rc = qdsp_hip_fir_cf32_set_history_dev(fir, rank == 0 ? prev : halo, nullptr); }
+            if (rc == 0 && s + 1 < steps) { rc = qdsp_hip_ring_post(ring, static_cast<complex_t*>(nxt) + (n - H), nullptr); }
+            if (rc == 0) { const long long r2 = qdsp_hip_fir_cf32_process_dev(fir, cur, n, d_out, nullptr); rc = r2 < 0 ? (int)r2 : 0; }
+            if (rc == 0) { rc = qdsp_hip_memcpy_d2h(dev, y.data() + (size_t)s * n, d_out, (size_t)n * sizeof(complex_t)); }
+        }
+        if (rc != 0) { fprintf(stderr, "shard: %s\n", qdsp_hip_error_string(rc)); return 3; }
+        (void)qdsp_hip_ring_drain(ring);
+        std::ofstream o(world > 1 ? std::string(out) + "." + std::to_string(rank) : std::string(out), std::ios::binary);
+        o.write(reinterpret_cast<const char*>(y.data()), (std::streamsize)(y.size() * sizeof(complex_t)));
+        printf("shard ok: rank %d of %d, %ld chunks of %d samples, halo %d samples over the ring\n", rank, world, steps, n, H);
+        qdsp_hip_fir_cf32_destroy(fir);
+        qdsp_hip_ring_destroy(ring);
+        for (void* p : d_in) { qdsp_hip_dev_free(dev, p); }
+        qdsp_hip_dev_free(dev, d_out);
+        return 0;
     }
     fprintf(stderr, "unknown mode %s\n", mode.c_str());
     return 2;

@@ -170,6 +170,10 @@ class _HistMixin:
         stream = torch.cuda.current_stream(t.device).cuda_stream
         capi.check(self._fn("set_history_dev")(self._h, t.data_ptr(), stream))
 
+    def set_history_ptr(self, ptr: int, stream: int):
+        """The same from a raw device pointer (the receive buffer of the C ring, qdsp_hip_ring_complete) on HIP stream `stream`."""
+        capi.check(self._fn("set_history_dev")(self._h, int(ptr), int(stream)))
+
     def history_dev_tensor(self):
         """The device history buffer the NEXT process call reads, as a torch view (no copy):
         an RCCL recv of the neighbour's tail can land here directly (multi-GPU halo)."""
@@ -331,6 +335,10 @@ class Channelizer:
         assert hist.is_cuda and hist.is_contiguous() and hist.dtype == torch.complex64 and hist.numel() == self.history_len
         stream = torch.cuda.current_stream(hist.device).cuda_stream
         capi.check(self._L.qdsp_hip_chan_cf32_set_history_dev(self._h, hist.data_ptr(), stream))
+
+    def set_history_ptr(self, ptr: int, stream: int):
+        """The same from a raw device pointer (the receive buffer of the C ring, qdsp_hip_ring_complete) on HIP stream `stream`."""
+        capi.check(self._L.qdsp_hip_chan_cf32_set_history_dev(self._h, int(ptr), int(stream)))
 
     def advance(self, n: int):
         capi.check(self._L.qdsp_hip_chan_cf32_advance(self._h, int(n)))

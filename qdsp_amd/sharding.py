@@ -90,6 +90,59 @@ def exchange_halo(tail, hist_out, rank: int, world: int, group=None):
             req.wait()
 
 
+class _CRing:
+    """qdsp_hip_ring_* (include/qdsp_hip.h, qdsp_amd/csrc/ring.cpp): the RCCL send/recv pair of one step, posted on the ring's own HIP
+    stream.  The 128-byte RCCL id comes from rank 0 and travels through the torch process group (a device broadcast); a
+    one-rank ring (the rank is its own neighbour) needs no process group at all."""
+
+    def __init__(self, device: int, rank: int, world: int, halo_bytes: int, group=None):
+        import ctypes as C
+
+        from . import capi
+
+        self._L = capi.load()
+        self._check = capi.check
+        idbuf = (C.c_char * 128)()
+        if world == 1:
+            capi.check(self._L.qdsp_hip_ring_unique_id(idbuf), "qdsp_hip_ring_unique_id")
+        else:
+            import numpy as np
+            import torch
+            import torch.distributed as dist
+
+            t = torch.zeros(128, dtype=torch.uint8, device=f"cuda:{device}")
+            if rank == 0:
+                capi.check(self._L.qdsp_hip_ring_unique_id(idbuf), "qdsp_hip_ring_unique_id")
+                t.copy_(torch.from_numpy(np.frombuffer(idbuf.raw, dtype=np.uint8).copy()))
+            dist.broadcast(t, 0, group=group)
+            idbuf.raw = t.cpu().numpy().tobytes()
+        self._h = C.c_void_p()
+        capi.check(self._L.qdsp_hip_ring_create(C.byref(self._h), device, rank, world, idbuf, halo_bytes), "qdsp_hip_ring_create")
+        self._C = C
+
+    def post(self, tail_ptr: int, stream: int):
+        self._check(self._L.qdsp_hip_ring_post(self._h, tail_ptr, stream), "qdsp_hip_ring_post")
+
+    def complete(self, stream: int):
+        halo, prev = self._C.c_void_p(), self._C.c_void_p()
+        self._check(self._L.qdsp_hip_ring_complete(self._h, stream, self._C.byref(halo), self._C.byref(prev)), "qdsp_hip_ring_complete")
+        return halo.value, prev.value
+
+    def drain(self):
+        self._check(self._L.qdsp_hip_ring_drain(self._h), "qdsp_hip_ring_drain")
+
+    def close(self):
+        if self._h:
+            self._L.qdsp_hip_ring_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
 class RingStream:
     """One rank's end of a continuous stream processed block-cyclically on `world` ranks.
 
@@ -105,9 +158,10 @@ class RingStream:
 
     op         a qdsp_amd.ops operator with history (`Fir`, `Resampler`, `Vfo`, `Channelizer`), or an
                `Xlator` (no halo; only the NCO bookkeeping applies)
-    transport  "device": halos travel as device tensors through the process group (nccl == RCCL;
-               world 1 with an initialised group = the rank is its own ring neighbour, which
-               exercises the real send/recv on a one-GPU box);
+    transport  "device": halos travel by RCCL send / recv through the library's C ring (qdsp_hip_ring_*, qdsp_amd/csrc/
+               ring.cpp -- the entry points a C++ graph uses as well); the process group only carries the 128-byte RCCL id
+               once (world 1 = the rank is its own ring neighbour: exercises the real send/recv on a one-GPU box, no
+               process group needed);
                "host": halos are staged through CPU tensors (gloo) -- several ranks sharing one
                GPU, where RCCL refuses to run; used by the one-GPU rehearsal tests.
     The NCO (if the operator has one) is put at this rank's first sample on construction and
@@ -140,7 +194,10 @@ class RingStream:
         self.step_index = 0
         self._pending = None          # (reqs, buffer index) of the exchange in flight
         self._posted = 0              # exchanges posted so far
-        if self.exchange:
+        self._ring = None
+        if self.exchange and transport == "device" and self.device.type == "cuda":
+            self._ring = _CRing(self.device.index or 0, self.rank, self.world, self.H * 8, group)
+        if self.exchange and self._ring is None:      # (host transport, or device tensors of a CPU stand-in operator over gloo: the CPU tests)
             z = lambda: torch.zeros(max(self.H, 1), dtype=torch.complex64, device=self.device)  # noqa: E731
             self._recv = [z() for _ in range(self.NBUF)]
             self._zeros = z()
@@ -164,8 +221,11 @@ class RingStream:
                 dist.P2POp(dist.irecv, torch.view_as_real(halo_h), prv, self.group),
             ])
             return (reqs, k, halo_h, tail_h)
-        # sent straight from the chunk (a contiguous view): `x` is the input of the step this exchange belongs to,
-        # so it stays untouched until that step has waited for the exchange
+        # sent straight from the chunk: `x` is the input of the step this exchange belongs to, so it stays untouched until that
+        # step has waited for the exchange
+        if self._ring is not None:
+            self._ring.post(x.data_ptr() + (x.numel() - self.H) * 8, torch.cuda.current_stream(x.device).cuda_stream)
+            return ("ring", k, None, None)
         reqs = dist.batch_isend_irecv([
             dist.P2POp(dist.isend, torch.view_as_real(x[x.numel() - self.H:]), nxt, self.group),
             dist.P2POp(dist.irecv, torch.view_as_real(self._recv[k]), prv, self.group),
@@ -186,7 +246,20 @@ class RingStream:
         step's kernel).  Returns the operator's output."""
         if x.numel() != self.n:
             raise ValueError(f"chunk of {x.numel()} samples, expected {self.n}")
-        if self.exchange:
+        if self.exchange and self._ring is not None:
+            import torch
+
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            if self._pending is None:
+                self._pending = self._post(x)
+            halo, prev = self._ring.complete(stream)
+            self._pending = None
+            # rank 0: what just arrived is the last rank's tail of THIS step = my halo of the NEXT step; this step reads what
+            # arrived one step earlier (qdsp_hip_ring_complete's d_prev_halo: zeros before the first exchange)
+            self.op.set_history_ptr(prev if self.rank == 0 else halo, stream)
+            if self.prefetch and next_x is not None:
+                self._pending = self._post(next_x)
+        elif self.exchange:
             if self._pending is None:
                 self._pending = self._post(x)
             k = self._complete(self._pending)
@@ -209,8 +282,11 @@ class RingStream:
     def drain(self):
         """Complete an exchange posted for a step that will not run (every rank has one in flight)."""
         if self._pending is not None:
-            for r in self._pending[0]:
-                r.wait()
+            if self._ring is not None:
+                self._ring.drain()
+            else:
+                for r in self._pending[0]:
+                    r.wait()
             self._pending = None
 
     def stream_position(self) -> int:

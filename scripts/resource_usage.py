@@ -24,7 +24,7 @@ UNITS = {"qdsp_hip": "", "fft_fir": "-fno-slp-vectorize", "fft1k_fir": "-fno-slp
 def source_hash() -> str:
     h = hashlib.sha256()
     for f in sorted(os.listdir(CSRC)):
-        if f.endswith((".hip", ".h")) or f == "Makefile":
+        if f.endswith((".hip", ".hip.h")):
             h.update(f.encode())
             h.update(open(os.path.join(CSRC, f), "rb").read())
     return h.hexdigest()[:16]
@@ -56,7 +56,7 @@ def main():
                 cur[m.group(2).strip()] = int(m.group(3))
     names = demangle([r["name"] for r in rows])
     with open(OUT, "w") as f:
-        f.write(f"# sources {source_hash()}  (qdsp_amd/csrc: *.hip, *.h, Makefile)  -- scripts/resource_usage.py, hipcc -Rpass-analysis=kernel-resource-usage, gfx950\n")
+        f.write(f"# sources {source_hash()}  (qdsp_amd/csrc: *.hip, *.hip.h)  -- scripts/resource_usage.py, hipcc -Rpass-analysis=kernel-resource-usage, gfx950\n")
         f.write(f"# {len(rows)} kernel instantiations; columns: unit, VGPRs, SGPRs, SGPRs spilled (to VGPR lanes), VGPRs spilled, scratch bytes/lane, waves/SIMD, LDS bytes (static), kernel\n")
         for r, n in zip(rows, names):
             f.write(f"{r['unit']:10s} {r.get('VGPRs', -1):4d} {r.get('TotalSGPRs', -1):4d} {r.get('SGPRs Spill', -1):4d} {r.get('VGPRs Spill', -1):4d} "

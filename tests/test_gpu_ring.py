@@ -131,9 +131,9 @@ def test_channelizer_64_on_two_ranks(tmp_path):
 
 @pytest.mark.parametrize("case", ["fir256", "xlate_fir_decim8"])
 def test_rccl_self_ring_matches_unsharded_oracle(tmp_path, case):
-    """One rank as its own ring neighbour over real RCCL (nccl backend): the halo of step s+1 is this rank's own
-    tail of step s, sent and received through batch_isend_irecv on device tensors and prefetched under the kernel --
-    the transport the 8-GPU run uses, with world = 1 so the result is the plain unsharded stream."""
+    """One rank as its own ring neighbour over real RCCL: the halo of step s+1 is this rank's own tail of step s, sent and
+    received by the library's C ring (qdsp_hip_ring_post / _complete: ncclSend + ncclRecv on the ring's own stream) and
+    prefetched under the kernel -- the transport the 8-GPU run uses, with world = 1 so the result is the plain unsharded stream."""
     steps, n = 4, 1 << 17
     _run_ranks(case, "nccl", 1, tmp_path, steps, n)
     y = np.concatenate(_collect(case, tmp_path, 1, steps))
@@ -143,3 +143,69 @@ def test_rccl_self_ring_matches_unsharded_oracle(tmp_path, case):
     per = len(want) // steps
     for c in range(1, steps):
         assert rel_rms(y[c * per:c * per + 64], want[c * per:c * per + 64]) < 1e-5, (case, c)
+
+
+def test_c_ring_entry_points_self_ring():
+    """qdsp_hip_ring_* straight through ctypes, one rank as its own neighbour (include/qdsp_hip.h "ring"; what a C++ graph calls):
+    what a post sends is what its complete delivers, `d_prev_halo` is the delivery of the post before (zeros before the
+    first), a post reads the tail as of what the producer stream had queued, three posts outstanding are refused, and a
+    256-tap FIR fed chunk by chunk with the halos from the ring equals the unsharded oracle (src/dsp/filter.h:51-74)."""
+    import ctypes as C
+
+    import torch
+
+    from qdsp_amd import capi, ops
+
+    L = capi.load()
+    H = 255
+    idbuf = (C.c_char * 128)()
+    capi.check(L.qdsp_hip_ring_unique_id(idbuf))
+    ring = C.c_void_p()
+    capi.check(L.qdsp_hip_ring_create(C.byref(ring), 0, 0, 1, idbuf, H * 8))
+    try:
+        st = torch.cuda.current_stream().cuda_stream
+        halo, prev = C.c_void_p(), C.c_void_p()
+
+        def view(p):
+            buf = torch.empty(H, dtype=torch.complex64, device="cuda")
+            capi.check(L.qdsp_hip_memcpy_d2d(0, buf.data_ptr(), p, H * 8))
+            return buf.cpu().numpy()
+
+        tails = [torch.from_numpy(O.synth_iq(1000 * k, H, seed=7)).cuda() for k in range(4)]
+        for k, tl in enumerate(tails):
+            scratch = torch.zeros_like(tl)
+            scratch.copy_(tl, non_blocking=True)          # queued on the producer stream just before the post: the post must see it
+            capi.check(L.qdsp_hip_ring_post(ring, scratch.data_ptr(), st))
+            capi.check(L.qdsp_hip_ring_complete(ring, st, C.byref(halo), C.byref(prev)))
+            torch.cuda.synchronize()
+            assert np.array_equal(view(halo.value), tl.cpu().numpy())
+            want_prev = tails[k - 1].cpu().numpy() if k else np.zeros(H, np.complex64)
+            assert np.array_equal(view(prev.value), want_prev)
+        capi.check(L.qdsp_hip_ring_post(ring, tails[0].data_ptr(), st))
+        capi.check(L.qdsp_hip_ring_post(ring, tails[1].data_ptr(), st))
+        assert L.qdsp_hip_ring_post(ring, tails[2].data_ptr(), st) == -10001        # QDSP_HIP_EINVAL: two outstanding
+        capi.check(L.qdsp_hip_ring_drain(ring))
+        assert L.qdsp_hip_ring_complete(ring, st, None, None) == -10001             # nothing outstanding after the drain
+        # a FIR over four chunks, every chunk a fresh handle whose history is what a NEW ring delivered (d_prev_halo of its first
+        # complete is the stream's zero state)
+        L.qdsp_hip_ring_destroy(ring)
+        ring = C.c_void_p()
+        capi.check(L.qdsp_hip_ring_unique_id(idbuf))
+        capi.check(L.qdsp_hip_ring_create(C.byref(ring), 0, 0, 1, idbuf, H * 8))
+        taps = O.lowpass_taps_f64(256, 1 / 16).astype(np.float32)
+        n = 50_000
+        x = O.synth_iq(0, 4 * n, seed=11)
+        xd = torch.from_numpy(x).cuda()
+        ys = []
+        for k in range(4):
+            chunk = xd[k * n:(k + 1) * n]
+            capi.check(L.qdsp_hip_ring_post(ring, chunk.data_ptr() + (n - H) * 8, st))
+            capi.check(L.qdsp_hip_ring_complete(ring, st, C.byref(halo), C.byref(prev)))
+            f = ops.Fir(taps, max_block=0)
+            f.set_history_ptr(prev.value, st)      # rank 0 of a one-rank ring: the tail of the chunk before (zeros at the start)
+            ys.append(f.process(chunk).cpu().numpy())
+            f.close()
+        want = O.Fir(taps, acc=O.ACC_F64).process(x)
+        assert rel_rms(np.concatenate(ys), want) < 2e-6
+    finally:
+        L.qdsp_hip_ring_destroy(ring)

@@ -280,6 +280,25 @@ def test_graph_bank_retune_and_reconfigure(harness, data):
 
 
 @gpu
+def test_graph_shard_over_the_c_ring(harness, data):
+    """graph_check shard: the time-sharded path driven from C++ through the C ABI (include/qdsp_hip.h "ring"): one rank as its own
+    ring neighbour filters the stream chunk by chunk, every chunk's history delivered by qdsp_hip_ring_post / _complete (RCCL
+    send + recv on the ring's stream, posted one step ahead) and installed with qdsp_hip_fir_cf32_set_history_dev: the
+    concatenated chunks equal FIR<complex_t> over the whole stream (src/dsp/filter.h:51-74 carries exactly those ntaps - 1
+    samples from one run() to the next)."""
+    d, x = data
+    taps = O.lowpass_taps_f64(256, 1 / 16)
+    taps.tofile(d / "t256s.f32")
+    n = 60_000
+    run([harness, "shard", str(d / "x.cf32"), str(d / "ysh.cf32"), str(n), str(d / "t256s.f32")])
+    y = np.fromfile(d / "ysh.cf32", dtype=np.complex64)
+    want = O.Fir(taps, acc=O.ACC_F64).process(x)[:len(x) // n * n]
+    assert len(y) == len(want) and rel_rms(y, want) < 2e-6
+    for k in range(1, len(x) // n):          # the first outputs of every chunk: a wrong halo is an O(1) error there
+        assert rel_rms(y[k * n:k * n + 64], want[k * n:k * n + 64]) < 1e-5, k
+
+
+@gpu
 def test_graph_bank_rebind_on_a_live_splitter(harness, data):
     """bindStream / unbindStream on a Splitter whose outputs run as a bank (how VFOs are added to a running graph,
     src/dsp/routing.h:27-45): the bank is taken down while token blocks of the last banked block may still be waiting in the
