@@ -17,7 +17,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "qdsp_amd", "csrc")
 OUT = os.path.join(ROOT, "profiles", "r03_resource_usage.txt")
-UNITS = {"qdsp_hip": "", "fft_fir": "-fno-slp-vectorize", "fft1k_fir": "-fno-slp-vectorize", "chan": "-fno-slp-vectorize",
+UNITS = {"qdsp_hip": "", "chan_ops": "", "misc_ops": "", "fft_fir": "-fno-slp-vectorize", "fft1k_fir": "-fno-slp-vectorize", "chan": "-fno-slp-vectorize",
          "pfb_dec": "-fno-slp-vectorize", "mf_dec": "", "rm_resamp": "", "fir_lat": ""}
 
 
