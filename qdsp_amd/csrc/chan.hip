@@ -75,7 +75,7 @@ __device__ __forceinline__ v2f bperm_pair(int src, v2f v) {
 // output time that the DFT does not cover: its tile part rides in A_c, its in-tile part depends on
 // (c0, n') only and is applied with the wave twiddle.
 // (M = 8: its 40-value window takes 80 VGPRs; 2 waves/SIMD without spills measured 10 % faster than 3 with a few)
-// ABL (diagnostic builds, profiles/r03_ablate_chan64m8.txt): 1 = no global stores, 2 = no DMA (tiles are whatever lies in LDS), 4 = no finish arithmetic
+// ABL (diagnostic builds, profiles/r03_chan_tuning.txt): 1 = no global stores, 2 = no DMA (tiles are whatever lies in LDS), 8 = plain instead of non-temporal stores
 // QF: 4 = all four tap rows present (193..256 taps: no per-row test in the accumulation), 0 = a.Q rows (run-time)
 template <bool INV, int M, int QF = 0, int ABL = 0>
 __global__ __launch_bounds__(256, 3) void chan_uniform_kernel(const ChanArgs a) {
@@ -329,7 +329,10 @@ __global__ __launch_bounds__(256, 3) void chan_uniform_kernel(const ChanArgs a) 
                 }
                 const v2f rt = bperm_pair(tsrc, r);
                 if (ABL & 1) { if (rt.x == 1.2345e30f) o[(size_t)c0 * a.out_stride] = rt; }
-                else if (!decltype(guarded)::value || live) o[(size_t)c0 * a.out_stride] = rt;
+                else if (ABL & 8) { if (!decltype(guarded)::value || live) o[(size_t)c0 * a.out_stride] = rt; }
+                // results are written once and never read here: non-temporal stores (round 3, interleaved A/B on one box: M = 64
+                // 0.4068 -> 0.3846 ms per 2^27 samples, M = 8 2.424 -> 2.394; profiles/r03_chan_tuning.txt)
+                else if (!decltype(guarded)::value || live) __builtin_nontemporal_store(rt, o + (size_t)c0 * a.out_stride);
             }
         };
         if (n0 + kChT <= a.nout) {
@@ -363,7 +366,13 @@ int launch_chan_uniform(const ChanArgs& a, int grid, hipStream_t stream) {
     if (a.abl && a.M == 8 && !a.inv && a.Q == 4) {
         if (a.abl == 1) hipLaunchKernelGGL((chan_uniform_kernel<false, 8, 4, 1>), dim3(grid), dim3(256), lds_bytes, stream, a);
         else if (a.abl == 2) hipLaunchKernelGGL((chan_uniform_kernel<false, 8, 4, 2>), dim3(grid), dim3(256), lds_bytes, stream, a);
+        else if (a.abl == 8) hipLaunchKernelGGL((chan_uniform_kernel<false, 8, 4, 8>), dim3(grid), dim3(256), lds_bytes, stream, a);
         else hipLaunchKernelGGL((chan_uniform_kernel<false, 8, 4, 3>), dim3(grid), dim3(256), lds_bytes, stream, a);
+        const hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : -(int)e;
+    }
+    if (a.abl == 8 && a.M == 64 && !a.inv && a.Q == 4) {
+        hipLaunchKernelGGL((chan_uniform_kernel<false, 64, 4, 8>), dim3(grid), dim3(256), lds_bytes, stream, a);
         const hipError_t e = hipGetLastError();
         return e == hipSuccess ? 0 : -(int)e;
     }

@@ -170,6 +170,7 @@ bool mf_plan(const Engine* e, int* KJ, int* QS, int* keep2) {
     if (Mk > 8 * qk::kMfMaxKJ) return false;
     const int Q = (P + Mk - 1) / Mk;                  // taps per column: one set of 16 rows of the A operand, or two
     if (Q > qk::kMfMaxQ || (Q > 16 && qk::knob(qk::K_MF_NO_QS2, 0))) return false;
+    if (Q > 16 && M < 12) return false;      // (two tap sets on rows of < 12 samples: 0.44 ms per 2^27 at decimation 10 against 0.36 overlap-save, round 3)
     if (M < 14 && P < 12 * M) return false;
     if (use_win(e) && P < 6 * M) return false;
     *KJ = (Mk + 7) / 8;
@@ -1512,10 +1513,14 @@ int launch_rm(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d_
     a.total = 4 * a.G * a.M + a.ext;
     const long long nper = (nout + a.L - 1) / a.L;
     a.ntiles = (int)((nper + 4 * a.G - 1) / (4 * a.G));
-    int nwaves = 1024 * qk::knob(qk::K_RM_WAVES_PER_SIMD, 3);
+    // waves QUEUED per SIMD (three are resident): more, shorter-lived waves than fit even out the tail and keep the tiles in flight closer
+    // together in memory (round 3, scripts/tune_rm_waves.py, profiles/r03_tune_rm_waves.txt: 147/160 0.236 -> 0.224 ms per 2^26 samples,
+    // interpolate-by-6 0.164 -> 0.130, 10/7 0.181 -> 0.179; the small decimating ratios are indifferent)
+    int nwaves = 1024 * qk::knob(qk::K_RM_WAVES_PER_SIMD, e->M == 1 ? 12 : e->L >= 100 ? 8 : 6);
     if (nwaves > a.ntiles) nwaves = a.ntiles;
     if (nwaves < 1) nwaves = 1;
     a.nwaves = nwaves;
+    a.nts = qk::knob(qk::K_RM_NT, 0);
     if (e->rotate) {
         a.phase0 = e->phase;
         a.dphase = e->dphase;
@@ -1597,6 +1602,23 @@ bool win_yields_to_fft1k(const Engine* e, int64_t count) {
     return fft1k_eligible(e, count);
 }
 
+// The strided-window decimator on chip-filling calls (round 3, scripts/tune_dec_small.py, profiles/r03_tune_win_vs_fft.txt, 2^27 samples):
+// its time grows with the taps (decimation 2: 0.32 ms at 48 taps, 0.53 at 128) while the overlap-save forms cost the same at any
+// length -- 0.48 / 0.38 / 0.33 ms at decimation 2 / 3 / 4, pfb_dec8_kernel 0.24-0.25 at decimation 8 -- so past the measured
+// crossovers the big calls go there (decimation 8, 160 taps: 0.30 -> 0.25 ms, fused VFO 0.35 -> 0.25; decimation 2, 144 taps:
+// 0.57 -> 0.48).  use_win()'s limits, measured on 2^26-sample calls in round 1, keep the smaller calls.
+bool win_yields_to_fft_big(const Engine* e, int64_t count) {
+    if (e->ch != 2 || qk::knob(qk::K_NO_WIN_BIG_CALL_RULE, 0)) return false;
+    const int M = e->M, P = e->P;
+    if (M == 8) return pfb_eligible(e, count) && P >= (e->rotate ? 56 : 88);
+    // (at 2^24 samples the window kernel is still ahead at decimation 3-5 -- 0.046-0.049 against 0.053-0.055 ms at 112-160 taps --
+    // and level at decimation 2)
+    if (M == 2) return count >= (1 << 24) && P >= 104;
+    if (M == 3 || M == 4) return count >= (1 << 26) && P >= 104;
+    if (M == 5) return count >= (1 << 26) && !e->rotate && P >= 152;
+    return false;
+}
+
 int64_t mf_min_count(const Engine* e) {
     const int v = qk::knob(qk::K_MF_MIN_COUNT, -1);
     if (v >= 0) return v;
@@ -1628,7 +1650,7 @@ int64_t process_dev(Engine* e, const void* d_in, int64_t count, void* d_out, voi
         // large integer decimations (the VFO's usual job) as an FP32 matrix product on the MFMA units (mf_dec.hip.h)
         rc = launch_mf(e, d_in, count, nout, d_out, s);
         if (rc == 0) e->cur ^= 1;
-    } else if (fft_eligible(e, count) && !(mode_of(e) == 0 && use_win(e) && e->d_taps_lm && !win_yields_to_fft1k(e, count))) {
+    } else if (fft_eligible(e, count) && !(mode_of(e) == 0 && use_win(e) && e->d_taps_lm && !win_yields_to_fft1k(e, count) && !win_yields_to_fft_big(e, count))) {
         rc = launch_fft(e, d_in, count, nout, d_out, s);
         if (rc == 0) e->cur ^= 1;
         took_fft = true;

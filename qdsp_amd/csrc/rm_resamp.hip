@@ -154,10 +154,17 @@ template <bool ROT> __global__ __launch_bounds__(256, 3) void resamp_mfma_kernel
                         if (o + 3 < L && n + 3 < a.nout) {
                             // (round 3: the lane's 32 contiguous bytes as two 16-byte stores at 8-byte alignment -- odd L puts odd periods on
                             // odd samples -- measured 0.451 against 0.442 ms for these four 8-byte ones on 147/160: not kept)
-                            dst[0] = make_float2(zr[0], zi[0]);
-                            dst[1] = make_float2(zr[1], zi[1]);
-                            dst[2] = make_float2(zr[2], zi[2]);
-                            dst[3] = make_float2(zr[3], zi[3]);
+                            if (a.nts) {
+                                typedef float v2nt __attribute__((ext_vector_type(2)));
+                                v2nt* d = reinterpret_cast<v2nt*>(dst);
+#pragma unroll
+                                for (int v = 0; v < 4; v++) __builtin_nontemporal_store((v2nt){zr[v], zi[v]}, d + v);
+                            } else {
+                                dst[0] = make_float2(zr[0], zi[0]);
+                                dst[1] = make_float2(zr[1], zi[1]);
+                                dst[2] = make_float2(zr[2], zi[2]);
+                                dst[3] = make_float2(zr[3], zi[3]);
+                            }
                         } else {
 #pragma unroll
                             for (int v = 0; v < 4; v++)
