@@ -116,6 +116,7 @@ struct Engine {
     // polyphase overlap-save decimate-by-8 (pfb_dec.hip.h): column spectra + twiddles, built for (pfb_ntaps, pfb_dphase)
     float2* d_pfb = nullptr;
     int pfb_ntaps = -1;
+    int pfb_M = -1;               // (decimate by 8, or by 4 as two output phases: another table)
     unsigned long long pfb_dphase = 0;
     std::vector<float> taps_host;
     // A retune (set_phase_inc) may come from a control thread while the worker is inside process*: the new

@@ -85,16 +85,26 @@ __device__ __forceinline__ float2 load_stream(const float2* p) {
 
 // Segment b (one wave): input positions S0 + [0, 4096), S0 = 8 (b Lo - Q); outputs n' = b Lo + a' - (Q-1) for the
 // inverse's elements a' in [Q-1, 512).  Lane l = c + 8 g': column c = l & 7, g' = l >> 3.
-template <bool ROT>
-__global__ __launch_bounds__(kPfbNT, 2) void pfb_dec8_kernel(const PfbArgs a) {
-    __shared__ __attribute__((aligned(16))) float2 sTab[kPfbTableElems];          // G | TW | TI1 | TI2
-    __shared__ __attribute__((aligned(16))) float2 sEx[kPfbNT / 64][64 * kPfbRow];  // wave-private exchange buffers
+//
+// PH = 2 (round 3): decimate by FOUR with the same eight column transforms.  y4[n] = sum_k h[k] s[4n - N + k] splits by the
+// parity of n into two decimate-by-8 filters over the same eight columns: y4[2n'] has its window end at 8n' - 1 (taps g),
+// y4[2n' - 1] at 8n' - 5 (taps g delayed by four samples: g_1 = 0 0 0 0 ++ g).  So the forward side -- loads, eight
+// 512-point column transforms -- is done ONCE, the column spectra meet TWO sets of filter spectra (G, G1), and two
+// 512-point inverses give the even and the odd outputs: 9 N + 2 (N/8) 9 butterfly stages' worth per N input samples where
+// four 1024-point columns + one 1024-point inverse would take 12.5 N.  Eight waves per workgroup share the two tables
+// (G1 unpadded, its 16-byte chunks swizzled by the row so that wide reads stay conflict-free); the second phase's column
+// sums wait in a wave-private LDS patch (no register for them in the rounds), then take the same inverse.
+template <bool ROT, int PH>
+__device__ __forceinline__ void pfb_body(const PfbArgs& a) {
+    constexpr int NT = kPfbNT * PH, NW = NT / 64;
+    __shared__ __attribute__((aligned(16))) float2 sTab[kPfbTableElems + (PH - 1) * kPfbG1Elems];   // G | TW | TI1 | TI2 | EL [| G1]
+    __shared__ __attribute__((aligned(16))) float2 sEx[NW][64 * kPfbRow];                          // wave-private exchange buffers
     const int t = threadIdx.x;
     const int H = a.H;
 
     if ((int)blockIdx.x == a.nwg) {
         // history hand-over (resampling.h:129): last H samples of hist ++ in, in the form the handle keeps them
-        for (int i = t; i < H; i += kPfbNT) {
+        for (int i = t; i < H; i += NT) {
             const long long g = a.count - H + i;
             float2 v;
             if (g < 0) {
@@ -118,7 +128,7 @@ __global__ __launch_bounds__(kPfbNT, 2) void pfb_dec8_kernel(const PfbArgs a) {
     {
         const float4* src = reinterpret_cast<const float4*>(a.tables);
         float4* dst = reinterpret_cast<float4*>(sTab);
-        for (int i = t; i < kPfbTableElems / 2; i += kPfbNT) dst[i] = src[i];
+        for (int i = t; i < (kPfbTableElems + (PH - 1) * kPfbG1Elems) / 2; i += NT) dst[i] = src[i];
     }
     __syncthreads();
     const float2* sG = sTab;
@@ -128,11 +138,18 @@ __global__ __launch_bounds__(kPfbNT, 2) void pfb_dec8_kernel(const PfbArgs a) {
 
     const int l = t & 63, wv = t >> 6;
     float2* E = sEx[wv];
+    float2* EY = nullptr;                    // PH = 2: the second phase's column sums, in the layout the inverse reads
+    if constexpr (PH == 2) {
+        __shared__ __attribute__((aligned(16))) float2 sEy[NW][64 * 9];
+        EY = sEy[wv];
+    }
+    const float2* sG1 = sTab + kPfbTableElems;
+    const int sw = (l >> 2) & 3;             // chunk swizzle of G1's rows
     const int c = l & 7, hi3 = l >> 3;       // writer: (column, g'); round reader: (column, mu = kq)
     const bool cb2 = (c & 4) != 0, cb1 = (c & 2) != 0, cb0 = (c & 1) != 0;
 
-    const int nwaves = a.nwg * (kPfbNT / 64);
-    const int wave0 = (int)blockIdx.x * (kPfbNT / 64) + wv;
+    const int nwaves = a.nwg * NW;
+    const int wave0 = (int)blockIdx.x * NW + wv;
 
     float2 el = make_float2(1.0f, 0.0f);     // exp(j 2pi 8 l dphase): this lane's outputs sit at elements l + 64 b1
     double2 pb = make_double2(1.0, 0.0);     // exp(j 2pi ph(first output of the segment)), advanced per segment
@@ -156,6 +173,26 @@ __global__ __launch_bounds__(kPfbNT, 2) void pfb_dec8_kernel(const PfbArgs a) {
     const long long last_start = a.count - kPfbSeg;       // (the dispatch guarantees count >= 4096)
     auto seg_start = [&](int b) { return 8LL * ((long long)b * a.Lo - a.Q); };
     auto clamped = [&](long long s0) { return s0 < 0 ? 0LL : (s0 > last_start ? last_start : s0); };
+    // reduce-scatter over the eight columns (lanes c = 0..7 of each group of 8): lane c ends up with the sum for kg = c.
+    // (Round 3 tried the other road -- transpose through the exchange buffer, free between a round's reads and the next round's writes: 8
+    // ds_write_b64 + 4 ds_read_b128 + 14 v_add_f32 instead of 14 v_add_f32_dpp + 28 v_cndmask -- and measured 0.2436 against 0.2463 ms
+    // per 2^27 samples for the decimator, 0.2560 against 0.2484 for the fused VFO, no change at decimation 4: the ~1300 issue cycles it
+    // saves per segment come back as waits on the LDS round trip.  Not kept.)
+    auto colsum = [&](const float2 (&pr)[8]) -> float2 {
+        float2 s4[4], s2[2];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {   // partner 7 - c: differs in bit 2; keep the half kg bit 2 == c bit 2
+            const float2 keep = cb2 ? pr[4 + i] : pr[i], send = cb2 ? pr[i] : pr[4 + i];
+            s4[i] = make_float2(keep.x + dpp<kDppHalfMirror>(send.x), keep.y + dpp<kDppHalfMirror>(send.y));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) {   // partner c ^ 2
+            const float2 keep = cb1 ? s4[2 + i] : s4[i], send = cb1 ? s4[i] : s4[2 + i];
+            s2[i] = make_float2(keep.x + dpp<kDppXor2>(send.x), keep.y + dpp<kDppXor2>(send.y));
+        }
+        const float2 keep = cb0 ? s2[1] : s2[0], send = cb0 ? s2[0] : s2[1];      // partner c ^ 1
+        return make_float2(keep.x + dpp<kDppXor1>(send.x), keep.y + dpp<kDppXor1>(send.y));
+    };
     float2 v[64];
     {
         const float2* __restrict__ p = a.in + clamped(seg_start(wave0 < a.nseg ? wave0 : 0)) + l;
@@ -245,94 +282,125 @@ __global__ __launch_bounds__(kPfbNT, 2) void pfb_dec8_kernel(const PfbArgs a) {
 #pragma unroll
             for (int g = 1; g < 8; g++) r8[g] = cmulc<false>(r8[g], tw[g]);
             fft8<false, 1>(r8);
-            float2 pr[8];   // pr[kg] = G_c[k] X_c[k]
+            float2 pr[8], pr1[PH == 2 ? 8 : 1];   // pr[kg] = G_c[k] X_c[k]  (pr1: against the odd outputs' spectra)
+            if constexpr (PH == 2) {
+                // (both products before either column sum: the transformed values die here, as they do with one phase -- kept alive across
+                // the first reduce-scatter they cost the rounds, the kernel's pressure peak, sixteen registers and 10-33 spills)
+                float2 g1[8];
 #pragma unroll
-            for (int kg = 0; kg < 8; kg++) pr[kg] = cmulc<false>(r8[rev8(kg)], gg[kg]);
-            // reduce-scatter over the eight columns (lanes c = 0..7 of each group of 8): lane c ends up with the sum for kg = c
-            float2 s4[4], s2[2];
+                for (int i = 0; i < 4; i++) {
+                    const float4 g4 = lds_read4(sG1 + (rho * 64 + l) * 8 + 2 * (i ^ sw));
+                    g1[2 * i] = make_float2(g4.x, g4.y);
+                    g1[2 * i + 1] = make_float2(g4.z, g4.w);
+                }
 #pragma unroll
-            for (int i = 0; i < 4; i++) {   // partner 7 - c: differs in bit 2; keep the half kg bit 2 == c bit 2
-                const float2 keep = cb2 ? pr[4 + i] : pr[i], send = cb2 ? pr[i] : pr[4 + i];
-                s4[i] = make_float2(keep.x + dpp<kDppHalfMirror>(send.x), keep.y + dpp<kDppHalfMirror>(send.y));
-            }
+                for (int kg = 0; kg < 8; kg++) {
+                    pr[kg] = cmulc<false>(r8[rev8(kg)], gg[kg]);
+                    pr1[kg] = cmulc<false>(r8[rev8(kg)], g1[kg]);
+                }
+            } else {
 #pragma unroll
-            for (int i = 0; i < 2; i++) {   // partner c ^ 2
-                const float2 keep = cb1 ? s4[2 + i] : s4[i], send = cb1 ? s4[i] : s4[2 + i];
-                s2[i] = make_float2(keep.x + dpp<kDppXor2>(send.x), keep.y + dpp<kDppXor2>(send.y));
+                for (int kg = 0; kg < 8; kg++) pr[kg] = cmulc<false>(r8[rev8(kg)], gg[kg]);
             }
-            {                               // partner c ^ 1
-                const float2 keep = cb0 ? s2[1] : s2[0], send = cb0 ? s2[0] : s2[1];
-                yr[rho] = make_float2(keep.x + dpp<kDppXor1>(send.x), keep.y + dpp<kDppXor1>(send.y));
-            }
+            yr[rho] = colsum(pr);
+            if constexpr (PH == 2) EY[(rho + 8 * hi3) * 9 + c] = colsum(pr1);
         }
 
         // ---- inverse 512-point transform of Y: y[a'] = sum_k Y[k] V^(a' k), V = exp(+j 2pi/512) ---------------
-        // I0: lane (kg = c, mu) holds Y[rho + 8 mu + 64 kg]  ->  lane m reads Y[m + 64 kg], kg = 0..7
+        // in: lane m holds z[kg] = Y[m + 64 kg]; out: element a' = l + 64 b1 at z[rev8(b1)]
+        auto inverse = [&](float2 (&z)[8]) {
+            // pass I1 over kg -> alpha = a' mod 8 at z[rev8(alpha)]; twiddle V512^(m alpha)
+            fft8<true, 1>(z);
+            float2 zt[8];
+            zt[0] = z[0];
 #pragma unroll
-        for (int rho = 0; rho < 8; rho++) E[(rho + 8 * hi3) * 9 + c] = yr[rho];
-        __builtin_amdgcn_wave_barrier();
-        float2 z[8];
+            for (int i = 0; i < 4; i++) {
+                const float4 w4 = lds_read4(sTI1 + l * kPfbRow + 2 * i);
+                if (i) zt[2 * i] = cmulc<false>(z[rev8(2 * i)], make_float2(w4.x, w4.y));
+                zt[2 * i + 1] = cmulc<false>(z[rev8(2 * i + 1)], make_float2(w4.z, w4.w));
+            }
+            // I2: row alpha, column m  ->  lane (m0 = l & 7, alpha = l >> 3) reads m = m0 + 8 m1
 #pragma unroll
-        for (int kg = 0; kg < 8; kg++) z[kg] = E[l * 9 + kg];
-        __builtin_amdgcn_wave_barrier();
-        // pass I1 over kg -> alpha = a' mod 8 at z[rev8(alpha)]; twiddle V512^(m alpha)
-        fft8<true, 1>(z);
-        float2 zt[8];
-        zt[0] = z[0];
+            for (int al = 0; al < 8; al++) E[al * 72 + l] = zt[al];
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const float4 w4 = lds_read4(sTI1 + l * kPfbRow + 2 * i);
-            if (i) zt[2 * i] = cmulc<false>(z[rev8(2 * i)], make_float2(w4.x, w4.y));
-            zt[2 * i + 1] = cmulc<false>(z[rev8(2 * i + 1)], make_float2(w4.z, w4.w));
-        }
-        // I2: row alpha, column m  ->  lane (m0 = l & 7, alpha = l >> 3) reads m = m0 + 8 m1
+            for (int m1 = 0; m1 < 8; m1++) z[m1] = E[hi3 * 72 + c + 8 * m1];
+            __builtin_amdgcn_wave_barrier();
+            // pass I2 over m1 -> b0 at z[rev8(b0)]; twiddle V64^(m0 b0)   (a' = alpha + 8 b0 + 64 b1)
+            fft8<true, 1>(z);
+            zt[0] = z[0];
 #pragma unroll
-        for (int al = 0; al < 8; al++) E[al * 72 + l] = zt[al];
-        __builtin_amdgcn_wave_barrier();
+            for (int i = 0; i < 4; i++) {
+                const float4 w4 = lds_read4(sTI2 + c * kPfbRow + 2 * i);
+                if (i) zt[2 * i] = cmulc<false>(z[rev8(2 * i)], make_float2(w4.x, w4.y));
+                zt[2 * i + 1] = cmulc<false>(z[rev8(2 * i + 1)], make_float2(w4.z, w4.w));
+            }
+            // I3: row (b0, alpha), column m0  ->  lane alpha + 8 b0 reads its row
 #pragma unroll
-        for (int m1 = 0; m1 < 8; m1++) z[m1] = E[hi3 * 72 + c + 8 * m1];
-        __builtin_amdgcn_wave_barrier();
-        // pass I2 over m1 -> b0 at z[rev8(b0)]; twiddle V64^(m0 b0)   (a' = alpha + 8 b0 + 64 b1)
-        fft8<true, 1>(z);
-        zt[0] = z[0];
+            for (int b0 = 0; b0 < 8; b0++) E[(8 * b0 + hi3) * 9 + c] = zt[b0];
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const float4 w4 = lds_read4(sTI2 + c * kPfbRow + 2 * i);
-            if (i) zt[2 * i] = cmulc<false>(z[rev8(2 * i)], make_float2(w4.x, w4.y));
-            zt[2 * i + 1] = cmulc<false>(z[rev8(2 * i + 1)], make_float2(w4.z, w4.w));
-        }
-        // I3: row (b0, alpha), column m0  ->  lane alpha + 8 b0 reads its row
-#pragma unroll
-        for (int b0 = 0; b0 < 8; b0++) E[(8 * b0 + hi3) * 9 + c] = zt[b0];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int m0 = 0; m0 < 8; m0++) z[m0] = E[l * 9 + m0];
-        __builtin_amdgcn_wave_barrier();
-        // pass I3 over m0 -> b1 at z[rev8(b1)]: element a' = l + 64 b1
-        fft8<true, 1>(z);
-
-        // ---- store the Lo valid outputs, rotated by the NCO (fused VFO) ------------------------------------
+            for (int m0 = 0; m0 < 8; m0++) z[m0] = E[l * 9 + m0];
+            __builtin_amdgcn_wave_barrier();
+            // pass I3 over m0 -> b1 at z[rev8(b1)]: element a' = l + 64 b1
+            fft8<true, 1>(z);
+        };
+        // ---- store the Lo valid outputs, rotated by the NCO (fused VFO): element a' of phase phi is output PH n' - phi ----
         float2 q = make_float2(1.0f, 0.0f);
         if (ROT) {
             q = cmulc<false>(make_float2((float)pb.x, (float)pb.y), el);
             pb = dcmul(pb, a.rot_step);
         }
-        const long long nb = (long long)b * a.Lo - (a.Q - 1);
+        // (32-bit lane offsets from a segment base: per-lane 64-bit output indices get hoisted out of the segment loop and spilled)
+        const long long base = PH * ((long long)b * a.Lo - (a.Q - 1));           // output index of element a' = 0, phase 0
+        const long long room = a.nout - base;
+        const int hi = room > 8192 ? 8192 : (int)room;                            // offsets below this one are inside the call
+        const int lo = base > 0 ? -8 : (int)-base;                                // ... and from this one on not before its start
+        float2* __restrict__ ob = a.out + base;
+        auto store = [&](const float2 (&z)[8], int phi) {
 #pragma unroll
-        for (int b1 = 0; b1 < 8; b1++) {
-            const int ap = l + 64 * b1;
-            const long long n = nb + ap;
-            float2 y = z[rev8(b1)];
-            if (ROT) y = cmulc<false>(y, (b1 == 0) ? q : cmulc<false>(q, a.wtab[b1]));
-            if (ap >= a.Q - 1 && n < a.nout) store_nt(a.out + n, y);
+            for (int b1 = 0; b1 < 8; b1++) {
+                const int ap = l + 64 * b1;
+                const int off = PH * ap - phi;
+                float2 y = z[rev8(b1)];
+                if (ROT) y = cmulc<false>(y, (b1 == 0) ? q : cmulc<false>(q, a.wtab[b1]));
+                if (ap >= a.Q - 1 && off >= lo && off < hi) {
+                    // (decimate by 4: the two phases interleave 8-byte pieces; written non-temporally those cost 0.414 against 0.313 ms)
+                    if (PH == 1) store_nt(ob + off, y);
+                    else ob[off] = y;
+                }
+            }
+        };
+        float2 z[8];
+        // I0: lane (kg = c, mu) holds Y[rho + 8 mu + 64 kg]  ->  lane m reads Y[m + 64 kg], kg = 0..7
+#pragma unroll
+        for (int rho = 0; rho < 8; rho++) E[(rho + 8 * hi3) * 9 + c] = yr[rho];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int kg = 0; kg < 8; kg++) z[kg] = E[l * 9 + kg];
+        __builtin_amdgcn_wave_barrier();
+        inverse(z);
+        store(z, 0);
+        if constexpr (PH == 2) {
+#pragma unroll
+            for (int kg = 0; kg < 8; kg++) z[kg] = EY[l * 9 + kg];
+            __builtin_amdgcn_wave_barrier();
+            inverse(z);
+            store(z, 1);
         }
 #pragma unroll
         for (int r = 0; r < 64; r++) v[r] = vn[r];
     }
 }
 
+template <bool ROT> __global__ __launch_bounds__(kPfbNT, 2) void pfb_dec8_kernel(const PfbArgs a) { pfb_body<ROT, 1>(a); }
+template <bool ROT> __global__ __launch_bounds__(2 * kPfbNT, 1) void pfb_dec4_kernel(const PfbArgs a) { pfb_body<ROT, 2>(a); }
+
 int launch_pfb_dec(const PfbArgs& a, hipStream_t stream) {
-    if (a.rot) hipLaunchKernelGGL((pfb_dec8_kernel<true>), dim3(a.nwg + 1), dim3(kPfbNT), 0, stream, a);
+    if (a.PH == 2) {
+        if (a.rot) hipLaunchKernelGGL((pfb_dec4_kernel<true>), dim3(a.nwg + 1), dim3(2 * kPfbNT), 0, stream, a);
+        else hipLaunchKernelGGL((pfb_dec4_kernel<false>), dim3(a.nwg + 1), dim3(2 * kPfbNT), 0, stream, a);
+    } else if (a.rot) hipLaunchKernelGGL((pfb_dec8_kernel<true>), dim3(a.nwg + 1), dim3(kPfbNT), 0, stream, a);
     else hipLaunchKernelGGL((pfb_dec8_kernel<false>), dim3(a.nwg + 1), dim3(kPfbNT), 0, stream, a);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;

@@ -53,9 +53,11 @@ struct PfbArgs {
     double2 seg_pow[12];          // exp(j 2pi * 8 Lo * 2^k * dphase): segment b's base = pb_base * prod over the set bits of b (no sincos on the device)
     float2 wtab[8];               // exp(j 2pi * 512 b1 * dphase)
     float gm1;
+    int PH;                       // output phases per column output: 1 = decimate by 8, 2 = decimate by 4 (pfb_dec.hip)
 };
 
 constexpr int kPfbTableElems = (512 + 64 + 64 + 8) * kPfbRow + 64;   // + EL: exp(j 2pi 8 l dphase) per lane (fused VFO)
+constexpr int kPfbG1Elems = 512 * 8;                                 // decimate by 4: the odd outputs' column spectra, rows of 8 (chunk-swizzled)
 
 int launch_pfb_dec(const PfbArgs& a, hipStream_t stream);
 

@@ -1131,25 +1131,30 @@ int launch_xlate_inc(Engine* e, const void* d_in, int64_t count, void* d_out, un
 // Serves PolyphaseResampler<complex_t> / the fused VFO with interp 1, decim 8 on calls big enough to fill the chip
 // with one segment per wave (8 waves per CU: measured crossover against the per-segment fir_fft_kernel<8> in
 // scripts/tune_call_size.py).
+// (round 3: decimate by 4 as TWO output phases over the same eight columns, pfb_dec.hip: taps per column counted with the odd
+// outputs' four-sample delay)
+inline int pfb_phases(const Engine* e) { return e->M == 4 ? 2 : 1; }
+inline int pfb_Q(const Engine* e) { return (e->ntaps + e->M * (pfb_phases(e) - 1) + qk::kPfbD - 1) / qk::kPfbD; }
 bool pfb_eligible(const Engine* e, int64_t count) {
-    if (e->ch != 2 || e->L != 1 || e->M != qk::kPfbD || e->ntaps < 2) return false;
+    if (e->ch != 2 || e->L != 1 || (e->M != qk::kPfbD && e->M != 4) || e->ntaps < 2) return false;
     if (e->kind != KIND_DECIM && e->kind != KIND_VFO) return false;
-    if ((e->ntaps + qk::kPfbD - 1) / qk::kPfbD > qk::kPfbMaxQ) return false;
-    if (qk::knob(qk::K_NO_PFB, 0)) return false;
+    if (pfb_Q(e) > qk::kPfbMaxQ) return false;
+    if (qk::knob(qk::K_NO_PFB, 0) || (e->M == 4 && qk::knob(qk::K_NO_PFB4, 0))) return false;
     // measured crossover (scripts/tune_pfb_threshold.py, 256 taps): a lone segment takes a wave ~7 us (15 us per call
     // with the table load) where fir_fft_kernel<8> needs 8 us, so the per-segment kernels keep the reference-sized
     // calls; from 2^23 samples (decimator) / 2^24 (fused VFO) on this form is ahead, 1.2x at 2^27
     // (never below one segment: the kernel's prefetch reads whole 4096-sample segments from a clamped in-range start)
     if (count < qk::kPfbSeg) return false;
-    return count >= (int64_t)qk::knob(qk::K_PFB_MIN_COUNT, e->rotate ? 1 << 24 : 1 << 23);
+    // (decimate by 4, profiles/r03_tune_pfb4.txt: level with fir_fft_dec_kernel<4> at 2^25 samples, 0.166 against 0.181 ms at 2^26, 0.312 against 0.330 at 2^27)
+    return count >= (int64_t)qk::knob(qk::K_PFB_MIN_COUNT, e->M == 4 ? 1 << 26 : e->rotate ? 1 << 24 : 1 << 23);
 }
 
 int pfb_prepare(Engine* e) {
     const unsigned long long key_dphase = e->rotate ? e->dphase : 0;
-    if (e->pfb_ntaps == e->ntaps && e->d_pfb && e->pfb_dphase == key_dphase) return 0;
+    if (e->pfb_ntaps == e->ntaps && e->pfb_M == e->M && e->d_pfb && e->pfb_dphase == key_dphase) return 0;
     constexpr int F = qk::kPfbF, D = qk::kPfbD, R = qk::kPfbRow;
     const long double two_pi = 6.283185307179586476925286766559005768L;
-    const int N = e->ntaps, Q = (N + D - 1) / D;
+    const int N = e->ntaps, PH = pfb_phases(e), Q = pfb_Q(e);
     // g[j] = taps[N-1-j] (x exp(j (N-1-j) dphase) for the fused VFO: the mixer folded into the taps, fft_fir.hip.h)
     std::vector<long double> gr((size_t)Q * D, 0.0L), gi((size_t)Q * D, 0.0L);
     for (int j = 0; j < N; j++) {
@@ -1165,7 +1170,7 @@ int pfb_prepare(Engine* e) {
     }
     std::vector<long double> cs(F), ss(F);
     for (int i = 0; i < F; i++) { cs[i] = cosl(two_pi * i / F); ss[i] = sinl(two_pi * i / F); }
-    std::vector<float2> tab((size_t)qk::kPfbTableElems, make_float2(0.0f, 0.0f));
+    std::vector<float2> tab((size_t)qk::kPfbTableElems + (size_t)(PH - 1) * qk::kPfbG1Elems, make_float2(0.0f, 0.0f));
     // G: row (k0*64 + kq*8 + c), element kg: spectrum of column c's filter gamma_c[q] = g[8q + 7 - c] at bin k0 + 8 kq + 64 kg, / 512
     for (int c = 0; c < D; c++) {
         std::vector<long double> cr((size_t)Q), ci((size_t)Q);
@@ -1178,6 +1183,34 @@ int pfb_prepare(Engine* e) {
         for (int k = 0; k < F; k++) {
             const int k0 = k & 7, kq = (k >> 3) & 7, kg = k >> 6;
             tab[(size_t)((k0 * 64 + kq * 8 + c) * R + kg)] = make_float2((float)(sre[k] / F), (float)(sim[k] / F));
+        }
+    }
+    if (PH == 2) {
+        // G1: the odd outputs y4[2n' - 1]: window end 8n' - 5, i.e. the same taps four samples later, g_1 = 0 0 0 0 ++ g; the NCO phase of
+        // that output is four samples behind the even one's (x exp(-j 4 dphase), folded in here).  Rows of 8 values, 16-byte chunk i of row
+        // (k0, kq, c) stored at chunk i ^ ((kq*8 + c) >> 2 & 3): pfb_dec.hip reads it back the same way
+        long double rc = 1.0L, rs = 0.0L;
+        if (e->rotate) {
+            const long double tt = ldexpl((long double)e->dphase, -64) * 4.0L;
+            rc = cosl(two_pi * (tt - floorl(tt)));
+            rs = -sinl(two_pi * (tt - floorl(tt)));
+        }
+        float2* G1 = tab.data() + qk::kPfbTableElems;
+        for (int c = 0; c < D; c++) {
+            std::vector<long double> cr((size_t)Q, 0.0L), ci((size_t)Q, 0.0L);
+            for (int q = 0; q < Q; q++) {
+                const int j = D * q + (D - 1 - c) - 4;       // index into g
+                if (j < 0 || j >= N) continue;
+                cr[q] = gr[j] * rc - gi[j] * rs;
+                ci[q] = gr[j] * rs + gi[j] * rc;
+            }
+            std::vector<double> sre, sim;
+            host_spectrum(cr, ci, F, sre, sim);
+            for (int k = 0; k < F; k++) {
+                const int k0 = k & 7, kq = (k >> 3) & 7, kg = k >> 6;
+                const int row = k0 * 64 + kq * 8 + c, swz = ((kq * 8 + c) >> 2) & 3;
+                G1[(size_t)row * 8 + 2 * ((kg >> 1) ^ swz) + (kg & 1)] = make_float2((float)(sre[k] / F), (float)(sim[k] / F));
+            }
         }
     }
     float2* TW = tab.data() + 512 * R;     // row (k0*8 + kq), element g': W512^(g' (k0 + 8 kq))
@@ -1199,10 +1232,11 @@ int pfb_prepare(Engine* e) {
         if (e->rotate) unit_of_fx_c(e->dphase, (long double)(8 * l), &c, &sn);
         EL[l] = make_float2((float)c, (float)sn);
     }
-    if (!e->d_pfb) HIPCHK(hipMalloc(&e->d_pfb, tab.size() * sizeof(float2)));
+    if (!e->d_pfb) HIPCHK(hipMalloc(&e->d_pfb, ((size_t)qk::kPfbTableElems + qk::kPfbG1Elems) * sizeof(float2)));
     HIPCHK(hipDeviceSynchronize());   // (retune / new taps: nothing in flight may still read the old tables)
     HIPCHK(hipMemcpy(e->d_pfb, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice));
     e->pfb_ntaps = N;
+    e->pfb_M = e->M;
     e->pfb_dphase = key_dphase;
     return 0;
 }
@@ -1253,14 +1287,19 @@ int launch_pfb(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
     a.count = count;
     a.nout = nout;
     a.H = e->H;
-    a.Q = (e->ntaps + qk::kPfbD - 1) / qk::kPfbD;
+    a.PH = pfb_phases(e);
+    a.Q = pfb_Q(e);
     a.Lo = qk::kPfbF + 1 - a.Q;
-    a.nseg = (int)((nout + a.Lo - 1) / a.Lo);
+    // column outputs n' the call needs: output n = PH n' - phi, n < nout  ->  n' <= ceil((nout - 1) / PH)
+    const int64_t ncol = a.PH == 1 ? nout : (nout + a.PH - 2) / a.PH + 1;
+    a.nseg = (int)((ncol + a.Lo - 1) / a.Lo);
     // persistent workgroups of 4 waves, one segment per wave at a time; 2 workgroups resident per CU (72 KB of LDS,
     // ~220 VGPRs), QDSP_HIP_PFB_WG_PER_CU queued per CU
-    int nwg = 256 * qk::knob(qk::K_PFB_WG_PER_CU, 2);
+    // (decimate by 4: 8 waves per workgroup -- they share the two spectrum tables, 159 KB of LDS -- one workgroup per CU)
+    const int wpw = 4 * a.PH;
+    int nwg = 256 * qk::knob(qk::K_PFB_WG_PER_CU, 2) / a.PH;
     if (nwg > 1024) nwg = 1024;
-    const int need = (a.nseg + 3) / 4;
+    const int need = (a.nseg + wpw - 1) / wpw;
     if (nwg > need) nwg = need;
     if (nwg < 1) nwg = 1;
     a.nwg = nwg;
@@ -1270,8 +1309,8 @@ int launch_pfb(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
         a.phase0 = e->phase - (unsigned long long)(e->ntaps - 1) * e->dphase;
         a.dphase = e->dphase;
         a.gm1 = e->volk_gain ? e->gm1 : 0.0f;
-        unit_of_fx_c(e->dphase, 8.0L * (long double)a.Lo * (long double)(4 * nwg), &a.rot_step.x, &a.rot_step.y);
-        if (4 * nwg > 4096) return QDSP_HIP_EINVAL;     // (seg_pow covers wave indices below 2^12)
+        unit_of_fx_c(e->dphase, 8.0L * (long double)a.Lo * (long double)(wpw * nwg), &a.rot_step.x, &a.rot_step.y);
+        if (wpw * nwg > 4096) return QDSP_HIP_EINVAL;     // (seg_pow covers wave indices below 2^12)
         unit_of_fx(a.phase0 - (unsigned long long)(8 * (a.Q - 1) + 1) * a.dphase, 1.0L, &a.pb_base.x, &a.pb_base.y);
         for (int k = 0; k < 12; k++) unit_of_fx_c(e->dphase, 8.0L * (long double)a.Lo * (long double)(1 << k), &a.seg_pow[k].x, &a.seg_pow[k].y);
         for (int b1 = 0; b1 < 8; b1++) {
@@ -1283,10 +1322,10 @@ int launch_pfb(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
     rc = qk::launch_pfb_dec(a, s);
     if (rc) return rc;
     e->raw_valid = e->rotate && e->H > 0;   // (the caller flips cur: the raw hand-over then sits at d_hist_raw[cur])
-    e->last.name = "pfb_dec8_kernel";
+    e->last.name = a.PH == 2 ? "pfb_dec4_kernel" : "pfb_dec8_kernel";
     e->last.grid = nwg + 1;
-    e->last.block = qk::kPfbNT;
-    e->last.lds = (int)((qk::kPfbTableElems + 4 * 64 * qk::kPfbRow) * sizeof(float2));
+    e->last.block = qk::kPfbNT * a.PH;
+    e->last.lds = (int)((qk::kPfbTableElems + (a.PH - 1) * qk::kPfbG1Elems + wpw * 64 * qk::kPfbRow + (a.PH - 1) * wpw * 64 * 9) * sizeof(float2));
     return 0;
 }
 

@@ -17,7 +17,7 @@ def floor_of(x, taps):
 
 
 KNOBS = ("QDSP_HIP_NO_FFT1K_REAL", "QDSP_HIP_NO_FFT1K", "QDSP_HIP_MF_BATCH_MIN_WORK", "QDSP_HIP_MF_MIN_COUNT", "QDSP_HIP_RM_MIN_COUNT",
-         "QDSP_HIP_RM_MIN_INTERP", "QDSP_HIP_NO_LM_SMALL_CALL_RULE")
+         "QDSP_HIP_RM_MIN_INTERP", "QDSP_HIP_NO_LM_SMALL_CALL_RULE", "QDSP_HIP_PFB_MIN_COUNT")
 
 
 def run(budget, seed, default_only=False, verbose=True):
@@ -120,7 +120,7 @@ def run(budget, seed, default_only=False, verbose=True):
             ntaps = int(rng.integers(L, 40 * L))
         vfo = bool(rng.integers(0, 2)) and kind != "fir"
         lift = bool(rng.integers(0, 2))
-        for k in ("QDSP_HIP_MF_MIN_COUNT", "QDSP_HIP_RM_MIN_COUNT", "QDSP_HIP_RM_MIN_INTERP", "QDSP_HIP_NO_FFT1K", "QDSP_HIP_NO_LM_SMALL_CALL_RULE"):
+        for k in ("QDSP_HIP_MF_MIN_COUNT", "QDSP_HIP_RM_MIN_COUNT", "QDSP_HIP_RM_MIN_INTERP", "QDSP_HIP_NO_FFT1K", "QDSP_HIP_NO_LM_SMALL_CALL_RULE", "QDSP_HIP_PFB_MIN_COUNT"):
             knob(k, None)
         if rng.integers(0, 3) == 0:
             knob("QDSP_HIP_NO_LM_SMALL_CALL_RULE", "1")     # (resamp_lm_kernel on the small calls the general kernel takes by default)
@@ -129,6 +129,7 @@ def run(budget, seed, default_only=False, verbose=True):
         if lift:
             knob("QDSP_HIP_MF_MIN_COUNT", "0")
             knob("QDSP_HIP_RM_MIN_COUNT", "0")
+            knob("QDSP_HIP_PFB_MIN_COUNT", "4096")      # (the wave-per-segment polyphase kernels, decimation 8 and 4, on test-sized calls)
             if rng.integers(0, 2):
                 knob("QDSP_HIP_RM_MIN_INTERP", "2")
         taps = (O.lowpass_taps_f64(ntaps, 0.45 / max(L, M)) * L).astype(np.float32) if ntaps > 2 else rng.standard_normal(ntaps).astype(np.float32)

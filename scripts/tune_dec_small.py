@@ -57,8 +57,6 @@ def main():
                 row = []
                 for setting in [""] + a.alts.split(";"):
                     t, name = run(x, M, ntaps, nco, setting)
-                    if setting and name == row[0][1]:
-                        continue
                     row.append((t, name, setting))
                 cells = "   ".join(f"{s or 'default':18s} {nm:20s} {t:.4f} ms = {(8 + 8 / M) * n / t / 1e6 / 8000:.3f}" for t, nm, s in row)
                 print(f"decimate by {M:2d}, {ntaps:3d} taps{', NCO' if nco else '     '}: {cells}", flush=True)
