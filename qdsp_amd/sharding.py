@@ -195,7 +195,11 @@ class RingStream:
         self._pending = None          # (reqs, buffer index) of the exchange in flight
         self._posted = 0              # exchanges posted so far
         self._ring = None
-        if self.exchange and transport == "device" and self.device.type == "cuda":
+        # (QDSP_RING_TRANSPORT=torch: the same exchange through torch.distributed's batch_isend_irecv on device tensors -- round 2's
+        # transport, kept as a switch for hosts whose RCCL the library cannot bind; every rank must set it alike)
+        import os
+
+        if self.exchange and transport == "device" and self.device.type == "cuda" and os.environ.get("QDSP_RING_TRANSPORT", "c") != "torch":
             self._ring = _CRing(self.device.index or 0, self.rank, self.world, self.H * 8, group)
         if self.exchange and self._ring is None:      # (host transport, or device tensors of a CPU stand-in operator over gloo: the CPU tests)
             z = lambda: torch.zeros(max(self.H, 1), dtype=torch.complex64, device=self.device)  # noqa: E731

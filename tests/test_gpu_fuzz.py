@@ -68,7 +68,7 @@ DIRECTED = [
     ("res", 1, 8, 256, False, [(1_000_000, "fir_fft1k_kernel"), ((1 << 23) + 8, "pfb_dec8_kernel")]),
     ("res", 1, 8, 256, True, [((1 << 24) + 16, "pfb_dec8_kernel")]),
     ("res", 1, 4, 63, False, [(200_000, "decim_win_kernel")]),
-    ("res", 1, 4, 160, True, [(500_000, "decim_win_kernel"), ((1 << 26) + 4, "pfb_dec4_kernel")]),
+    ("res", 1, 4, 160, True, [(2_000_000, "decim_win_kernel"), ((1 << 26) + 4, "pfb_dec4_kernel")]),
     ("res", 1, 16, 129, True, [(300_000, "decim_mfma_kernel")]),
     ("res", 1, 50, 401, True, [(100_000, "resamp_any_kernel"), (3_200_000, "decim_mfma_kernel")]),
     ("res", 3, 2, 36, False, [(100_000, "resamp_lm_kernel")]),
