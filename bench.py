@@ -61,6 +61,9 @@ WORKLOADS = {
     "decim8": dict(ntaps=256, decim=8, rot=False, bytes=9.0, flops=128.0),
     "xlate_fir_decim8": dict(ntaps=256, decim=8, rot=True, bytes=9.0, flops=134.0),
     "xlate": dict(ntaps=0, decim=1, rot=True, bytes=16.0, flops=6.0),
+    # decimate by 4 (round 3: pfb_dec4_kernel): 8 B in + 8/4 B out
+    "decim4": dict(ntaps=256, decim=4, rot=False, bytes=10.0, flops=256.0),
+    "xlate_fir_decim4": dict(ntaps=256, decim=4, rot=True, bytes=10.0, flops=262.0),
     # short filters (the strided-window direct kernel)
     "decim8_t63": dict(ntaps=63, decim=8, rot=False, bytes=9.0, flops=31.5),
     "xlate_fir_decim8_t63": dict(ntaps=63, decim=8, rot=True, bytes=9.0, flops=37.5),
@@ -236,6 +239,8 @@ WORKLOAD_TEXT = {
     "decim8": "256-tap polyphase decimate-by-8, synthetic IQ",
     "xlate_fir_decim8": "fused NCO + 256-tap FIR + decimate-by-8 (BASELINE configs[2])",
     "xlate": "NCO frequency translator alone",
+    "decim4": "256-tap polyphase decimate-by-4, synthetic IQ",
+    "xlate_fir_decim4": "fused NCO + 256-tap FIR + decimate-by-4",
     "decim8_t63": "63-tap polyphase decimate-by-8",
     "xlate_fir_decim8_t63": "fused NCO + 63-tap FIR + decimate-by-8",
     "vfo50": "fused NCO + 401-tap FIR + decimate-by-50 (the reference VFO's 2.4 Msps -> 48 kHz shape)",
@@ -424,6 +429,9 @@ def run_workload(name: str, args, ctx) -> dict:
         # polyphase overlap-save, one wave per segment of 4096 inputs: ~2860 VALU instructions per wave (PMC), of which
         # ~950 are fused multiply-adds: ~3800 FLOP per lane x 64 lanes / (8 * (513 - ntaps/8)) new input samples
         flops = 3800.0 * 64 / (8 * (513 - (w["ntaps"] + 7) // 8))
+    elif kinfo["name"] == "pfb_dec4_kernel":
+        # the same eight column transforms against two spectrum sets + two inverses: ~3850 VALU instructions per wave and segment
+        flops = 5100.0 * 64 / (8 * (513 - (w["ntaps"] + 4 + 7) // 8))
     elif kinfo["name"] == "chan_uniform_kernel":
         # per lane and wave tile (16 output times x 64 channels = 1024 input samples per wave): 64 complex
         # MACs (512), radix-16 (~200), twiddles (~90), radix-4 across the quad (~220), per-channel
