@@ -458,7 +458,8 @@ def run_workload(name: str, args, ctx) -> dict:
             "halo_samples": H if world > 1 else 0,
             "partition": ("single stream" + (" (self-ring RCCL exchange every step)" if self_ring else "")) if world == 1
                          else f"block-cyclic time chunks over {world} ranks, ring halo over RCCL "
-                              + ("(torch.distributed p2p)" if os.environ.get("QDSP_RING_TRANSPORT", "c") == "torch" else "(qdsp_hip_ring_*, the C ABI)"),
+                              + ("(qdsp_hip_ring_*, the C ABI)" if getattr(ring, "_ring", None) is not None else
+                                 "(gloo, ranks sharing one GPU: rehearsal)" if rehearse else "(torch.distributed p2p)"),
             **({"channels": w["nchan"], "out_row_stride": nout + CHAN_ROW_PAD} if is_chan else {}),
         },
         "roofline": {

@@ -200,13 +200,40 @@ class RingStream:
         import os
 
         if self.exchange and transport == "device" and self.device.type == "cuda" and os.environ.get("QDSP_RING_TRANSPORT", "c") != "torch":
-            self._ring = _CRing(self.device.index or 0, self.rank, self.world, self.H * 8, group)
+            self._ring = self._make_c_ring(group)
         if self.exchange and self._ring is None:      # (host transport, or device tensors of a CPU stand-in operator over gloo: the CPU tests)
             z = lambda: torch.zeros(max(self.H, 1), dtype=torch.complex64, device=self.device)  # noqa: E731
             self._recv = [z() for _ in range(self.NBUF)]
             self._zeros = z()
         if self.has_nco and self.world > 1:
             op.advance(self.rank * self.n)
+
+    def _make_c_ring(self, group):
+        """The C ring, or None when it cannot be had on EVERY rank (then all ranks take torch.distributed's p2p path together: a ring
+        with one end on another transport would hang).  One rank alone has nobody to agree with: the error is the caller's."""
+        import sys
+
+        import torch
+
+        ring, err = None, None
+        try:
+            ring = _CRing(self.device.index or 0, self.rank, self.world, self.H * 8, group)
+        except Exception as e:  # noqa: BLE001
+            if self.world == 1:
+                raise
+            err = e
+        if self.world > 1:
+            import torch.distributed as dist
+
+            ok = torch.tensor([0 if ring is None else 1], dtype=torch.int32, device=self.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if int(ok.item()) == 0:
+                if ring is not None:
+                    ring.close()
+                    ring = None
+                print(f"qdsp_amd.sharding: rank {self.rank}: the C ring is not available on every rank ({err!r}); "
+                      "halos travel through torch.distributed send / recv instead", file=sys.stderr, flush=True)
+        return ring
 
     # -- the exchange -------------------------------------------------------------------------
     def _post(self, x):
