@@ -20,7 +20,7 @@ namespace qk {
     X(MF_TASK_MAX) X(NO_ANY_POLICY) X(NO_CHAN_BATCH) X(NO_FFT1K) X(NO_FFT1K_REAL) X(NO_FIR_LAT) X(NO_LM) \
     X(NO_LM_SMALL_CALL_RULE) X(NO_MF) X(NO_MF_BATCH) X(NO_NCO_TABLES) X(NO_PFB) X(NO_PFB4) X(NO_RAW_CARRY) X(NO_RM) X(NO_RM_SMALL) \
     X(NO_WIN) X(NO_WIN_BIG_CALL_RULE) X(NO_WIN_SMALL_CALL_RULE) X(NT) X(PFB_MIN_COUNT) X(PFB_WG_PER_CU) X(R) X(RM_MIN_COUNT) X(RM_MIN_INTERP) \
-    X(RM_NT) X(RM_WAVES_PER_SIMD) X(SYNC_SPIN_US) X(WIN_MAX_TAPS) X(WIN_R) X(XLATE_WG_PER_CU)
+    X(RM_WAVES_PER_SIMD) X(SYNC_SPIN_US) X(WIN_MAX_TAPS) X(WIN_R) X(XLATE_WG_PER_CU)
 
 enum Knob {
 #define X(n) K_##n,

@@ -1559,7 +1559,6 @@ int launch_rm(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d_
     if (nwaves > a.ntiles) nwaves = a.ntiles;
     if (nwaves < 1) nwaves = 1;
     a.nwaves = nwaves;
-    a.nts = qk::knob(qk::K_RM_NT, 0);
     if (e->rotate) {
         a.phase0 = e->phase;
         a.dphase = e->dphase;

@@ -8,6 +8,8 @@ namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 }
 
+// (Round 3 also tried two tiles in flight per wave instead of one -- 24 more VGPRs, still three waves per SIMD: 147/160 0.4466 -> 0.4493 ms per
+// 2^27 samples, the other ratios 2-4 % slower -- and four waves per SIMD (128 VGPRs: 2-13 spilled).  Bytes in flight are not what it waits for.)
 template <bool ROT> __global__ __launch_bounds__(256, 3) void resamp_mfma_kernel(const RmArgs a) {
     constexpr int NE = kRmNE, GM = kRmMaxGrp;
     const int t = threadIdx.x, l = t & 63;
@@ -154,17 +156,11 @@ template <bool ROT> __global__ __launch_bounds__(256, 3) void resamp_mfma_kernel
                         if (o + 3 < L && n + 3 < a.nout) {
                             // (round 3: the lane's 32 contiguous bytes as two 16-byte stores at 8-byte alignment -- odd L puts odd periods on
                             // odd samples -- measured 0.451 against 0.442 ms for these four 8-byte ones on 147/160: not kept)
-                            if (a.nts) {
-                                typedef float v2nt __attribute__((ext_vector_type(2)));
-                                v2nt* d = reinterpret_cast<v2nt*>(dst);
-#pragma unroll
-                                for (int v = 0; v < 4; v++) __builtin_nontemporal_store((v2nt){zr[v], zi[v]}, d + v);
-                            } else {
-                                dst[0] = make_float2(zr[0], zi[0]);
-                                dst[1] = make_float2(zr[1], zi[1]);
-                                dst[2] = make_float2(zr[2], zi[2]);
-                                dst[3] = make_float2(zr[3], zi[3]);
-                            }
+                            // (... and written non-temporally 0.601 against 0.435 ms: 8-byte pieces 32 bytes apart do not combine on that path)
+                            dst[0] = make_float2(zr[0], zi[0]);
+                            dst[1] = make_float2(zr[1], zi[1]);
+                            dst[2] = make_float2(zr[2], zi[2]);
+                            dst[3] = make_float2(zr[3], zi[3]);
                         } else {
 #pragma unroll
                             for (int v = 0; v < 4; v++)

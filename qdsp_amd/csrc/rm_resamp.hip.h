@@ -56,7 +56,6 @@ struct RmArgs {
     double2 rot_step;             // exp(j 2pi nwaves 4 G M dphase): a wave's step from one of its tiles to the next
     float2 rot_k[kRmNE];          // exp(j 2pi 64 e dphase)
     float gm1;
-    int nts;                      // non-temporal output stores (QDSP_HIP_RM_NT)
 };
 
 inline size_t rm_lds_bytes(int ngrp, int KB, int G, int pitch) {
