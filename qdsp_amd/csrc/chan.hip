@@ -35,6 +35,9 @@
 // (scripts/micro/write_streams.hip: the same loads and stores without any arithmetic take the same
 // 0.43 ms per 2^27 samples; a plain 1 GiB copy takes 0.37-0.41 ms, scripts/micro/copy_bw.hip).
 #include "chan.hip.h"
+#ifndef QDSP_HIP_DIAG
+#define QDSP_HIP_DIAG 0
+#endif
 #include "cfft.hip.h"
 #include "cpk.hip.h"
 #include "ldsdma.hip.h"
@@ -363,6 +366,7 @@ int launch_chan_uniform(const ChanArgs& a, int grid, hipStream_t stream) {
             else hipLaunchKernelGGL((chan_uniform_kernel<false, m, 0>), dim3(grid), dim3(256), lds_bytes, stream, a);        \
         }                                                                                                              \
         break;
+#if QDSP_HIP_DIAG   // (make DIAG=1: the ablation builds behind profiles/r03_chan_tuning.txt)
     if (a.abl && a.M == 8 && !a.inv && a.Q == 4) {
         if (a.abl == 1) hipLaunchKernelGGL((chan_uniform_kernel<false, 8, 4, 1>), dim3(grid), dim3(256), lds_bytes, stream, a);
         else if (a.abl == 2) hipLaunchKernelGGL((chan_uniform_kernel<false, 8, 4, 2>), dim3(grid), dim3(256), lds_bytes, stream, a);
@@ -376,6 +380,7 @@ int launch_chan_uniform(const ChanArgs& a, int grid, hipStream_t stream) {
         const hipError_t e = hipGetLastError();
         return e == hipSuccess ? 0 : -(int)e;
     }
+#endif
     switch (a.M) {
         QK_CHAN(64) QK_CHAN(32) QK_CHAN(16) QK_CHAN(8)
         default: return -1;

@@ -40,6 +40,9 @@
 // (2 waves/SIMD); scalar f32 VALU ops issue at the same FLOP rate on gfx950's 32-wide
 // SIMDs once two waves share a SIMD, need no shuffles, and fit in 126 VGPRs (4 waves/SIMD).
 #include "fft_fir.hip.h"
+#ifndef QDSP_HIP_DIAG
+#define QDSP_HIP_DIAG 0
+#endif
 #include "cfft.hip.h"
 #include "cpk.hip.h"
 #include "ldsdma.hip.h"
@@ -1048,13 +1051,16 @@ int launch_fir_fft(const FftArgs& a, int grid, hipStream_t stream) {
     const bool r = a.rot != 0;
     switch (a.dec) {
         case 1:  // FIR, or any-decimation resampler / VFO through the strided store (a.decm)
+#if QDSP_HIP_DIAG   // (make DIAG=1: the ablation builds and the in-kernel time stamps behind profiles/r03_ablate_*.txt, r03_stamp_*.txt)
             if (a.dma == 2 && a.abl == 1) hipLaunchKernelGGL((fir_fft_dmapk_kernel<false, 1>), dim3(grid), dim3(kFftNT), 0, stream, a);
             else if (a.dma == 2 && a.abl == 2) hipLaunchKernelGGL((fir_fft_dmapk_kernel<false, 2>), dim3(grid), dim3(kFftNT), 0, stream, a);
             else if (a.dma == 2 && a.abl == 4) hipLaunchKernelGGL((fir_fft_dmapk_kernel<false, 4>), dim3(grid), dim3(kFftNT), 0, stream, a);
             else if (a.dma == 2 && a.abl == 6) hipLaunchKernelGGL((fir_fft_dmapk_kernel<false, 6>), dim3(grid), dim3(kFftNT), 0, stream, a);
             else if (a.dma == 2 && a.abl == 7) hipLaunchKernelGGL((fir_fft_dmapk_kernel<false, 7>), dim3(grid), dim3(kFftNT), 0, stream, a);
             else if (a.dma == 2 && a.stamps) hipLaunchKernelGGL(fir_fft_dmapk_kernel<true>, dim3(grid), dim3(kFftNT), 0, stream, a);
-            else if (a.dma == 2) hipLaunchKernelGGL(fir_fft_dmapk_kernel<false>, dim3(grid), dim3(kFftNT), 0, stream, a);
+            else
+#endif
+            if (a.dma == 2) hipLaunchKernelGGL(fir_fft_dmapk_kernel<false>, dim3(grid), dim3(kFftNT), 0, stream, a);
             else if (a.dma) hipLaunchKernelGGL(fir_fft_dma_kernel, dim3(grid), dim3(kFftNT), 0, stream, a);
             else if (a.real2) hipLaunchKernelGGL((fir_fft_kernel<1, false, true>), dim3(grid), dim3(kFftNT), 0, stream, a);
             else if (r) hipLaunchKernelGGL((fir_fft_kernel<1, true>), dim3(grid), dim3(kFftNT), 0, stream, a);

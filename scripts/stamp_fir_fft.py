@@ -4,6 +4,7 @@ s_memtime ticks per phase of its segment loop; this script runs it on the bench 
 
     python scripts/stamp_fir_fft.py [--log2n 27]
 
+(Needs the diagnostic build of the library: make -C qdsp_amd/csrc -B DIAG=1.)
 The device buffer is handed over through QDSP_HIP_FFT_STAMPS=<device pointer> (read by launch_fft only for this purpose)."""
 import argparse
 import os
