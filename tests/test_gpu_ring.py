@@ -27,10 +27,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_ranks(case, backend, world, outdir, steps, n):
+def _run_ranks(case, backend, world, outdir, steps, n, extra_env=None):
     port = str(_free_port())
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(extra_env or {})
     procs = [subprocess.Popen([sys.executable, WORKER, case, backend, str(world), str(r), port, str(outdir), str(steps), str(n)],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
@@ -129,13 +130,16 @@ def test_channelizer_64_on_two_ranks(tmp_path):
             assert rel_rms(y[c][k * per:k * per + 8], want[k * per:k * per + 8]) < 2e-5, (c, k)
 
 
+@pytest.mark.parametrize("transport", ["c", "torch"])
 @pytest.mark.parametrize("case", ["fir256", "xlate_fir_decim8"])
-def test_rccl_self_ring_matches_unsharded_oracle(tmp_path, case):
+def test_rccl_self_ring_matches_unsharded_oracle(tmp_path, case, transport):
     """One rank as its own ring neighbour over real RCCL: the halo of step s+1 is this rank's own tail of step s, sent and
     received by the library's C ring (qdsp_hip_ring_post / _complete: ncclSend + ncclRecv on the ring's own stream) and
-    prefetched under the kernel -- the transport the 8-GPU run uses, with world = 1 so the result is the plain unsharded stream."""
+    prefetched under the kernel -- the transport the 8-GPU run uses, with world = 1 so the result is the plain unsharded stream.
+    "torch": the same exchange through torch.distributed's send / recv (QDSP_RING_TRANSPORT=torch), the path all ranks fall back
+    to together when the C ring cannot be had on every one of them."""
     steps, n = 4, 1 << 17
-    _run_ranks(case, "nccl", 1, tmp_path, steps, n)
+    _run_ranks(case, "nccl", 1, tmp_path, steps, n, {"QDSP_RING_TRANSPORT": transport})
     y = np.concatenate(_collect(case, tmp_path, 1, steps))
     x = O.synth_iq(0, steps * n, seed=4321)
     want = _expected(case, x)
