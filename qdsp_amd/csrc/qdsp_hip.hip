@@ -1350,6 +1350,14 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
     a.nout = nout;
     a.H = e->H;
     a.dec = fft_dec(e);
+    // Decimate by 2 on chip-filling calls (round 3, profiles/r03_tune_dec2.txt): the pruned inverse saves one radix-16 pass on half the
+    // lanes but runs its last two passes on 128 of them behind two more barriers and stores 8 bytes per lane; the full inverse with every
+    // other output kept is ahead from 2^25 samples (0.115 against 0.128 ms; 0.400 against 0.491 at 2^27), with the NCO from 2^26
+    // (0.247 / 0.254; 0.472 / 0.505).  Decimations 4, 8, 16 keep the pruned form at every size (0.33 / 0.30 / 0.29 against 0.38 / 0.37 / 0.39).
+    if (a.dec == 2 && e->ch == 2) {
+        const int lim = qk::knob(qk::K_FFT_PRUNE2_MAX_COUNT, -1);
+        if (count >= (lim >= 0 ? (int64_t)lim : (int64_t)(e->rotate ? 1 << 26 : 1 << 25))) a.dec = 1;
+    }
     a.rot = e->rotate ? 1 : 0;
     a.decm = 1;
     if (a.dec == 1 && e->kind != KIND_FIR) {

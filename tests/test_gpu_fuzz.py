@@ -69,7 +69,8 @@ DIRECTED = [
     ("res", 1, 8, 256, True, [((1 << 24) + 16, "pfb_dec8_kernel")]),
     # round 3's big-call rule: past the measured crossovers the strided-window decimator hands chip-filling calls to the overlap-save forms
     ("res", 1, 8, 128, True, [(3_000_000, "decim_win_kernel"), ((1 << 24) + 8, "pfb_dec8_kernel")]),
-    ("res", 1, 2, 128, False, [(3_000_000, "decim_win_kernel"), ((1 << 24) + 2, "fir_fft_kernel")]),
+    # (... and decimate-by-2 changes form inside fir_fft_kernel at 2^25 samples: pruned inverse below, full inverse + every other output kept above)
+    ("res", 1, 2, 128, False, [(3_000_000, "decim_win_kernel"), ((1 << 24) + 2, "fir_fft_kernel"), ((1 << 25) + 6, "fir_fft_kernel")]),
     ("res", 1, 4, 63, False, [(200_000, "decim_win_kernel")]),
     ("res", 1, 4, 160, True, [(2_000_000, "decim_win_kernel"), ((1 << 26) + 4, "pfb_dec4_kernel")]),
     ("res", 1, 16, 129, True, [(300_000, "decim_mfma_kernel")]),

@@ -350,6 +350,35 @@ def test_polyphase_overlap_save_decimator_vs_oracle(ops, monkeypatch, ntaps, rot
     assert np.allclose(op.get_history(), op2.get_history(), rtol=0, atol=2e-6)       # same (rotated) history handed over
 
 
+@pytest.mark.parametrize("rot", [False, True])
+@pytest.mark.parametrize("ntaps", [24, 255, 700])
+def test_decimate_by_two_both_overlap_save_forms(ops, monkeypatch, ntaps, rot):
+    """Decimate-by-2 has two overlap-save forms in fir_fft_kernel: the pruned inverse (calls below 2^25 / 2^26 samples) and the full
+    inverse with every other output kept (above: faster there, profiles/r03_tune_dec2.txt).  The size rule is lowered to 100 000 samples
+    so that one ragged stream crosses it in both directions; both forms against the FP64 oracle, state carried across the switch."""
+    monkeypatch.setenv("QDSP_HIP_FFT_PRUNE2_MAX_COUNT", "100000")
+    monkeypatch.setenv("QDSP_HIP_NO_FFT1K", "1")
+    taps = O.lowpass_taps_f64(ntaps, 0.24).astype(np.float32)
+    x = O.synth_iq(0, 700_000, seed=77 + ntaps)
+    cuts = [0, 150_001, 150_001 + 40_000, 400_000, 400_000 + 99_998, 700_000]
+    inc = ops.phase_delta(1.0, 0.1234)
+    op = ops.Vfo(taps, 1, 2, inc, max_block=0) if rot else ops.Resampler(taps, 1, 2, max_block=0)
+    op.set_mode(op.FFT)
+    y = np.concatenate([op.process(dev(x[a:b])).cpu().numpy() for a, b in zip(cuts, cuts[1:])])
+    assert kname(op) == "fir_fft_kernel"
+    rs = O.Resampler(taps, 1, 2, acc=O.ACC_F64)
+    xl = O.Xlator(1.0, 0.1234, exact=True, volk_gain=True)
+    want = np.concatenate([rs.process(xl.process(x[a:b]) if rot else x[a:b]) for a, b in zip(cuts, cuts[1:])])
+    assert len(y) == len(want) and rel_rms(y, want) < TOL_FFT
+    # the same stream with the rule off (pruned inverse throughout): one operator, two factorizations of its last passes
+    monkeypatch.setenv("QDSP_HIP_FFT_PRUNE2_MAX_COUNT", str(2**31 - 1))
+    op2 = ops.Vfo(taps, 1, 2, inc, max_block=0) if rot else ops.Resampler(taps, 1, 2, max_block=0)
+    op2.set_mode(op2.FFT)
+    y2 = np.concatenate([op2.process(dev(x[a:b])).cpu().numpy() for a, b in zip(cuts, cuts[1:])])
+    assert rel_rms(y, y2) < 2e-6
+    assert np.allclose(op.get_history(), op2.get_history(), rtol=0, atol=2e-6)
+
+
 def test_polyphase_overlap_save_decimator_switches_forms_mid_stream(ops, gold, monkeypatch):
     """A stream whose calls alternate between the polyphase kernel (big calls) and the direct / 4096-point forms (small
     calls): the history each leaves -- rotated, plus the raw side copy of the overlap-save forms -- serves the next."""
