@@ -1662,6 +1662,7 @@ bool win_yields_to_fft_big(const Engine* e, int64_t count) {
     if (M == 2) return count >= (1 << 24) && P >= 104;
     if (M == 3 || M == 4) return count >= (1 << 26) && P >= 104;
     if (M == 5) return count >= (1 << 26) && !e->rotate && P >= 152;
+    if (M == 6) return count >= (1 << 26) && !e->rotate && P >= 208;      // (256 taps: 0.455 against 0.37 ms; level at 192)
     return false;
 }
 
