@@ -111,6 +111,7 @@ struct Engine {
     unsigned long long fft_dphase = 0;   // NCO increment d_fft_H was built for (fused VFO), 0 otherwise
     float* d_taps_rm = nullptr;    // rational MFMA resampler (rm_resamp.hip.h): A operands + first columns, built with the taps
     int rm_ngrp = 0, rm_KB = 0, rm_ext = 0, rm_pitch = 0, rm_G = 0, rm_J = 1, rm_qpb = 1;
+    bool rm_big_only = false;     // plan admitted by the round-3 extension of the rule: chip-filling calls only (rm_min_count)
     float* d_taps_mf = nullptr;    // MFMA decimator (mf_dec.hip.h): [2 KJ][64] A operands, built with the taps
     int mf_KJ = 0, mf_QS = 1, mf_keep2 = 0;
     // polyphase overlap-save decimate-by-8 (pfb_dec.hip.h): column spectra + twiddles, built for (pfb_ntaps, pfb_dphase)

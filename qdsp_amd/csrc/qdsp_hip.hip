@@ -263,6 +263,25 @@ int upload_taps(Engine* e, const float* taps, int ntaps) {
     bool rm_wanted = e->L >= qk::knob(qk::K_RM_MIN_INTERP, 33) || (e->M == 1 && e->L >= 6 && !use_lm(e));
     if (use_lm(e) && e->L >= 2 && !qk::knob(qk::K_NO_RM_SMALL, 0))
         rm_wanted = rm_wanted || (e->M >= 5 && e->P <= (e->L == 10 ? 36 : 24)) || (e->L == 10 && e->M >= 3 && e->P <= 24);
+    // Round 3 (scripts/sweep_rm_grid.py, profiles/r03_sweep_rm_grid.txt: 130 ratios x 8-32 taps per phase on 2^26-sample calls): the block
+    // form is ahead of the general direct kernel on nearly every ratio from 16 taps per phase on (x 0.5-0.9 of its time; at 8 taps per
+    // phase anything from x 0.7 to x 1.4), and of resamp_lm_kernel on its decimating side up to 32 taps per phase (3/8: x 0.49, 5/8:
+    // x 0.53, 4/7: x 0.61) and on 4/3, 5/3, 5/4 from 16 taps per phase (x 0.73-0.97); resamp_lm_kernel keeps decimations 1-2,
+    // 2/3 and 3/4 (x 1.05-2.2).  These plans only serve chip-filling calls (rm_min_count): their reference-sized calls stay where
+    // round 2's survey put them.
+    e->rm_big_only = false;
+    if (!rm_wanted && e->L >= 2 && !qk::knob(qk::K_NO_RM_EXT, 0)) {
+        bool ext;
+        if (use_lm(e))
+            ext = (e->M >= 5 && e->P <= 36) || (e->L == 10 && e->M >= 3 && e->P <= 36) ||
+                  ((e->M == 3 || e->M == 4) && e->L >= 4 && e->P >= 16 && e->P <= 32);      // (3/4: x 0.90-0.94 at 16 / 24 taps per phase, x 1.2 at 20: left alone)
+        else
+            ext = e->M >= 2 && e->P >= 16;
+        if (ext) {
+            rm_wanted = true;
+            e->rm_big_only = true;
+        }
+    }
     if (e->ch == 2 && rm_wanted && e->has_filter && e->kind != KIND_FIR && !use_core(e) && e->M < (1 << 16)) {
         const int L0 = e->L, M0 = e->M, P = e->P;
         for (int J = 1; J <= 64 && !e->rm_ngrp; J++) {
@@ -1676,6 +1695,7 @@ int64_t mf_min_count(const Engine* e) {
 int64_t rm_min_count(const Engine* e) {
     const int v = qk::knob(qk::K_RM_MIN_COUNT, -1);
     if (v >= 0) return v;
+    if (e->rm_big_only) return 1 << 22;
     return e->L >= 33 ? 6 << 20 : 0;
 }
 
