@@ -275,8 +275,8 @@ int upload_taps(Engine* e, const float* taps, int ntaps) {
         if (use_lm(e))
             ext = (e->M >= 5 && e->P <= 36) || (e->L == 10 && e->M >= 3 && e->P <= 36) ||
                   ((e->M == 3 || e->M == 4) && e->L >= 4 && e->P >= 16 && e->P <= 32);      // (3/4: x 0.90-0.94 at 16 / 24 taps per phase, x 1.2 at 20: left alone)
-        else
-            ext = e->M >= 2 && e->P >= 16;
+        else      // (7/6, 9/7, 9/8 at 16 taps per phase: x 1.04-1.17, the only losers of that column)
+            ext = e->M >= 2 && e->P >= 16 && !(e->P < 20 && ((e->L == 7 && e->M == 6) || (e->L == 9 && (e->M == 7 || e->M == 8))));
         if (ext) {
             rm_wanted = true;
             e->rm_big_only = true;
@@ -1695,7 +1695,9 @@ int64_t mf_min_count(const Engine* e) {
 int64_t rm_min_count(const Engine* e) {
     const int v = qk::knob(qk::K_RM_MIN_COUNT, -1);
     if (v >= 0) return v;
-    if (e->rm_big_only) return 1 << 22;
+    // (profiles/r03_sweep_rm_grid.txt, second part: decimating ratios are ahead from 2^22 input samples; interpolating ones -- whose work follows
+    // the OUTPUT count -- only from ~10 million inputs: 8/3 at 6.3 million x 1.2, at 12.6 million x 0.9)
+    if (e->rm_big_only) return e->L > e->M ? 12 << 20 : 1 << 22;
     return e->L >= 33 ? 6 << 20 : 0;
 }
 

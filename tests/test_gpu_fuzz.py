@@ -79,8 +79,8 @@ DIRECTED = [
     ("res", 10, 7, 160, False, [(100_000, "resamp_mfma_kernel")]),
     ("res", 7, 5, 140, True, [(100_000, "resamp_any_kernel")]),
     # round 3: from 16 taps per phase on, chip-filling calls of the small ratios go to the block form on the MFMA units as well
-    ("res", 7, 5, 7 * 24 - 3, True, [(200_000, "resamp_any_kernel"), (4_200_005, "resamp_mfma_kernel")]),
-    ("res", 4, 3, 4 * 20 - 3, False, [(300_000, "resamp_lm_kernel"), (4_200_003, "resamp_mfma_kernel")]),
+    ("res", 7, 5, 7 * 24 - 3, True, [(200_000, "resamp_any_kernel"), (13_000_005, "resamp_mfma_kernel")]),
+    ("res", 4, 3, 4 * 20 - 3, False, [(300_000, "resamp_lm_kernel"), (13_000_003, "resamp_mfma_kernel")]),
     ("res", 147, 160, 147 * 16 - 3, False, [(200_000, "resamp_any_kernel"), (6_400_000, "resamp_mfma_kernel")]),
 ]
 
