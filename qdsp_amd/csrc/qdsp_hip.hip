@@ -172,6 +172,7 @@ bool mf_plan(const Engine* e, int* KJ, int* QS, int* keep2) {
     if (Q > qk::kMfMaxQ || (Q > 16 && qk::knob(qk::K_MF_NO_QS2, 0))) return false;
     if (Q > 16 && M < 12) return false;      // (two tap sets on rows of < 12 samples: 0.44 ms per 2^27 at decimation 10 against 0.36 overlap-save, round 3)
     if (M < 14 && P < 12 * M) return false;
+    if (P < M) return false;                          // (fewer taps than the decimation: most of each row meets no tap, the general kernel is 5-16 % ahead)
     if (use_win(e) && P < 6 * M) return false;
     *KJ = (Mk + 7) / 8;
     *QS = Q > 16 ? 2 : 1;
