@@ -135,6 +135,10 @@ int win_R(int M, int P) {
     if (M == 8) return P > 63 ? 2 : 1;
     return 1;
 }
+int win_limit(int M) {
+    static const int limit[17] = {0, 7, 150, 150, 160, 200, 256, 160, 200, 0, 192, 0, 224, 0, 0, 0, 256};
+    return M >= 0 && M <= 16 ? limit[M] : 0;
+}
 bool use_win(const Engine* e) {
     if (!e->has_filter || e->L != 1) return false;
     const int M = e->M;
@@ -142,8 +146,7 @@ bool use_win(const Engine* e) {
     // where the overlap-save forms take over (per 2^26 samples they run 0.25 / 0.19 / 0.15 / 0.17 ms at decimation
     // 2 / 4 / 8 / 16 -- pruned inverse -- and 0.20-0.21 ms at every other decimation: full inverse, strided store)
     // ([1] = FIR<T> and equal-rate resamplers below the overlap-save threshold: 0.22 ms against 0.25 de-interleaved)
-    static const int limit[17] = {0, 7, 150, 150, 160, 200, 256, 160, 200, 0, 192, 0, 224, 0, 0, 0, 256};
-    const int max_taps = qk::knob(qk::K_WIN_MAX_TAPS, limit[M]);
+    const int max_taps = qk::knob(qk::K_WIN_MAX_TAPS, win_limit(M));
     return e->P <= max_taps && qk::knob(qk::K_NO_WIN, 0) == 0;
 }
 
@@ -850,8 +853,20 @@ bool fft_eligible(const Engine* e, int64_t count) {
     // (decimate-by-8, 256 taps: 324 vs 321 Gs/s)
     int min_taps;
     if (e->ch == 1) {
-        min_taps = qk::knob(qk::K_FFT_MIN_TAPS_REAL, 96);
-        if (e->M > 1 && min_taps < 32 * e->M) min_taps = 32 * e->M;
+        // Chip-filling calls (round 3, profiles/r03_sweep_real.txt, 2^27 real samples): the overlap-save form costs 0.23-0.28 ms at any
+        // length; against it the direct form stays ahead to 64 taps (FIR), 128-192 taps at decimation 2-5, 384 at decimation 8, the
+        // strided-window kernel to its own limits at decimation 10 / 12 / 16 -- and nothing else serves the decimations in between:
+        // round 2's 32 taps per unit of decimation left decimate-by-10 with 256 taps on the general kernel at 0.56 ms (now 0.26).
+        const bool big = count >= (1 << 22) && !qk::knob(qk::K_NO_REAL_BIG_CALL_RULE, 0);
+        min_taps = qk::knob(qk::K_FFT_MIN_TAPS_REAL, big && e->M == 1 ? 64 : 96);
+        if (e->M > 1) {
+            int need = 32 * e->M;
+            if (big) {
+                static const int t[9] = {0, 0, 144, 128, 192, 176, 224, 224, 384};
+                need = e->M <= 8 ? t[e->M] : win_limit(e->M) ? win_limit(e->M) + 1 : 128;
+            }
+            if (min_taps < need) min_taps = need;
+        }
     } else if (e->M == 1 && e->kind != KIND_FIR) {
         // equal-rate resampler / pure xlating FIR: full inverse + per-element store (0.52 ms per 2^27 samples)
         // against the tile-per-block direct form (0.51 ms at 7 taps, 0.63 at 63)
@@ -1686,6 +1701,14 @@ bool win_yields_to_fft_big(const Engine* e, int64_t count) {
     return false;
 }
 
+// Real data, chip-filling calls (same sweep): the de-interleaved direct kernel moves 4-byte samples at decimation 2 / 4 faster than the
+// strided window does (decimation 2: 0.14-0.25 against 0.18-0.36 ms at 32-128 taps; decimation 4: 0.12-0.18 against 0.15-0.23), and from
+// ~100 taps at decimation 5 / 8.
+bool real_win_yields_to_core_big(const Engine* e, int64_t count) {
+    if (e->ch != 1 || count < (1 << 22) || !use_core(e) || qk::knob(qk::K_NO_REAL_BIG_CALL_RULE, 0)) return false;
+    return e->M == 2 || e->M == 4 || (e->M == 5 && e->P >= 96) || (e->M == 8 && e->P >= 128);
+}
+
 int64_t mf_min_count(const Engine* e) {
     const int v = qk::knob(qk::K_MF_MIN_COUNT, -1);
     if (v >= 0) return v;
@@ -1724,7 +1747,7 @@ int64_t process_dev(Engine* e, const void* d_in, int64_t count, void* d_out, voi
         rc = launch_fft(e, d_in, count, nout, d_out, s);
         if (rc == 0) e->cur ^= 1;
         took_fft = true;
-    } else if (use_win(e) && e->d_taps_lm && mode_of(e) == 0) {
+    } else if (use_win(e) && e->d_taps_lm && mode_of(e) == 0 && !real_win_yields_to_core_big(e, count)) {
         // AUTO only: QDSP_HIP_FIR_DIRECT keeps meaning fir_core_kernel (the form the bit-exactness tests pin),
         // QDSP_HIP_FIR_FFT the overlap-save kernels
         if (e->ch == 2) rc = e->rotate ? launch_win<2, true>(e, d_in, count, nout, d_out, s) : launch_win<2, false>(e, d_in, count, nout, d_out, s);

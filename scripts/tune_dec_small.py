@@ -22,13 +22,16 @@ def lowpass(ntaps, fc):
     return (2 * fc * np.sinc(2 * fc * n) * np.blackman(ntaps)).astype(np.float32)
 
 
-def run(x, M, ntaps, nco, setting):
+def run(x, M, ntaps, nco, setting, real=False):
     for kv in filter(None, setting.split(",")):
         k, v = kv.split("=")
         capi.setenv(k, v)
     taps = lowpass(ntaps, 0.45 / M)
-    op = ops.Vfo(taps, 1, M, ops.phase_delta(1.0, 0.1234), max_block=0) if nco else ops.Resampler(taps, 1, M, max_block=0)
-    out = torch.empty(x.numel() // M + 8, dtype=torch.complex64, device="cuda")
+    if real:
+        op = ops.Resampler(taps, 1, M, complex_data=False, max_block=0) if M > 1 else ops.Fir(taps, complex_data=False, max_block=0)
+    else:
+        op = ops.Vfo(taps, 1, M, ops.phase_delta(1.0, 0.1234), max_block=0) if nco else ops.Resampler(taps, 1, M, max_block=0)
+    out = torch.empty(x.numel() // M + 8, dtype=x.dtype, device="cuda")
     op.process(x, out)
     for _ in range(3):
         op.time_dev(x, out, 20)
@@ -47,18 +50,19 @@ def main():
     ap.add_argument("--taps", default="128,256,512")
     ap.add_argument("--alts", default="QDSP_HIP_NO_MF=1", help="semicolon-separated alternative settings next to the defaults")
     ap.add_argument("--no-nco", action="store_true")
+    ap.add_argument("--real", action="store_true", help="PolyphaseResampler<float> (4 + 4/M bytes per sample)")
     a = ap.parse_args()
     n = 1 << a.log2n
-    x = ops.synth_iq(n, seed=7)
+    x = torch.randn(n, device="cuda") if a.real else ops.synth_iq(n, seed=7)
     print(f"# kernel ms per 2^{a.log2n} input samples (min of 5 x 20 launches), algorithmic bytes (8 + 8/M) per sample, fraction of 8 TB/s")
     for M in [int(v) for v in a.decims.split(",")]:
         for ntaps in [int(v) for v in a.taps.split(",")]:
-            for nco in ((False,) if a.no_nco else (False, True)):
+            for nco in ((False,) if a.no_nco or a.real else (False, True)):
                 row = []
                 for setting in [""] + a.alts.split(";"):
-                    t, name = run(x, M, ntaps, nco, setting)
+                    t, name = run(x, M, ntaps, nco, setting, a.real)
                     row.append((t, name, setting))
-                cells = "   ".join(f"{s or 'default':18s} {nm:20s} {t:.4f} ms = {(8 + 8 / M) * n / t / 1e6 / 8000:.3f}" for t, nm, s in row)
+                cells = "   ".join(f"{s or 'default':18s} {nm:20s} {t:.4f} ms = {(0.5 if a.real else 1.0) * (8 + 8 / M) * n / t / 1e6 / 8000:.3f}" for t, nm, s in row)
                 print(f"decimate by {M:2d}, {ntaps:3d} taps{', NCO' if nco else '     '}: {cells}", flush=True)
 
 
