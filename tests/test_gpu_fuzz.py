@@ -113,6 +113,36 @@ def test_directed_plans_default_thresholds(ops, plan):
         _SEEN.add(name)
 
 
+REAL_DIRECTED = [
+    # (decimation, taps, call sizes and the kernel family each must land on): PolyphaseResampler<float> / FIR<float> on both sides of the
+    # chip-filling rule of round 3 (2^22 samples)
+    (10, 256, [(1_000_000, "resamp_any_kernel"), ((1 << 22) + 10, "fir_fft1k_kernel")]),      # (the one-wave overlap-save form up to 2^26; was the general kernel at every size)
+    (2, 64, [(1_000_000, "decim_win_kernel"), ((1 << 22) + 2, "fir_core_kernel")]),
+    (1, 64, [(1_000_000, "fir_core_kernel"), ((1 << 22) + 1, "fir_fft1k_kernel")]),
+]
+
+
+@pytest.mark.parametrize("plan", REAL_DIRECTED, ids=lambda p: f"real_{p[0]}_{p[1]}")
+def test_directed_real_plans_default_thresholds(ops, plan):
+    """Real data (src/dsp/filter.h:58-62, src/dsp/resampling.h:113-118: the float branches) under the shipped thresholds."""
+    M, ntaps, calls = plan
+    assert _no_overrides()
+    taps = _lp(ntaps, 0.45 / M)
+    if M == 1:
+        op, orc = ops.Fir(taps, complex_data=False, max_block=0), O.Fir(taps, complex_data=False, acc=O.ACC_F64)
+    else:
+        op, orc = ops.Resampler(taps, 1, M, complex_data=False, max_block=0), O.Resampler(taps, 1, M, complex_data=False, acc=O.ACC_F64)
+    rng = np.random.default_rng(ntaps + M)
+    for count, family in calls:
+        x = rng.standard_normal(count).astype(np.float32)
+        got = op.process(_dev(x)).cpu().numpy()
+        name = op.last_kernel()["name"]
+        assert name == family, (plan, count, name)
+        want = orc.process(x)
+        assert got.shape == want.shape and _rel(got, want) < TOL, (plan, count, name)
+        _SEEN.add(name)
+
+
 def test_directed_channel_banks_default_thresholds(ops):
     """Splitter -> N x VFO (src/dsp/routing.h:47-57 + src/dsp/vfo.h:19-36): the uniform 64-channel plan, and arbitrary offsets on
     both sides of the batch kernels' work threshold."""
