@@ -1713,6 +1713,9 @@ int64_t mf_min_count(const Engine* e) {
     const int v = qk::knob(qk::K_MF_MIN_COUNT, -1);
     if (v >= 0) return v;
     if (e->mf_keep2) return 1 << 24;
+    // (filters of at most three taps per unit of decimation: two or three tap rows of the operand in use -- the general kernel is 10-25 % ahead at
+    // 2^22 samples, level at 2^24; profiles/r03_sweep_mid.txt)
+    if (e->P <= 3 * e->M) return 8 << 20;
     if (e->mf_QS == 2 || e->mf_KJ > 4) return 3 << 20;
     return 0;
 }
