@@ -268,8 +268,8 @@ int upload_taps(Engine* e, const float* taps, int ntaps) {
     if (use_lm(e) && e->L >= 2 && !qk::knob(qk::K_NO_RM_SMALL, 0))
         rm_wanted = rm_wanted || (e->M >= 5 && e->P <= (e->L == 10 ? 36 : 24)) || (e->L == 10 && e->M >= 3 && e->P <= 24);
     // Round 3 (scripts/sweep_rm_grid.py, profiles/r03_sweep_rm_grid.txt: 130 ratios x 8-32 taps per phase on 2^26-sample calls): the block
-    // form is ahead of the general direct kernel on nearly every ratio from 16 taps per phase on (x 0.5-0.9 of its time; at 8 taps per
-    // phase anything from x 0.7 to x 1.4), and of resamp_lm_kernel on its decimating side up to 32 taps per phase (3/8: x 0.49, 5/8:
+    // form is ahead of the general direct kernel on nearly every ratio from 14 taps per phase on (x 0.5-0.9 of its time; 72 of 79 ratios at
+    // 14 taps per phase, 60 at 12 with losses up to x 1.25, at 8 anything from x 0.7 to x 1.4), and of resamp_lm_kernel on its decimating side up to 32 taps per phase (3/8: x 0.49, 5/8:
     // x 0.53, 4/7: x 0.61) and on 4/3, 5/3, 5/4 from 16 taps per phase (x 0.73-0.97); resamp_lm_kernel keeps decimations 1-2,
     // 2/3 and 3/4 (x 1.05-2.2).  These plans only serve chip-filling calls (rm_min_count): their reference-sized calls stay where
     // round 2's survey put them.
@@ -280,7 +280,7 @@ int upload_taps(Engine* e, const float* taps, int ntaps) {
             ext = (e->M >= 5 && e->P <= 36) || (e->L == 10 && e->M >= 3 && e->P <= 36) ||
                   ((e->M == 3 || e->M == 4) && e->L >= 4 && e->P >= 16 && e->P <= 32);      // (3/4: x 0.90-0.94 at 16 / 24 taps per phase, x 1.2 at 20: left alone)
         else      // (7/6, 9/7, 9/8 at 16 taps per phase: x 1.04-1.17, the only losers of that column)
-            ext = e->M >= 2 && e->P >= 16 && !(e->P < 20 && ((e->L == 7 && e->M == 6) || (e->L == 9 && (e->M == 7 || e->M == 8))));
+            ext = e->M >= 2 && e->P >= 14 && !(e->P < 20 && ((e->L == 7 && e->M == 6) || (e->L == 9 && (e->M == 7 || e->M == 8))));
         if (ext) {
             rm_wanted = true;
             e->rm_big_only = true;

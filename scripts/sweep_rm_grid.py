@@ -43,7 +43,7 @@ for L in ((3, 4, 5, 7, 8, 12, 16, 25) if SMALL else (2, 3, 4, 5, 6, 7, 8, 9, 10,
     for M in ((3, 5, 7, 9, 24) if SMALL else (1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 15, 24, 25, 49)):
         if math.gcd(L, M) != 1:
             continue
-        for tpp in ((16, 32) if SMALL else (8, 16, 24, 32)):
+        for tpp in (tuple(int(v) for v in os.environ["QDSP_SWEEP_TPP"].split(",")) if os.environ.get("QDSP_SWEEP_TPP") else (16, 32) if SMALL else (8, 16, 24, 32)):
             taps = (bench.lowpass_taps(L * tpp - 3, 0.4 / max(L, M)) * L).astype(np.float32)
             nin = N if L <= M else int(N * M / L)
             nin -= nin % M
