@@ -71,18 +71,20 @@ __host__ __device__ constexpr int pos1(int e) { return (e >> 1) + 136 * (e & 1);
 //              real and imaginary parts of its input apart, so TWO consecutive real segments ride one
 //              complex transform as re / im (segment 2b -> re, 2b+1 -> im); loads and stores are 4-byte.
 template <int DEC, bool ROT, bool REAL = false>
-__global__ __launch_bounds__(kFftNT, (DEC == 1 && !ROT && !REAL) ? 4 : 3) void fir_fft_kernel(const FftArgs a) {
+__global__ __launch_bounds__(kFftNT, (DEC == 1 && !REAL) ? 4 : 3) void fir_fft_kernel(const FftArgs a) {
     __shared__ __attribute__((aligned(16))) float2 lds[kFftLdsElems + 16 * 17];
+    // ROT: exp(j 2pi (phase0 + seg0 dphase)) of the workgroup's current segment lives HERE, not in four VGPRs of every lane (round 3: the fused
+    // variants ran 147 VGPRs = three workgroups per CU where the plain FIR has 128 = four; with this and the output phasor formed at the
+    // stores instead of at the loads they fit 128 as well).  Two slots: segment k reads [k & 1], lane 0 leaves segment k+1's in the other.
+    __shared__ double2 s_pb[2];
     float2* tbl = lds + kFftLdsElems;  // pass-B twiddles W256^(lo*k), rows padded to 17
-    const int t = threadIdx.x;
-    const int hi = t >> 4, lo = t & 15;
+    const int t_lane = threadIdx.x, t = t_lane;
     const int H = a.H;
     // Element of the segment this lane owns in passes A / A' (all 16 rows n2 of it).  Lanes l and
     // l+32 of a wave own the adjacent elements 2l', 2l'+1 so that one 16-byte load/store covers
     // both: each lane moves float4s for half the rows and trades halves with v_permlane32_swap.
-    const int te = (t & ~63) | ((t & 31) << 1) | ((t >> 5) & 1);
-    const int half = (t >> 5) & 1;
-    const int pte = pos1(te);
+    const int te_lane = (t & ~63) | ((t & 31) << 1) | ((t >> 5) & 1);
+    const int te = te_lane;
     constexpr int NS = 16 / DEC;       // kept values of n0: 0, DEC, 2*DEC, ...
     constexpr int NACT = 256 / DEC;    // lanes active in the pruned inverse passes
 
@@ -134,17 +136,23 @@ __global__ __launch_bounds__(kFftNT, (DEC == 1 && !ROT && !REAL) ? 4 : 3) void f
     // living in 32 more VGPRs: keeps the kernel at 128 VGPRs = 4 waves/SIMD without spills.
     const int e0 = ((t / NS) * 16 + (t % NS) * DEC) & 255;
     tbl[(t >> 4) * 17 + (t & 15)] = a.TB[t];
-    const float2* tb = tbl + lo * 17;
 
     float2 pl = make_float2(1.0f, 0.0f);   // exp(j 2pi e dphase), e = element of the lane's outputs
-    double2 pb = make_double2(1.0, 0.0);   // exp(j 2pi (phase0 + seg0 dphase)) of the current block
     if (ROT) {
         const double2 p = fx_phasor((unsigned long long)(DEC == 1 ? te : e0) * a.dphase);
         pl = make_float2((float)p.x, (float)p.y);
-        pb = fx_phasor(a.phase0 + (unsigned long long)((long long)blockIdx.x * a.L - a.seg_shift) * a.dphase);
+        if (t == 0) s_pb[0] = fx_phasor(a.phase0 + (unsigned long long)((long long)blockIdx.x * a.L - a.seg_shift) * a.dphase);
     }
+    int seg_parity = 0;
 
     for (int b = blockIdx.x; b < a.nblocks; b += a.nwg) {
+        // (ROT: the lane's element index is made opaque once per segment, so that the 64-bit per-lane addresses built from it are formed here
+        // -- one v_lshl_add_u64 each -- instead of being hoisted out of the loop, held in eight VGPRs and spilled: the fourth workgroup per CU)
+        int t_seg = t_lane;
+        if constexpr (ROT && DEC == 1) asm volatile("" : "+v"(t_seg));
+        const int t = t_seg, hi = t >> 4, lo = t & 15;
+        const int te = (t & ~63) | ((t & 31) << 1) | ((t >> 5) & 1), half = (t >> 5) & 1, pte = pos1(te);
+        const float2* tb = tbl + lo * 17;
         const long long seg0 = (long long)(REAL ? 2 * b : b) * a.L - a.seg_shift;  // stream position of element 0
         const long long segB = seg0 + a.L;                         // REAL: the second segment of the pair
         const bool interior = seg0 >= 0 && (REAL ? segB : seg0) + kFftN <= a.count;
@@ -224,9 +232,16 @@ __global__ __launch_bounds__(kFftNT, (DEC == 1 && !ROT && !REAL) ? 4 : 3) void f
                     if (nohist || seg0 + n2 * 256 + te >= 0) v[n2] = make_float2(v[n2].x * gg, v[n2].y * gg);   // (history carries its gain)
                 }
             }
-            q = cmulc<false>(make_float2((float)pb.x, (float)pb.y), pl);
-            pb = dcmul(pb, a.rot_step);
         }
+        // the output phasor of this lane for this segment, formed where the stores begin (the segment's barriers lie between lane 0's
+        // write of a slot and every read of it)
+        auto make_q = [&]() {
+            if (!ROT) return;
+            const double2 pbv = s_pb[seg_parity];
+            q = cmulc<false>(make_float2((float)pbv.x, (float)pbv.y), pl);
+            if (t == 0) s_pb[seg_parity ^ 1] = dcmul(pbv, a.rot_step);
+            seg_parity ^= 1;
+        };
         auto rot_out = [&](int n2, float2 y) {
             if (!ROT) return y;
             return cmulc<false>(y, (n2 == 0) ? q : cmulc<false>(q, a.wtab[n2]));
@@ -281,6 +296,7 @@ __global__ __launch_bounds__(kFftNT, (DEC == 1 && !ROT && !REAL) ? 4 : 3) void f
             }
             // ---- pass A' (over k0) and store the L valid outputs --------------------------
             fft16<true>(v);
+            make_q();
             const long long o0 = seg0 + te;  // output index == stream position (element n2*256 + te)
             // strided stores: element i of a segment starting at s sits at position p = s + i and is output
             // n' iff p + 1 == n' * decm.  One 64-bit division per segment (s + 1 = q0 * decm + r0), then per
@@ -399,6 +415,7 @@ __global__ __launch_bounds__(kFftNT, (DEC == 1 && !ROT && !REAL) ? 4 : 3) void f
                     v[k] = (k == 0) ? e : cmulc<true>(e, ta2[k]);
                 }
                 fft16<true>(v);
+                make_q();
                 // (32-bit lane offsets from a wave-uniform base: sixteen 64-bit per-lane indices cost the ROT variants two spilled VGPRs)
                 const long long nb = ((long long)b * a.L - a.ov) / DEC;  // (b*L + i - ov)/DEC at i = 0
                 float2* __restrict__ seg_out = a.out + nb;
