@@ -10,7 +10,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 // (Round 3 also tried two tiles in flight per wave instead of one -- 24 more VGPRs, still three waves per SIMD: 147/160 0.4466 -> 0.4493 ms per
 // 2^27 samples, the other ratios 2-4 % slower -- and four waves per SIMD (128 VGPRs: 2-13 spilled).  Bytes in flight are not what it waits for.)
-template <bool ROT> __global__ __launch_bounds__(256, 3) void resamp_mfma_kernel(const RmArgs a) {
+template <bool ROT> __global__ __launch_bounds__(256, ROT ? 3 : 4) void resamp_mfma_kernel(const RmArgs a) {
     constexpr int NE = kRmNE, GM = kRmMaxGrp;
     const int t = threadIdx.x, l = t & 63;
     const int P = a.P, M = a.M, L = a.L;
@@ -33,18 +33,17 @@ template <bool ROT> __global__ __launch_bounds__(256, 3) void resamp_mfma_kernel
     // A operands for the whole workgroup: atab[g][k][lane] = W[4 (16 g + lane / 4) + lane % 4][cb + k], cb = first band
     // column of the lane's block (in registers they cost 72 VGPRs and the third wave per SIMD)
     float* atab = reinterpret_cast<float*>(rm_smem);
-    const int na = a.ngrp * a.KB * 64;
-    for (int i = t; i < na; i += 256) atab[i] = a.atab[i];
+    const int na = a.ngrp * a.KB * 64, nmeta = 2 * a.ngrp * 64;
+    // (... and behind them the two per-lane block tables -- first band column, period quad | output block -- which round 2 held in six VGPRs
+    // per lane: read back from LDS where they are used the plain kernel fits 122 VGPRs = four waves per SIMD (measured: +- 1 % -- it is not
+    // occupancy this kernel lacks) and the fused one drops from 142 to 130, which is worth 4-8 % to it: 147/160 0.240 -> 0.225 ms per 2^26 samples,
+    // 3/8 0.178 -> 0.164)
+    for (int i = t; i < na + nmeta; i += 256) atab[i] = a.atab[i];
     __syncthreads();
-    float2* tile = reinterpret_cast<float2*>(atab + ((na + 3) & ~3)) + (size_t)(t >> 6) * (rows * a.pitch + 64);
+    const int* lmeta = reinterpret_cast<const int*>(atab + na);
+    float2* tile = reinterpret_cast<float2*>(atab + ((na + nmeta + 3) & ~3)) + (size_t)(t >> 6) * (rows * a.pitch + 64);
     const int wave = (int)blockIdx.x * 4 + (t >> 6);
     if (wave >= a.nwaves) return;
-    int cb[GM], meta[GM];
-#pragma unroll
-    for (int g = 0; g < GM; g++) {
-        cb[g] = g < a.ngrp ? reinterpret_cast<const int*>(a.atab + na)[g * 64 + l] : 0;
-        meta[g] = g < a.ngrp ? reinterpret_cast<const int*>(a.atab + na)[(a.ngrp + g) * 64 + l] : 0xffff;
-    }
     // sample e of a tile for this lane: tile-relative index u = 64 e + l, period row u / M, column u % M; a column below
     // ext is also the tail of the previous row; what has no slot goes to the lane's spare one.  (Recomputed per tile:
     // as register tables the slots cost 24 VGPRs and spills.)
@@ -124,8 +123,9 @@ template <bool ROT> __global__ __launch_bounds__(256, 3) void resamp_mfma_kernel
 #pragma unroll
             for (int g = 0; g < GM; g++) {
                 if (g < a.ngrp) {
-                    const int lq = qd + (meta[g] >> 16);        // the lane's period quad
-                    const float2* bp = tile + 4 * lq * a.pitch + brow + cb[g];
+                    const int cbg = lmeta[g * 64 + l], mg = lmeta[(a.ngrp + g) * 64 + l];
+                    const int lq = qd + (mg >> 16);             // the lane's period quad
+                    const float2* bp = tile + 4 * lq * a.pitch + brow + cbg;
                     const float* ap = atab + g * a.KB * 64 + l;
                     f32x4 zr = {0.0f, 0.0f, 0.0f, 0.0f}, zi = {0.0f, 0.0f, 0.0f, 0.0f};
                     // Band columns in chunks of eight: a run-time loop over the chunks, the steps of a full chunk unrolled without a test
@@ -149,7 +149,7 @@ template <bool ROT> __global__ __launch_bounds__(256, 3) void resamp_mfma_kernel
                         zi = __builtin_amdgcn_mfma_f32_4x4x1f32(ap[k0 * 64], bv.y, zi, 0, 0, 0);
                     }
                     // lane = (block l / 4, period l % 4 of the quad): outputs o .. o + 3 of that period, 32 bytes
-                    const int o = 4 * (meta[g] & 0xffff);
+                    const int o = 4 * (mg & 0xffff);
                     const long long n = (per0 + 4 * lq + (l & 3)) * L + o;
                     if (o < L && n < a.nout) {
                         float2* dst = a.out + n;

@@ -59,7 +59,7 @@ struct RmArgs {
 };
 
 inline size_t rm_lds_bytes(int ngrp, int KB, int G, int pitch) {
-    return (size_t)((ngrp * KB * 64 + 3) & ~3) * 4 + 4 * ((size_t)4 * G * pitch + 64) * 8;      // A operands + four waves' tiles
+    return (size_t)((ngrp * KB * 64 + 2 * ngrp * 64 + 3) & ~3) * 4 + 4 * ((size_t)4 * G * pitch + 64) * 8;      // A operands + block tables + four waves' tiles
 }
 
 int launch_rm_resamp(const RmArgs& a, bool rot, hipStream_t stream);
