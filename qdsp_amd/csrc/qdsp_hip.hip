@@ -1643,7 +1643,7 @@ int launch_mf(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d_
         a.gm1 = e->volk_gain ? e->gm1 : 0.0f;
         mf_rot_tables(e->dphase, a.M, e->mf_KJ, &a.rot_step, a.rot_k);
     }
-    const int rc = qk::launch_mf_dec(a, e->mf_KJ, e->rotate, qk::knob(qk::K_MF_DEPTH, e->mf_KJ <= 8 ? 2 : 1), e->mf_QS, s);
+    const int rc = qk::launch_mf_dec(a, e->mf_KJ, e->rotate, qk::knob(qk::K_MF_DEPTH, (e->mf_KJ <= 8 && !(e->rotate && e->mf_KJ >= 5)) ? 2 : 1)      /* (fused VFO from decimation 33 on: one tile ahead = 118 VGPRs = four waves per SIMD, 1-3 % ahead of two tiles at three: 0.232 -> 0.229 ms at decimation 50; the plain decimator the other way round) */, e->mf_QS, s);
     if (rc) return rc < 0 && rc != -1 ? rc : QDSP_HIP_EINVAL;
     e->last.name = "decim_mfma_kernel";
     e->last.grid = (a.ntasks + 3) / 4 + 1;
