@@ -71,7 +71,7 @@ __host__ __device__ constexpr int pos1(int e) { return (e >> 1) + 136 * (e & 1);
 //              real and imaginary parts of its input apart, so TWO consecutive real segments ride one
 //              complex transform as re / im (segment 2b -> re, 2b+1 -> im); loads and stores are 4-byte.
 template <int DEC, bool ROT, bool REAL = false>
-__global__ __launch_bounds__(kFftNT, (DEC == 1) ? 4 : 3) void fir_fft_kernel(const FftArgs a) {
+__global__ __launch_bounds__(kFftNT, (DEC == 1 || !ROT) ? 4 : 3) void fir_fft_kernel(const FftArgs a) {
     __shared__ __attribute__((aligned(16))) float2 lds[kFftLdsElems + 16 * 17];
     // ROT: exp(j 2pi (phase0 + seg0 dphase)) of the workgroup's current segment lives HERE, not in four VGPRs of every lane (round 3: the fused
     // variants ran 147 VGPRs = three workgroups per CU where the plain FIR has 128 = four; with this and the output phasor formed at the
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(kFftNT, (DEC == 1) ? 4 : 3) void fir_fft_kernel(con
         // (ROT: the lane's element index is made opaque once per segment, so that the 64-bit per-lane addresses built from it are formed here
         // -- one v_lshl_add_u64 each -- instead of being hoisted out of the loop, held in eight VGPRs and spilled: the fourth workgroup per CU)
         int t_seg = t_lane;
-        if constexpr ((ROT || REAL) && DEC == 1) asm volatile("" : "+v"(t_seg));
+        if constexpr (DEC == 1 ? (ROT || REAL) : !ROT) asm volatile("" : "+v"(t_seg));
         const int t = t_seg, hi = t >> 4, lo = t & 15;
         const int te = (t & ~63) | ((t & 31) << 1) | ((t >> 5) & 1), half = (t >> 5) & 1, pte = pos1(te);
         const float2* tb = tbl + lo * 17;
