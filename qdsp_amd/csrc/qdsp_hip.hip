@@ -1391,7 +1391,8 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
     // (0.247 / 0.254; 0.472 / 0.505).  Decimations 4, 8, 16 keep the pruned form at every size (0.33 / 0.30 / 0.29 against 0.38 / 0.37 / 0.39).
     if (a.dec == 2 && e->ch == 2) {
         const int lim = qk::knob(qk::K_FFT_PRUNE2_MAX_COUNT, -1);
-        if (count >= (lim >= 0 ? (int64_t)lim : (int64_t)(e->rotate ? 1 << 26 : 1 << 25))) a.dec = 1;
+        // (re-measured once both forms ran four workgroups per CU where they can: 2^24 samples 0.0606 against 0.0623 ms, NCO from 2^25: 0.126 / 0.131)
+        if (count >= (lim >= 0 ? (int64_t)lim : (int64_t)(e->rotate ? 1 << 25 : 1 << 24))) a.dec = 1;
     }
     a.rot = e->rotate ? 1 : 0;
     a.decm = 1;

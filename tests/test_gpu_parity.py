@@ -353,7 +353,7 @@ def test_polyphase_overlap_save_decimator_vs_oracle(ops, monkeypatch, ntaps, rot
 @pytest.mark.parametrize("rot", [False, True])
 @pytest.mark.parametrize("ntaps", [24, 255, 700])
 def test_decimate_by_two_both_overlap_save_forms(ops, monkeypatch, ntaps, rot):
-    """Decimate-by-2 has two overlap-save forms in fir_fft_kernel: the pruned inverse (calls below 2^25 / 2^26 samples) and the full
+    """Decimate-by-2 has two overlap-save forms in fir_fft_kernel: the pruned inverse (calls below 2^24 / 2^25 samples) and the full
     inverse with every other output kept (above: faster there, profiles/r03_tune_dec2.txt).  The size rule is lowered to 100 000 samples
     so that one ragged stream crosses it in both directions; both forms against the FP64 oracle, state carried across the switch."""
     monkeypatch.setenv("QDSP_HIP_FFT_PRUNE2_MAX_COUNT", "100000")
