@@ -326,7 +326,7 @@ __device__ __forceinline__ void f1k_store_real_one(const FftArgs& a, long long s
 
 // ---- reference-sized calls: one workgroup = one wave = one segment ----------------------------------------------
 template <bool ROT, bool REAL = false>
-__global__ __launch_bounds__(64) void fir_fft1k_kernel(const FftArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void fir_fft1k_kernel(const FftArgs a) {
     __shared__ __attribute__((aligned(16))) float2 lds[16 * kF1P];
     const int l = threadIdx.x;
     const int nh = (a.H + 63) >> 6;
