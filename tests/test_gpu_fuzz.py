@@ -70,6 +70,9 @@ DIRECTED = [
     # round 3's big-call rule: past the measured crossovers the strided-window decimator hands chip-filling calls to the overlap-save forms
     ("res", 1, 8, 128, True, [(3_000_000, "decim_win_kernel"), ((1 << 24) + 8, "pfb_dec8_kernel")]),
     # (... and decimate-by-2 changes form inside fir_fft_kernel at 2^25 samples: pruned inverse below, full inverse + every other output kept above)
+    # fused VFO through the full inverse, big enough (> 4096 segments) that workgroups take a second segment: the segment phasor they
+    # carry in LDS from one to the next (round 3's four-workgroup form of fir_fft_kernel<1, ROT>)
+    ("res", 1, 3, 256, True, [((1 << 24) + 2 * 4096 + 3, "fir_fft_kernel")]),
     ("res", 1, 2, 128, False, [(3_000_000, "decim_win_kernel"), ((1 << 24) + 2, "fir_fft_kernel"), ((1 << 25) + 6, "fir_fft_kernel")]),
     ("res", 1, 4, 63, False, [(200_000, "decim_win_kernel")]),
     ("res", 1, 4, 160, True, [(2_000_000, "decim_win_kernel"), ((1 << 26) + 4, "pfb_dec4_kernel")]),
