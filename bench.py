@@ -304,6 +304,23 @@ def run_workload(name: str, args, ctx) -> dict:
 
     world, rank, local_rank, dev = ctx["world"], ctx["rank"], ctx["local_rank"], ctx["dev"]
     rehearse, self_ring = ctx["rehearse"], ctx["self_ring"]
+    ctrl, ctrl_dev = ctx.get("ctrl"), ctx.get("ctrl_dev", "cpu")
+    ring = None
+
+    def ctrl_reduce(v: float, how=None) -> float:
+        """Control-plane reduction over the ranks.  The ring's own RCCL communicator must be idle first: two communicators of
+        one process with operations in flight on different streams may wait for each other (so: drain, then the collective --
+        which runs on gloo whenever that group could be had, main())."""
+        if world == 1:
+            return v
+        if ring is not None:
+            ring.drain()
+        t = torch.tensor([v], dtype=torch.float64, device=ctrl_dev)
+        dist.all_reduce(t, op=how or dist.ReduceOp.MAX, group=ctrl)
+        return float(t.item())
+
+    def ctrl_barrier():
+        ctrl_reduce(0.0)
 
     def dbg(msg):
         if os.environ.get("QDSP_BENCH_DEBUG"):
@@ -333,8 +350,11 @@ def run_workload(name: str, args, ctx) -> dict:
     # stride is the caller's to choose (qdsp_hip_chan_cf32_process_dev's out_stride argument); reported in config.out_row_stride.
     out = torch.empty((w["nchan"], nout + CHAN_ROW_PAD) if is_chan else nout, dtype=torch.complex64, device=dev)
     ring = RingStream(op, n, rank, world, transport="host" if rehearse else "device", align=align,
-                      exchange=(world > 1 or self_ring),
+                      exchange=(world > 1 or self_ring), ctrl_group=ctrl,
                       prefetch=os.environ.get("QDSP_BENCH_NO_PREFETCH", "0") != "1")
+    c_ring = getattr(ring, "_ring", None)
+    if c_ring is not None:
+        c_ring.set_timing(True)
 
     def step():
         ring.step(x, out, next_x=x)
@@ -356,8 +376,7 @@ def run_workload(name: str, args, ctx) -> dict:
             torch.cuda.synchronize()
         restart()
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        ctrl_barrier()
     dbg("spinup done")
     for _ in range(args.warmup):
         step()
@@ -365,6 +384,7 @@ def run_workload(name: str, args, ctx) -> dict:
 
     # Halo check (outside the timed region, no oracle): a fresh operator fed the predecessor's
     # regenerated tail + my head must reproduce my head.
+    halo_err = None
     if world > 1 and H:
         pos_now = ring.stream_position()
         step()
@@ -381,13 +401,18 @@ def run_workload(name: str, args, ctx) -> dict:
         # (not bit-equal by construction: the short reference call ends in a zero-padded FFT
         # segment where the full chunk has real samples; a wrong halo is an O(1) error)
         err = (ref - got).abs().max().item()
-        if not err < 2e-6 * max(ref.abs().max().item(), 1e-30):
+        halo_err = err / max(ref.abs().max().item(), 1e-30)
+        if not halo_err < 2e-6:
+            # (the other ranks are released by the launcher: torch.distributed.run ends every rank when one exits non-zero)
             raise SystemExit(f"rank {rank}: {name}: halo exchange produced different outputs than the unsharded filter (max err {err:.3e})")
         chk.close()
+        halo_err = ctrl_reduce(halo_err)
     dbg("halo check done")
 
-    if world > 1:
-        dist.barrier()
+    if c_ring is not None:
+        ring.drain()
+        c_ring.set_timing(True)        # (restarts the statistics: only the timed region's exchanges are reported)
+    ctrl_barrier()
     torch.cuda.synchronize()
     # HIP events on the stream the operator launches on (torch's current stream: ops.* pass it to *_process_dev), around the SAME
     # K steps the wall clock brackets: the dominant kernel's mean launch duration, <= ms_per_step by construction
@@ -398,16 +423,36 @@ def run_workload(name: str, args, ctx) -> dict:
         step()
     ev1.record()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    ctrl_barrier()                     # (drains the exchange prefetched for a step that does not run, then the barrier)
     dt = time.perf_counter() - t0
     kms_timed = ev0.elapsed_time(ev1) / args.steps
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt = ctrl_reduce(dt)
     dbg("timed loop done")
     ring.drain()
+    rccl = None
+    if world > 1 or self_ring:
+        info = c_ring.info() if c_ring is not None else {}
+        xus = c_ring.exchange_us() if c_ring is not None else {}
+        rccl = {
+            "ring_transport": ring.transport_name(),
+            "ring_ranks_requested": world,
+            # what ncclCommCount says on rank 0, and the smallest / largest answer over all ranks
+            "ring_comm_ranks": info.get("comm_ranks"),
+            "ring_comm_ranks_min": int(-ctrl_reduce(-float(info.get("comm_ranks", -1)))) if world > 1 else info.get("comm_ranks"),
+            "ring_comm_ranks_max": int(ctrl_reduce(float(info.get("comm_ranks", -1)))) if world > 1 else info.get("comm_ranks"),
+            "ring_comm_device": info.get("comm_device"),
+            "rccl_version": info.get("rccl_version"),
+            "halo_bytes": H * 8,
+            "halo_check_max_rel_err": halo_err,
+            "halo_check": ("fresh operator + regenerated predecessor tail vs this rank's output head, max over ranks" if halo_err is not None
+                           else "not run (one rank: its own tail is its halo; tests/test_gpu_ring.py compares that stream with the oracle)"),
+            "exchange_us_mean": round(ctrl_reduce(xus.get("mean_us", 0.0)), 2),
+            "exchange_us_max": round(ctrl_reduce(xus.get("max_us", 0.0)), 2),
+            "exchanges_timed": xus.get("exchanges"),
+            "exchange_us_source": "HIP events around each ncclSend/ncclRecv group on the ring stream, timed region only, max over ranks "
+                                  "(includes waiting for the neighbour's end of the pair)" if c_ring is not None else None,
+            "control_plane": ctx.get("ctrl_name"),
+        }
     ms_per_step = dt / args.steps * 1e3
     value = world * n / (dt / args.steps) / 1e6
 
@@ -488,6 +533,8 @@ def run_workload(name: str, args, ctx) -> dict:
         "hbm_roofline_msps": round(HBM_PEAK_GBS * 1e9 / w["bytes"] / 1e6, 1),
         "frac_of_hbm_roofline_msps": round(value / world / (HBM_PEAK_GBS * 1e9 / w["bytes"] / 1e6), 4),
     }
+    if rccl is not None:
+        res["rccl"] = rccl
     tj = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tj):
         try:
@@ -535,6 +582,7 @@ def main():
     # first send / recv between two ranks fails with `hipIpcGetMemHandle: invalid argument`.  It is exported by the image already;
     # set here as well -- before anything initialises HIP -- so that a launcher with a scrubbed environment still works.
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # one node: never depend on the hostname resolving
 
     import torch
     import torch.distributed as dist
@@ -564,6 +612,18 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     ctx = dict(world=world, rank=rank, local_rank=local_rank, dev=dev, rehearse=rehearse, self_ring=self_ring)
+    if world > 1:
+        # Control plane (barriers, the max-over-ranks clock, the ring's id broadcast) on gloo: the only RCCL communicator with
+        # traffic in this process is then the halo ring's.  If gloo cannot be had (every rank fails alike: one host), the default
+        # RCCL group carries it, always behind a drained ring (run_workload.ctrl_reduce).
+        if rehearse:
+            ctx.update(ctrl=None, ctrl_dev="cpu", ctrl_name="gloo (default group, rehearsal)")
+        else:
+            try:
+                ctx.update(ctrl=dist.new_group(backend="gloo"), ctrl_dev="cpu", ctrl_name="gloo group beside the default nccl group")
+            except Exception as e:  # noqa: BLE001
+                print(f"bench.py rank {rank}: no gloo control group ({e!r}); control collectives on the default RCCL group", file=sys.stderr, flush=True)
+                ctx.update(ctrl=None, ctrl_dev=dev, ctrl_name="default nccl group (no gloo)")
 
     res = run_workload(args.workload, args, ctx)
     chain = None
@@ -601,16 +661,20 @@ def main():
             "hbm_roofline_msps": res["hbm_roofline_msps"],
             "frac_of_hbm_roofline_msps": res["frac_of_hbm_roofline_msps"],
         }
+        if "rccl" in res:
+            line["rccl"] = res["rccl"]
         if chain is not None:
             line["chain"] = {"value": chain["value"], "unit": "Msamples/s", "ms_per_step": chain["ms_per_step"],
                              "steps": args.steps, "warmup": args.warmup, "config": chain["config"],
                              "roofline": chain["roofline"], "hbm_roofline_msps": chain["hbm_roofline_msps"],
-                             "frac_of_hbm_roofline_msps": chain["frac_of_hbm_roofline_msps"]}
+                             "frac_of_hbm_roofline_msps": chain["frac_of_hbm_roofline_msps"],
+                             **({"rccl": chain["rccl"]} if "rccl" in chain else {})}
         for key, leg in (("channelizer", chan), ("channelizer_m8", chan8)):
             if leg is not None:
                 line[key] = {"value": leg["value"], "unit": "Msamples/s (input rate, all 64 channels)", "ms_per_step": leg["ms_per_step"],
                              "steps": args.steps, "warmup": args.warmup, "config": leg["config"], "roofline": leg["roofline"],
-                             "hbm_roofline_msps": leg["hbm_roofline_msps"], "frac_of_hbm_roofline_msps": leg["frac_of_hbm_roofline_msps"]}
+                             "hbm_roofline_msps": leg["hbm_roofline_msps"], "frac_of_hbm_roofline_msps": leg["frac_of_hbm_roofline_msps"],
+                             **({"rccl": leg["rccl"]} if "rccl" in leg else {})}
         if world == 1 and not args.no_block_call:
             # what a block of the reference's graph gets per call (latency-bound: DESIGN.md "Reference-sized calls")
             line["block_call"] = block_call(args.workload, ctx)
@@ -622,7 +686,9 @@ def main():
 
     if world > 1 or self_ring:
         torch.cuda.synchronize()
-        dist.barrier()
+        if world > 1:
+            t = torch.zeros(1, device=ctx["ctrl_dev"])
+            dist.all_reduce(t, group=ctx["ctrl"])          # (every ring is drained and closed by now)
         dist.destroy_process_group()
 
 

@@ -370,21 +370,39 @@ int qdsp_hip_time_process_dev(void* h, const void* d_in, int64_t count, void* d_
  *     ncclGroupStart(); ncclSend(my tail -> rank + 1); ncclRecv(rank - 1's tail); ncclGroupEnd();
  * on the ring's own HIP stream and installs what arrives with <op>_set_history_dev.  A C++ graph (qdsp_amd/host/examples/
  * graph_check.cpp `shard`) and qdsp_amd/sharding.py RingStream call the same five entry points.
+ *   available  1 when RCCL could be bound in this process (dlopen of librccl.so.1), else 0: lets every rank vote BEFORE the
+ *              collective create (a ring with one end missing would hang; qdsp_amd/sharding.py takes that vote)
  *   unique_id  one rank (rank 0) obtains the 128-byte id; the caller carries it to every rank (file, socket, MPI, a torch store)
  *   create     collective: every rank of the ring calls it with the same id; world 1 = the rank is its own neighbour
  *   post       my tail (halo_bytes at d_tail, as of what `producer_stream` has queued so far) -> rank + 1, and rank - 1's tail ->
- *              the next of three receive buffers; returns at once.  At most two posts may be outstanding.
+ *              the next of four receive buffers; returns at once.  At most two posts may be outstanding.
  *   complete   `consumer_stream` waits for the oldest outstanding post; *d_halo = what arrived with it, *d_prev_halo = what
  *              arrived with the post before it (zeros before the first): in a block-cyclic cut rank 0's predecessor is the LAST
  *              rank of the step before.  Either pointer may be NULL.
- *   drain      host-side wait for everything posted (end of stream: every rank has one exchange in flight that no step reads)
+ *   drain      host-side wait for everything posted (end of stream: every rank has one exchange in flight that no step reads;
+ *              also: call it before a collective of ANOTHER communicator of the same process, e.g. a torch.distributed barrier)
+ *   info       what the communicator itself reports: ncclCommCount / ncclCommUserRank / ncclCommCuDevice and the RCCL version
+ *              code (-1 where the bound RCCL lacks the query) -- evidence for a scaling run, not needed by the data path
+ *   set_timing / exchange_us   optional: HIP timing events around each send/recv group on the ring stream; mean / max duration
+ *              in microseconds of the exchanges finished so far (includes waiting for the neighbour to post its end)
+ * Lifetimes (one consumer stream per ring):
+ *   d_tail        must stay unmodified until the matching complete(): work queued on consumer_stream AFTER that complete may
+ *                 overwrite it (the send is ordered before the event complete waits for).
+ *   *d_halo       valid for work queued on consumer_stream between this complete() and the next but one complete();
+ *   *d_prev_halo  ... between this complete() and the next one.  The ring waits for that work (an event recorded on
+ *                 consumer_stream by each complete) before a later post receives into the same buffer.  Work on another
+ *                 stream must be ordered behind consumer_stream by the caller.
  * Errors: QDSP_HIP_ERCCL when librccl.so.1 cannot be loaded or an RCCL call fails (its message goes to stderr). */
 #define QDSP_HIP_RING_ID_BYTES 128
+int qdsp_hip_ring_available(void);
 int qdsp_hip_ring_unique_id(void* id);
 int qdsp_hip_ring_create(void** ring, int device, int rank, int world, const void* id, int halo_bytes);
 int qdsp_hip_ring_post(void* ring, const void* d_tail, void* producer_stream);
 int qdsp_hip_ring_complete(void* ring, void* consumer_stream, const void** d_halo, const void** d_prev_halo);
 int qdsp_hip_ring_drain(void* ring);
+int qdsp_hip_ring_info(void* ring, int* comm_ranks, int* comm_rank, int* comm_device, int* rccl_version);
+int qdsp_hip_ring_set_timing(void* ring, int on);
+int qdsp_hip_ring_exchange_us(void* ring, double* mean_us, double* max_us, long long* exchanges);
 void qdsp_hip_ring_destroy(void* ring);
 
 #ifdef __cplusplus

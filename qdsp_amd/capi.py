@@ -69,11 +69,15 @@ def load():
     sig("qdsp_hip_abi_version", i32)
     sig("qdsp_hip_error_string", C.c_char_p, i32)
     sig("qdsp_hip_reload_env", i32)
+    sig("qdsp_hip_ring_available", i32)
     sig("qdsp_hip_ring_unique_id", i32, vp)
     sig("qdsp_hip_ring_create", i32, pvp, i32, i32, i32, vp, i32)
     sig("qdsp_hip_ring_post", i32, vp, vp, vp)
     sig("qdsp_hip_ring_complete", i32, vp, vp, pvp, pvp)
     sig("qdsp_hip_ring_drain", i32, vp)
+    sig("qdsp_hip_ring_info", i32, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32))
+    sig("qdsp_hip_ring_set_timing", i32, vp, i32)
+    sig("qdsp_hip_ring_exchange_us", i32, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong))
     sig("qdsp_hip_ring_destroy", None, vp)
     sig("qdsp_hip_device_count", i32, C.POINTER(i32))
     sig("qdsp_hip_device_info", i32, i32, C.c_char_p, i32, C.c_char_p, i32, C.POINTER(i32))

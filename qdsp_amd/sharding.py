@@ -90,12 +90,63 @@ def exchange_halo(tail, hist_out, rank: int, world: int, group=None):
             req.wait()
 
 
+def _ctrl_device(group, fallback):
+    """Where the tensors of a control-plane collective live: the CPU when the group can carry CPU tensors (gloo, or a
+    'cpu:gloo,cuda:nccl' group), else `fallback` (an nccl-only group)."""
+    import torch
+    import torch.distributed as dist
+
+    try:
+        names = str(dist.get_backend(group)).lower()
+    except Exception:  # noqa: BLE001
+        names = ""
+    return torch.device("cpu") if "gloo" in names else torch.device(fallback)
+
+
+def negotiate_c_ring(rank: int, world: int, group, ctrl_device, *, load=None):
+    """Phase 1 of bringing up the C ring on `world` > 1 ranks: decide TOGETHER whether RCCL can be bound on every rank, and carry
+    rank 0's RCCL id to all of them.  Every rank issues exactly the same two collectives whatever fails locally --
+        broadcast(id, 0)  (a zeroed id when rank 0 could not produce one),  all_reduce(ok, MIN)
+    -- so a rank whose library or RCCL is missing can never leave the others waiting in a different collective.
+    Returns (library, id bytes) when every rank is able, else (None, reason)."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    L, ok, why = None, 1, ""
+    try:
+        if load is None:
+            from . import capi
+
+            load = capi.load
+        L = load()
+        if int(L.qdsp_hip_ring_available()) != 1:
+            ok, why = 0, "RCCL cannot be bound in this process (qdsp_hip_ring_available() == 0)"
+    except Exception as e:  # noqa: BLE001
+        ok, why = 0, f"libqdsp_hip.so cannot be loaded: {e!r}"
+    idbuf = (C.c_char * 128)()
+    if rank == 0 and ok:
+        rc = int(L.qdsp_hip_ring_unique_id(idbuf))
+        if rc != 0:
+            ok, why = 0, f"qdsp_hip_ring_unique_id failed ({rc})"
+            idbuf = (C.c_char * 128)()
+    t = torch.from_numpy(np.frombuffer(idbuf.raw, dtype=np.uint8).copy()).to(ctrl_device)
+    dist.broadcast(t, 0, group=group)
+    flag = torch.tensor([ok], dtype=torch.int32, device=ctrl_device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) != 1:
+        return None, (why or "another rank cannot bind RCCL")
+    return L, t.cpu().numpy().tobytes()
+
+
 class _CRing:
     """qdsp_hip_ring_* (include/qdsp_hip.h, qdsp_amd/csrc/ring.cpp): the RCCL send/recv pair of one step, posted on the ring's own HIP
-    stream.  The 128-byte RCCL id comes from rank 0 and travels through the torch process group (a device broadcast); a
-    one-rank ring (the rank is its own neighbour) needs no process group at all."""
+    stream.  `idbytes`: the 128-byte RCCL id (rank 0's, carried by `negotiate_c_ring`); None = a one-rank ring (the rank is its
+    own neighbour), which needs no process group at all."""
 
-    def __init__(self, device: int, rank: int, world: int, halo_bytes: int, group=None):
+    def __init__(self, device: int, rank: int, world: int, halo_bytes: int, idbytes=None):
         import ctypes as C
 
         from . import capi
@@ -103,19 +154,12 @@ class _CRing:
         self._L = capi.load()
         self._check = capi.check
         idbuf = (C.c_char * 128)()
-        if world == 1:
+        if idbytes is None:
+            if world != 1:
+                raise ValueError("a ring of several ranks needs rank 0's id")
             capi.check(self._L.qdsp_hip_ring_unique_id(idbuf), "qdsp_hip_ring_unique_id")
         else:
-            import numpy as np
-            import torch
-            import torch.distributed as dist
-
-            t = torch.zeros(128, dtype=torch.uint8, device=f"cuda:{device}")
-            if rank == 0:
-                capi.check(self._L.qdsp_hip_ring_unique_id(idbuf), "qdsp_hip_ring_unique_id")
-                t.copy_(torch.from_numpy(np.frombuffer(idbuf.raw, dtype=np.uint8).copy()))
-            dist.broadcast(t, 0, group=group)
-            idbuf.raw = t.cpu().numpy().tobytes()
+            idbuf.raw = bytes(idbytes)
         self._h = C.c_void_p()
         capi.check(self._L.qdsp_hip_ring_create(C.byref(self._h), device, rank, world, idbuf, halo_bytes), "qdsp_hip_ring_create")
         self._C = C
@@ -130,6 +174,22 @@ class _CRing:
 
     def drain(self):
         self._check(self._L.qdsp_hip_ring_drain(self._h), "qdsp_hip_ring_drain")
+
+    def info(self) -> dict:
+        """What the communicator itself reports (ncclCommCount / ncclCommUserRank / ncclCommCuDevice, RCCL version code)."""
+        C = self._C
+        v = [C.c_int(-1) for _ in range(4)]
+        self._check(self._L.qdsp_hip_ring_info(self._h, *[C.byref(x) for x in v]), "qdsp_hip_ring_info")
+        return {"comm_ranks": v[0].value, "comm_rank": v[1].value, "comm_device": v[2].value, "rccl_version": v[3].value}
+
+    def set_timing(self, on: bool = True):
+        self._check(self._L.qdsp_hip_ring_set_timing(self._h, 1 if on else 0), "qdsp_hip_ring_set_timing")
+
+    def exchange_us(self) -> dict:
+        C = self._C
+        mean, mx, n = C.c_double(0), C.c_double(0), C.c_longlong(0)
+        self._check(self._L.qdsp_hip_ring_exchange_us(self._h, C.byref(mean), C.byref(mx), C.byref(n)), "qdsp_hip_ring_exchange_us")
+        return {"mean_us": mean.value, "max_us": mx.value, "exchanges": n.value}
 
     def close(self):
         if self._h:
@@ -171,7 +231,7 @@ class RingStream:
     NBUF = 3   # receive buffers in rotation: rank 0 reads the one filled a step earlier while the next one is in flight
 
     def __init__(self, op, n: int, rank: int, world: int, *, group=None, transport: str = "device",
-                 prefetch: bool = True, align: int = 1, exchange: bool | None = None):
+                 prefetch: bool = True, align: int = 1, exchange: bool | None = None, ctrl_group=None):
         import torch
 
         if transport not in ("device", "host"):
@@ -180,6 +240,9 @@ class RingStream:
             raise ValueError(f"chunk of {n} samples is not a positive multiple of the alignment {align}")
         self.op, self.n, self.rank, self.world = op, int(n), int(rank), int(world)
         self.group, self.transport = group, transport
+        # control plane (the id broadcast and the all-ranks vote while the C ring comes up): `ctrl_group` if given -- bench.py hands
+        # over a gloo group so that no torch RCCL collective ever shares the process with the ring's communicator -- else `group`
+        self.ctrl_group = ctrl_group if ctrl_group is not None else group
         self.H = int(getattr(op, "history_len", 0) or 0) if hasattr(op, "set_history_dev") else 0
         if self.world > 1 and self.n < self.H:
             raise ValueError(f"chunk of {n} samples is shorter than the {self.H}-sample halo")
@@ -210,30 +273,46 @@ class RingStream:
 
     def _make_c_ring(self, group):
         """The C ring, or None when it cannot be had on EVERY rank (then all ranks take torch.distributed's p2p path together: a ring
-        with one end on another transport would hang).  One rank alone has nobody to agree with: the error is the caller's."""
+        with one end on another transport would hang).  One rank alone has nobody to agree with: the error is the caller's.
+        world > 1: `negotiate_c_ring` (identical collectives on every rank whatever fails locally), then the collective create,
+        then a second vote on its outcome."""
         import sys
 
         import torch
 
-        ring, err = None, None
-        try:
-            ring = _CRing(self.device.index or 0, self.rank, self.world, self.H * 8, group)
-        except Exception as e:  # noqa: BLE001
-            if self.world == 1:
-                raise
-            err = e
-        if self.world > 1:
-            import torch.distributed as dist
+        dev_index = self.device.index or 0
+        if self.world == 1:
+            return _CRing(dev_index, self.rank, 1, self.H * 8)
+        import torch.distributed as dist
 
-            ok = torch.tensor([0 if ring is None else 1], dtype=torch.int32, device=self.device)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-            if int(ok.item()) == 0:
-                if ring is not None:
-                    ring.close()
-                    ring = None
-                print(f"qdsp_amd.sharding: rank {self.rank}: the C ring is not available on every rank ({err!r}); "
-                      "halos travel through torch.distributed send / recv instead", file=sys.stderr, flush=True)
+        cg = self.ctrl_group
+        cdev = _ctrl_device(cg, self.device)
+        L, got = negotiate_c_ring(self.rank, self.world, cg, cdev)
+        ring, err = None, None
+        if L is None:
+            err = got
+        else:
+            try:
+                ring = _CRing(dev_index, self.rank, self.world, self.H * 8, got)
+            except Exception as e:  # noqa: BLE001
+                err = repr(e)
+            ok = torch.tensor([0 if ring is None else 1], dtype=torch.int32, device=cdev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=cg)
+            if int(ok.item()) == 0 and ring is not None:
+                ring.close()
+                ring = None
+        if ring is None:
+            print(f"qdsp_amd.sharding: rank {self.rank}: the C ring is not available on every rank ({err or 'another rank failed'}); "
+                  "halos travel through torch.distributed send / recv instead", file=sys.stderr, flush=True)
         return ring
+
+    def transport_name(self) -> str:
+        """Which transport the halo actually travels on (bench.py's `rccl` object)."""
+        if not self.exchange:
+            return "none"
+        if self._ring is not None:
+            return "qdsp_hip_ring (RCCL ncclSend/ncclRecv on the ring's own stream)"
+        return "gloo, CPU-staged (one-GPU rehearsal)" if self.transport == "host" else "torch.distributed p2p (fallback)"
 
     # -- the exchange -------------------------------------------------------------------------
     def _post(self, x):

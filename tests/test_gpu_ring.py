@@ -213,3 +213,57 @@ def test_c_ring_entry_points_self_ring():
         assert rel_rms(np.concatenate(ys), want) < 2e-6
     finally:
         L.qdsp_hip_ring_destroy(ring)
+
+
+# ---------------------------------------------------------------------------------------------
+# bench.py's own multi-rank path, end to end: launcher -> ranks -> halo
+# self-check -> max-over-ranks clock -> ONE JSON line that says by itself what carried the halo.
+# ---------------------------------------------------------------------------------------------
+def _run_bench(argv, extra_env, timeout=900):
+    import json
+
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    env.update(extra_env)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py")] + argv, env=env,
+                       capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, f"bench.py {argv} failed ({r.returncode}):\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}"
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_rehearsal_end_to_end():
+    """`python bench.py --gpus 2` with no launcher: it starts torch.distributed.run itself (a child, before touching the GPU),
+    both ranks share cuda:0 (QDSP_BENCH_REHEARSE=1: halos over gloo, RCCL refuses two ranks on one device), every leg of the
+    default line runs its halo self-check, and the line carries the `rccl` object."""
+    line = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--log2n", "20", "--no-cpu-baseline", "--spinup-ms", "20"],
+                      {"QDSP_BENCH_REHEARSE": "1"})
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["config"]["halo_samples"] == 255 and line["config"]["samples_per_gpu_per_step"] == 1 << 20
+    assert line["value"] > 0 and line["ms_per_step"] > 0
+    assert abs(line["value"] - 2 * (1 << 20) / (line["ms_per_step"] * 1e-3) / 1e6) < 0.01 * line["value"]
+    rc = line["rccl"]
+    assert rc["ring_ranks_requested"] == 2 and rc["halo_bytes"] == 2040
+    assert rc["ring_transport"].startswith("gloo")                      # the rehearsal says so itself
+    assert rc["halo_check_max_rel_err"] is not None and rc["halo_check_max_rel_err"] < 2e-6
+    for leg, halo in (("chain", 256), ("channelizer", 256), ("channelizer_m8", 256)):
+        assert line[leg]["config"]["halo_samples"] == halo, leg
+        assert line[leg]["rccl"]["halo_check_max_rel_err"] < 2e-6, leg
+    assert "block_call" not in line and "cpu_baseline" not in line      # N = 1 only
+
+
+def test_bench_self_ring_reports_the_communicator():
+    """One rank as its own ring neighbour over REAL RCCL, through bench.py: the `rccl` object is filled from the communicator
+    (ncclCommCount == 1 here; == N on an N-GPU run) and the exchange is timed on the ring's stream."""
+    line = _run_bench(["--gpus", "1", "--steps", "5", "--warmup", "2", "--log2n", "20", "--no-cpu-baseline", "--no-block-call", "--no-channelizer",
+                       "--spinup-ms", "20"], {"QDSP_BENCH_SELF_RING": "1"})
+    rc = line["rccl"]
+    assert rc["ring_transport"].startswith("qdsp_hip_ring")
+    assert rc["ring_comm_ranks"] == 1 and rc["ring_comm_ranks_min"] == 1 and rc["ring_comm_ranks_max"] == 1
+    assert rc["ring_comm_device"] == 0 and rc["rccl_version"] > 0
+    assert rc["exchanges_timed"] >= 3 and 0 < rc["exchange_us_mean"] <= rc["exchange_us_max"] < 5e4
+    assert line["chain"]["rccl"]["ring_comm_ranks"] == 1

@@ -188,3 +188,45 @@ def test_partition_refuses_short_trailing_chunks():
     assert [c.count for c in ch] == [512, 488]
     with pytest.raises(ValueError):
         sharding.RingStream(_OracleOp("fir"), 1000, 0, 2, align=512)   # chunk not a multiple of the alignment
+
+
+# ---------------------------------------------------------------------------------------------
+# Bringing up the C ring: every rank must issue the same collectives whatever fails locally
+# (rank 0 failing before the id broadcast left the other ranks inside it).
+# ---------------------------------------------------------------------------------------------
+def _vote_worker(rank, world, port, disabled_rank, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if rank == disabled_rank:
+        os.environ["QDSP_RING_DISABLE_RCCL"] = "1"      # read once, when this process first asks for RCCL
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        L, got = sharding.negotiate_c_ring(rank, world, None, sharding._ctrl_device(None, "cpu"))
+        # a collective AFTER the negotiation: if the ranks had taken different paths this would pair with a left-over one
+        t = torch.tensor([rank + 1.0])
+        dist.all_reduce(t)
+        assert t.item() == world * (world + 1) / 2
+        with open(os.path.join(outdir, f"vote_{rank}.txt"), "w") as f:
+            f.write("none" if L is None else got.hex())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("disabled_rank", [0, 1, -1])
+def test_c_ring_vote_is_the_same_collective_sequence_on_every_rank(tmp_path, disabled_rank):
+    """RCCL forced off in the library of ONE rank (rank 0: the id's owner; rank 1: a receiver), or on none: all ranks come
+    back with the same verdict -- nobody hangs in a collective the failing rank skipped -- and, when all are able, with the
+    same 128-byte id."""
+    world = 2
+    ctx = mp.spawn(_vote_worker, args=(world, _free_port(), disabled_rank, str(tmp_path)), nprocs=world, join=False)
+    import time
+
+    t_end = time.time() + 120
+    while not ctx.join(timeout=1.0):
+        assert time.time() < t_end, "the ranks did not finish: mismatched collectives"
+    got = [open(tmp_path / f"vote_{r}.txt").read() for r in range(world)]
+    assert got[0] == got[1]
+    if disabled_rank >= 0:
+        assert got[0] == "none"
+    else:
+        assert len(got[0]) == 256 and set(got[0]) != {"0"}
