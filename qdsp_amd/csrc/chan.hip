@@ -21,11 +21,15 @@
 //   lane p:  16 branch sums for staged column p straight from global memory (19 rows of 64
 //            consecutive samples = 512-byte coalesced loads, sliding 4-row window, complex taps in 8
 //            VGPRs) -> wave-private LDS tile T[n'][mu]
-//   lane (n' = l>>2, sub = l&3): U[sub + 4i] from T -> radix-16 DFT over i in registers
-//            -> * exp(+-j 2pi c0 sub / 64) -> radix-4 across the quad with DPP (no LDS)
-//            -> channels c0 + 16 c1 at time n': rot_c(n'), wave transpose (ds_bpermute) and stores; each
-//            store instruction writes 4 runs of 16 consecutive n' (128-byte lines), each run by 16
-//            neighbouring lanes.  (The first version scattered 64 8-byte pieces per store and was bound
+//   lane (sub = l>>4, n' = l&15): U[sub + 4i] from T -> radix-16 DFT over i in registers
+//            -> * exp(+-j 2pi c0 sub / 64) -> radix-4 across the four 16-lane ROWS of the wave, two groups c0 at a time:
+//            v_permlane32_swap pairs rows (sub, sub^2), v_permlane16_swap rows (sub, sub^1) -- a swap hands each lane its
+//            butterfly partner AND leaves the results where the stores want them: row r of a result register holds ONE
+//            channel c0 + 16 c1 at the 16 consecutive times n' (round 4; rounds 2-3 ran the radix-4 inside the quads with
+//            DPP -- lane = 4 n' + sub -- and then transposed the wave with two ds_bpermute per group: 32 LDS operations
+//            per tile and a wait in front of every store)
+//            -> rot_c(n') and stores; each store instruction writes 4 runs of 16 consecutive n' (128-byte lines), each
+//            run by 16 neighbouring lanes.  (The first version scattered 64 8-byte pieces per store and was bound
 //            by L2 write requests: 134 M per GiB of output.)
 // rot_c(n') = A_c(tile) * W(n' - n0) * B_c(n' - n0): A_c is FP64 state of lane c advanced by one
 // complex multiply per tile, W = exp(j 64 m dphi_0) a per-lane constant, B_c = exp(j 64 m delta_c) a
@@ -46,28 +50,37 @@
 namespace qk {
 
 constexpr int kChT = 16;                 // output times per wave tile
-constexpr int kChRowT = 68;              // T[n'][mu] row pitch: lanes (n', sub) read 4n' + sub (mod 32): conflict-free
+constexpr int kChRowT = 66;              // T[n'][mu] row pitch in float2: the 32 lanes (sub in {0,1} or {2,3}, n') of one ds_read_b64 group
+                                         // read dwords 132 n' + 2 sub + 8 i = 4 n' + 2 sub (mod 64): conflict-free
 constexpr int kChWaveLds = kChT * kChRowT + 2 * 64;   // float2 elements per wave: T + {A_c, j A_c}[64]
 
-// quad_perm of both lanes of a packed pair.  One 64-bit update_dpp (expanded to two v_mov_b32_dpp):
-// with two 32-bit mov_dpp calls hipcc (ROCm 7.2) keeps only the first and feeds it to both halves of the
-// consuming v_pk_fma_f32.
-template <int CTRL> __device__ __forceinline__ v2f dpp_quad(v2f v) {
+// Row exchanges of a packed pair of registers (gfx950 v_permlane32_swap / v_permlane16_swap, one per 32-bit half):
+//   swap32(a, b): a = [a rows 0 1 | b rows 0 1],  b = [a rows 2 3 | b rows 2 3]
+//   swap16(a, b): a = [a row 0, b row 0, a row 2, b row 2],  b = [a row 1, b row 1, a row 3, b row 3]
+// quad_perm of both halves of a packed pair
+template <int CTRL> __device__ __forceinline__ v2f dpp_pair(v2f v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const long long r = __builtin_amdgcn_update_dpp(0ll, __builtin_bit_cast(long long, v), CTRL, 0xf, 0xf, true);
     return __builtin_bit_cast(v2f, r);
 #else
-    return v;   // (the host pass only parses this; the type-generic builtin exists for the device target)
+    return v;
 #endif
 }
-
-// Both lanes of a packed pair fetched from the lane whose byte index is `src` (two ds_bpermute_b32 through a 64-bit
-// integer: taken from .x and .y of the vector directly, hipcc permutes .x only and copies it into both halves).
-__device__ __forceinline__ v2f bperm_pair(int src, v2f v) {
-    const unsigned long long bits = __builtin_bit_cast(unsigned long long, v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)bits);
-    const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)(unsigned)(bits >> 32));
-    return __builtin_bit_cast(v2f, ((unsigned long long)hi << 32) | lo);
+__device__ __forceinline__ void swap32(v2f& a, v2f& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const auto x = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+    const auto y = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+    a = mk2(__uint_as_float(x[0]), __uint_as_float(y[0]));
+    b = mk2(__uint_as_float(x[1]), __uint_as_float(y[1]));
+#endif
+}
+__device__ __forceinline__ void swap16(v2f& a, v2f& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const auto x = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+    const auto y = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+    a = mk2(__uint_as_float(x[0]), __uint_as_float(y[0]));
+    b = mk2(__uint_as_float(x[1]), __uint_as_float(y[1]));
+#endif
 }
 
 // INV: channel c sits at +c/64 turn per sample relative to channel 0, else -c/64.
@@ -78,10 +91,18 @@ __device__ __forceinline__ v2f bperm_pair(int src, v2f v) {
 // output time that the DFT does not cover: its tile part rides in A_c, its in-tile part depends on
 // (c0, n') only and is applied with the wave twiddle.
 // (M = 8: its 40-value window takes 80 VGPRs; 2 waves/SIMD without spills measured 10 % faster than 3 with a few)
-// ABL (diagnostic builds, profiles/r03_chan_tuning.txt): 1 = no global stores, 2 = no DMA (tiles are whatever lies in LDS), 8 = plain instead of non-temporal stores
+// ABL (diagnostic builds, profiles/r03_chan_tuning.txt): 1 = no global stores, 2 = no DMA (tiles are whatever lies in LDS), 8 = plain instead of non-temporal stores,
+// 4 = DMA requested but never waited for (timing of the landing wait; results wrong), 32 = every DMA read wrapped into a 16 MB window (reads served
+// from cache; results wrong).  (16 = the tile's stores in one burst behind the arithmetic was measured and removed: 2.39 -> 2.69 ms)
 // QF: 4 = all four tap rows present (193..256 taps: no per-row test in the accumulation), 0 = a.Q rows (run-time)
-template <bool INV, int M, int QF = 0, int ABL = 0>
-__global__ __launch_bounds__(256, 3) void chan_uniform_kernel(const ChanArgs a) {
+// WV: waves per workgroup (4).  (16 = one 1024-thread workgroup per CU holding all 160 KiB of LDS, 4 waves per SIMD at 128 VGPRs, was
+// measured in round 4: 2.36-2.39 ms against 2.23 at M = 8 -- a fourth wave per SIMD does not help this kernel.)
+// ST4 (round 4): 16-byte stores.  Neighbouring lanes (output times n', n' ^ 1) trade one result of each pair of groups, so a lane
+// writes two consecutive times of ONE channel: 8 store instructions per tile instead of 16 (and 16 hoisted 64-bit row addresses
+// fewer: 158 -> 124 VGPRs at M = 8).  Needs `out` 16-byte aligned and an even row stride (ChanArgs::st4); chan64m8 2.44 -> 2.21 ms.
+template <bool INV, int M, int QF = 0, int ABL = 0, int WV = 4, bool ST4 = false>
+__global__ __launch_bounds__(64 * WV, M == 64 ? 4 : 3) void chan_uniform_kernel(const ChanArgs a) {
+    constexpr int kStores = ST4 ? 8 : 16;            // store instructions of a full tile: what the landing wait of the next tile's DMA leaves in flight
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int t = threadIdx.x;
     const int P = a.P, Q = QF ? QF : a.Q;
@@ -90,7 +111,7 @@ __global__ __launch_bounds__(256, 3) void chan_uniform_kernel(const ChanArgs a) 
 
     if ((int)blockIdx.x == a.nwg) {
         // history for the next call: the last P samples of hist ++ in
-        for (int i = t; i < P; i += 256) {
+        for (int i = t; i < P; i += 64 * WV) {
             const long long g = a.count - P + i;
             a.hist_next[i] = g < 0 ? a.hist[g + P] : a.in[g];
         }
@@ -105,15 +126,15 @@ __global__ __launch_bounds__(256, 3) void chan_uniform_kernel(const ChanArgs a) 
     // Round 3: ONE twiddle per (c0, lane) instead of three factors: exp(+-j 2pi c0 sub / 64) (the split of the 64-point DFT),
     // exp(+-j 2pi c0 M n'/64) (oversampled plans) -- both 64th roots of unity, so their product is one entry of tw64 -- and
     // W(n') = exp(j M n' dphi_0), common to the four lanes of a quad and therefore free to move in front of the butterfly.
-    v2f* ptw = reinterpret_cast<v2f*>(lds + 4 * kChWaveLds);                  // [c0][lane], shared by the four waves
+    v2f* ptw = reinterpret_cast<v2f*>(lds + WV * kChWaveLds);                 // [c0][lane], shared by the workgroup's waves
     auto kSlot = [](int c) { return ((c & 15) << 2) | (c >> 4); };
     {
-        const int ln = t & 63, nql = ln >> 2, subl = ln & 3;
+        const int ln = t & 63, nql = ln & 15, subl = ln >> 4;
         const double2 wd = fx_phasor((unsigned long long)(M * nql) * a.dphase0);
         const v2f W = mk2((float)wd.x, (float)wd.y);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int c0 = (t >> 6) * 4 + k;
+        for (int k = 0; k < 16 / WV; k++) {
+            const int c0 = (t >> 6) * (16 / WV) + k;
             float2 w = a.tw64[(c0 * (subl + M * nql)) & 63];    // exp(-j 2pi m / 64); conjugated when INV
             if (INV) w.y = -w.y;
             ptw[c0 * 64 + ln] = pk_cmul2<false>(mk2(w.x, w.y), W);
@@ -124,7 +145,10 @@ __global__ __launch_bounds__(256, 3) void chan_uniform_kernel(const ChanArgs a) 
     // (workgroup -> tile in launch order: dealing consecutive tiles to the same XCD, so that neighbours'
     // 3 shared rows meet in one L2, measured 8 % SLOWER -- the 64 output rows are then written at 8
     // distant fronts instead of one)
-    const int gw = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wv), nwaves = a.nwg * 4;   // (scalar: the tile index feeds SGPR operands)
+    const int gw = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WV + wv), nwaves = a.nwg * WV;   // (scalar: the tile index feeds SGPR operands)
+    // tile -> wave: round-robin (wave gw takes tiles gw, gw + nwaves, ...).  (Round 4 measured a contiguous run of tiles per wave, so that a
+    // wave's successive spans overlap in L1/L2: 2.14 -> 2.49 ms at M = 8; profiles/r04_chan_tuning.txt.)
+    const int wt_first = gw, wt_step = nwaves, wt_end = a.ntiles;
     const long long tile_pos = (long long)kChT * M;                       // stream positions per tile
 
     // ---- branch role: lane = staged column p ------------------------------------------------------
@@ -135,13 +159,13 @@ __global__ __launch_bounds__(256, 3) void chan_uniform_kernel(const ChanArgs a) 
         g[q] = mk2(gq.x, gq.y);
     }
     const int mu = (l - P) & 63;
-    // ---- DFT role: lane = (n' = l >> 2, sub = l & 3) ------------------------------------------------
-    const int nq = l >> 2, sub = l & 3;
+    // ---- DFT role: lane = (sub = l >> 4, n' = l & 15) -----------------------------------------------
+    const int nq = l & 15, sub = l >> 4;
     const v2f* __restrict__ tw = ptw + l;               // entry c0 at tw[64 c0]
-    const int c1 = ((sub & 1) << 1) | (sub >> 1);    // radix-4 output this lane keeps (bit-reversed quad index)
-    const v2f sA = (sub & 2) ? mk2(-1.0f, -1.0f) : mk2(1.0f, 1.0f), sB = (sub & 1) ? mk2(-1.0f, -1.0f) : mk2(1.0f, 1.0f);
-    // between the two radix-2 stages lane 3 takes the -+j twiddle (the other lanes multiply by 1)
-    const v2f Mq = sub == 3 ? (INV ? mk2(0.0f, 1.0f) : mk2(0.0f, -1.0f)) : mk2(1.0f, 0.0f);
+    // After the two row exchanges (finish()) row r of the pair's first result register holds (group ka if r < 2 else kb, c1 = r & 1)
+    // and of the second (same group, c1 = 2 + (r & 1)); the odd rows' second radix-2 stage carries the -+j twiddle:
+    const int rowq = l >> 4;
+    const bool oddrow = (rowq & 1) != 0;
     // ---- channel role: lane = channel c ----------------------------------------------------------
     double2 corr, corr_step;
     {
@@ -150,10 +174,10 @@ __global__ __launch_bounds__(256, 3) void chan_uniform_kernel(const ChanArgs a) 
         const long long del = a.ddelta[l];                      // delta_c (tiny, signed)
         const long long sc = INV ? (long long)l : -(long long)l;
         const unsigned long long inc = a.dphase0 + (unsigned long long)del + ((unsigned long long)sc << 58);   // == dphase_c
-        const long long j0 = (long long)gw * tile_pos - P;
+        const long long j0 = (long long)wt_first * tile_pos - P;
         corr = fx_phasor(a.phase0 + a.dphi[l] + (unsigned long long)j0 * inc + (unsigned long long)(a.kcentre * del) +
                          ((unsigned long long)(sc * P) << 58));
-        corr_step = fx_phasor((unsigned long long)(tile_pos * nwaves) * inc);
+        corr_step = fx_phasor((unsigned long long)(tile_pos * wt_step) * inc);
     }
     const float theta_c = (float)((double)(a.ddelta[l] * (long long)M) * 3.4061215800865545e-19);   // 2pi / 2^64: exp(j theta_c) per output time
     const float gm1_c = a.gm1[l];
@@ -192,16 +216,26 @@ __global__ __launch_bounds__(256, 3) void chan_uniform_kernel(const ChanArgs a) 
     };
     auto request = [&](int wt) {
         const v2f* src = in + (span_start(wt) - lead(wt));
+        if (ABL & 32) src = in + ((span_start(wt) - lead(wt)) & ((1 << 21) - 2));   // (diagnostic: every read inside a 16 MB window -- cache-resident)
 #pragma unroll
         for (int k = 0; k < kStChunks; k++)
             if (!(ABL & 2)) dma16_to_lds(src + 128 * k, voff, lds_T + (unsigned)(128 * k) * 8u);
     };
+    // The per-lane constants loaded above are waited for HERE.  Left to hipcc the wait lands at their first use -- inside the tile
+    // loop, where it can only be `s_waitcnt vmcnt(0)`: every tile then began by waiting for the sixteen stores of the tile before
+    // it (round 4: the ISA of rounds 2-3 had exactly that wait at the loop header; chan64m8 2.39 -> see profiles/r04_chan_tuning.txt).
+    {
+        float touch = theta_c + gm1_c + (float)corr.x + (float)corr_step.x;
+#pragma unroll
+        for (int q = 0; q < 4; q++) touch += g[q].x + g[q].y;
+        asm volatile("" ::"v"(touch));
+    }
     bool requested = false, sixteen_younger = false;
-    if (kStaged && gw < a.ntiles && dma_ok(gw)) {
-        request(gw);
+    if (kStaged && wt_first < wt_end && dma_ok(wt_first)) {
+        request(wt_first);
         requested = true;
     }
-    for (int wt = gw; wt < a.ntiles; wt += nwaves) {
+    for (int wt = wt_first; wt < wt_end; wt += wt_step) {
         const long long n0 = (long long)wt * kChT;            // first output time of the tile
         const long long jb = n0 * M - P + l;                   // stream position of this lane's column in row 0
         const bool interior = jb - l >= 0 && jb - l + kSpan <= a.count;
@@ -220,7 +254,8 @@ __global__ __launch_bounds__(256, 3) void chan_uniform_kernel(const ChanArgs a) 
                 int soff = 0;
                 if (requested) {
                     soff = lead(wt);
-                    if (sixteen_younger) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // the DMA is older than the last tile's 16 stores
+                    if (ABL & 4) {}                                                             // (diagnostic: timing without the landing wait)
+                    else if (sixteen_younger) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kStores) : "memory");   // the DMA is older than the last tile's stores
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 } else {
                     constexpr int kStRows = (kSpan + 63) / 64;
@@ -280,11 +315,11 @@ __global__ __launch_bounds__(256, 3) void chan_uniform_kernel(const ChanArgs a) 
         for (int i = 0; i < 16; i++) U[i] = T[nq * kChRowT + sub + 4 * i];
         if constexpr (kStaged) {
             // T is free once every lane's reads above have returned: request the next tile's span into it
-            requested = dma_ok(wt + nwaves);
+            requested = wt + wt_step < wt_end && dma_ok(wt + wt_step);
             if (requested) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
-                request(wt + nwaves);
+                request(wt + wt_step);
             }
         }
         pk_fft16<INV>(U);                            // over i -> group c0 at U[rev16(c0)]
@@ -292,29 +327,28 @@ __global__ __launch_bounds__(256, 3) void chan_uniform_kernel(const ChanArgs a) 
         const long long j = nn * M - P + a.kcentre;                  // window-centre position of this output
         const float jm = (float)(int)(j & 511);
         const float fl = (float)nq;
-        // Stores: in the DFT layout the four lanes of a quad hold four different channels (rows 16 apart in memory),
-        // so one store instruction touched 64 separate 32-byte pieces and the L1 tag pipeline, not HBM, set the pace
-        // (PMC: TCP busy for the whole kernel, 64 cache accesses per store).  One ds_bpermute pair transposes the wave
-        // to lane = 16 b + n': 16 neighbouring lanes then write one whole 128-byte line of channel c0 + 16 c1(b).
-        const int tsrc = (((l & 15) << 2) | (l >> 4)) << 2;          // byte index of the source lane 4 n' + b
-        const int c1s = (((l >> 4) & 1) << 1) | (l >> 5);              // c1 of the source lane's sub = b
-        v2f* __restrict__ o = reinterpret_cast<v2f*>(a.out) + n0 + (l & 15) + (size_t)(16 * c1s) * a.out_stride;
-        const bool live = n0 + (l & 15) < a.nout;
+        // Stores: row r of a result register is one channel at the tile's 16 consecutive times, so one store instruction writes
+        // four whole 128-byte lines (rounds 2-3 transposed the wave with ds_bpermute to get there; the very first version
+        // scattered 64 separate 8-byte pieces per store and the L1 tag pipeline, not HBM, set the pace).
+        // Per-lane bases are formed HERE, per tile, from an opaque copy of the lane index; the rows of a pair are then a wave-uniform
+        // offset away.  (Left visible, hipcc hoists all sixteen 64-bit row addresses out of the tile loop: 32 VGPRs, the fourth wave.)
+        int lop = l;
+        asm volatile("" : "+v"(lop));
+        const int nq_a = lop & 15, rowq_a = lop >> 4;
+        const int grp = rowq >> 1;                                     // 0: the pair's first group (ka), 1: its second (kb)
+        v2f* __restrict__ o = reinterpret_cast<v2f*>(a.out) + n0 + nq_a + (size_t)(16 * (rowq_a & 1) + (rowq_a >> 1)) * a.out_stride;
+        // ST4: the even lane writes times (n', n' + 1) of the pair's FIRST result's channel, the odd lane (n' - 1, n') of the SECOND's (32 rows on)
+        v2f* __restrict__ o4 = o + ((nq_a & 1) ? (size_t)32 * a.out_stride - 1 : (size_t)0);
+        const bool live = n0 + nq < a.nout;
         // (two copies of the loop: in the full-tile one nothing depends on `live`, so the compiler keeps
-        // it one basic block and overlaps the table reads / DPP hazards of neighbouring groups)
+        // it one basic block and overlaps the table reads of neighbouring groups)
         // `quad`: keep the -ang^2/2 term of B_c(n') = exp(j n' theta_c) (host: only when 15 max|theta_c| > 1e-4: float-rounded
         // uniform plans have theta ~ 1e-7 and the term is < 1e-12)
         auto finish = [&](auto guarded, auto quad) {
-#pragma unroll
-            for (int c0 = 0; c0 < 16; c0++) {
-                v2f z = U[rev16(c0)];
-                z = pk_cmul2<false>(z, tw[64 * c0]);
-                // stage A: pairs (sub, sub^2), then lane 3's -+j twiddle ; stage B: pairs (sub, sub^1)
-                v2f ta = pk_fma(z, sA, dpp_quad<0x4E>(z));
-                ta = pk_cmul2<false>(ta, Mq);
-                const v2f y = pk_fma(ta, sB, dpp_quad<0xB1>(ta));
+            // y (the DFT output of this lane's channel) -> rot_c(n') y, stored at row `cs` (channel) of the output
+            auto rot_store = [&](v2f y, int slot, size_t row_off) -> v2f {
                 // A_c(tile), B_c(n') and VOLK's magnitude sawtooth
-                const float4 A = tab[4 * c0 + c1];
+                const float4 A = tab[slot];
                 const v2f v = pk_cmul2<false>(y, mk2(A.x, A.y));
                 v2f r;
                 if constexpr (decltype(quad)::value) {
@@ -328,14 +362,43 @@ __global__ __launch_bounds__(256, 3) void chan_uniform_kernel(const ChanArgs a) 
                     // v + g1 v + ang (j v) -- one packed multiply for (ang, g1) and two packed FMAs
                     const v2f t2 = mk2(fl, jm) * mk2(A.z, A.w);                      // (ang, g1)
                     r = pk_fma(v, t2.yy, v);
-                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[1,0,0]" : "+v"(r) : "v"(v), "v"(t2));
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[1,0,0]" : "+&v"(r) : "v"(v), "v"(t2));
                 }
-                const v2f rt = bperm_pair(tsrc, r);
-                if (ABL & 1) { if (rt.x == 1.2345e30f) o[(size_t)c0 * a.out_stride] = rt; }
-                else if (ABL & 8) { if (!decltype(guarded)::value || live) o[(size_t)c0 * a.out_stride] = rt; }
+                if (ST4 && !decltype(guarded)::value) return r;
+                if (ABL & 1) { if (r.x == 1.2345e30f) o[row_off] = r; }
+                else if (ABL & 8) { if (!decltype(guarded)::value || live) o[row_off] = r; }
                 // results are written once and never read here: non-temporal stores (round 3, interleaved A/B on one box: M = 64
                 // 0.4068 -> 0.3846 ms per 2^27 samples, M = 8 2.424 -> 2.394; profiles/r03_chan_tuning.txt)
-                else if (!decltype(guarded)::value || live) __builtin_nontemporal_store(rt, o + (size_t)c0 * a.out_stride);
+                else if (!decltype(guarded)::value || live) __builtin_nontemporal_store(r, o + row_off);
+                return r;
+            };
+#pragma unroll
+            for (int kp = 0; kp < 8; kp++) {
+                const int ka = 2 * kp, kb = 2 * kp + 1;                // the two groups c0 of this pair
+                v2f za = pk_cmul2<false>(U[rev16(ka)], tw[64 * ka]);
+                v2f zb = pk_cmul2<false>(U[rev16(kb)], tw[64 * kb]);
+                // first radix-2 stage, rows (sub, sub ^ 2):  za = [a sub 0 1 | b sub 0 1],  zb = [a sub 2 3 | b sub 2 3]
+                swap32(za, zb);
+                v2f e = za + zb, d = za - zb;                          // rows: [E_a[0], E_a[1], E_b[0], E_b[1]] and the same of O
+                // second stage, rows (s', s' ^ 1):  e = [E_a[0], O_a[0], E_b[0], O_b[0]],  d = [E_a[1], O_a[1], E_b[1], O_b[1]]
+                swap16(e, d);
+                const v2f dj = pk_mulj<INV>(d);
+                const v2f wd = oddrow ? dj : d;                        // odd rows (the O halves): * -+j
+                const v2f y0 = e + wd, y1 = e - wd;                    // rows: (a, c1 0), (a, c1 1), (b, 0), (b, 1)  and  (a, 2), (a, 3), (b, 2), (b, 3)
+                // this lane's channel: group g = grp ? kb : ka, c1 = (rowq & 1) [+ 2 for y1]; table slot 4 g + c1 (kSlot)
+                const int g = grp ? kb : ka;
+                const v2f r0 = rot_store(y0, 4 * g + (rowq & 1), (size_t)ka * a.out_stride);
+                const v2f r1 = rot_store(y1, 4 * g + 2 + (rowq & 1), (size_t)(ka + 32) * a.out_stride);
+                if (ST4 && !decltype(guarded)::value) {
+                    // 16-byte stores: neighbouring lanes (times n', n' ^ 1) trade one result each -- the even lane ends up with times
+                    // (n', n' + 1) of r0's channel, the odd lane with (n' - 1, n') of r1's -- one store instruction = eight 128-byte runs
+                    const bool odd = (nq & 1) != 0;
+                    const v2f send = odd ? r0 : r1, own = odd ? r1 : r0;
+                    const v2f got = dpp_pair<0xB1>(send);                     // quad_perm [1,0,3,2]: the lane's neighbour n' ^ 1
+                    const v2f lo2 = odd ? got : own, hi2 = odd ? own : got;
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store((v4f){lo2.x, lo2.y, hi2.x, hi2.y}, reinterpret_cast<v4f*>(o4 + (size_t)ka * a.out_stride));
+                }
             }
         };
         if (n0 + kChT <= a.nout) {
@@ -352,26 +415,34 @@ __global__ __launch_bounds__(256, 3) void chan_uniform_kernel(const ChanArgs a) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-size_t chan_uniform_lds_bytes() { return (size_t)(4 * kChWaveLds + 16 * 64) * sizeof(float2); }   // + the [c0][lane] twiddles
+size_t chan_uniform_lds_bytes(int waves) { return (size_t)(waves * kChWaveLds + 16 * 64) * sizeof(float2); }   // + the [c0][lane] twiddles
 
 int launch_chan_uniform(const ChanArgs& a, int grid, hipStream_t stream) {
-    const size_t lds_bytes = chan_uniform_lds_bytes();
+    const size_t lds_bytes = chan_uniform_lds_bytes(a.waves);
+#define QK_CHAN2(m, q, st)                                                                                               \
+    do {                                                                                                                 \
+        if (a.inv) hipLaunchKernelGGL((chan_uniform_kernel<true, m, q, 0, 4, st>), dim3(grid), dim3(256), lds_bytes, stream, a);   \
+        else hipLaunchKernelGGL((chan_uniform_kernel<false, m, q, 0, 4, st>), dim3(grid), dim3(256), lds_bytes, stream, a);        \
+    } while (0)
 #define QK_CHAN(m)                                                                                                     \
     case m:                                                                                                            \
         if (a.Q == 4) {                                                                                                \
-            if (a.inv) hipLaunchKernelGGL((chan_uniform_kernel<true, m, 4>), dim3(grid), dim3(256), lds_bytes, stream, a);   \
-            else hipLaunchKernelGGL((chan_uniform_kernel<false, m, 4>), dim3(grid), dim3(256), lds_bytes, stream, a);        \
+            if (a.st4) QK_CHAN2(m, 4, true);                                                                           \
+            else QK_CHAN2(m, 4, false);                                                                                \
         } else {                                                                                                       \
-            if (a.inv) hipLaunchKernelGGL((chan_uniform_kernel<true, m, 0>), dim3(grid), dim3(256), lds_bytes, stream, a);   \
-            else hipLaunchKernelGGL((chan_uniform_kernel<false, m, 0>), dim3(grid), dim3(256), lds_bytes, stream, a);        \
+            if (a.st4) QK_CHAN2(m, 0, true);                                                                           \
+            else QK_CHAN2(m, 0, false);                                                                                \
         }                                                                                                              \
         break;
-#if QDSP_HIP_DIAG   // (make DIAG=1: the ablation builds behind profiles/r03_chan_tuning.txt)
+#if QDSP_HIP_DIAG   // (make DIAG=1: the ablation builds behind profiles/r03_chan_tuning.txt, r04_chan_tuning.txt)
     if (a.abl && a.M == 8 && !a.inv && a.Q == 4) {
-        if (a.abl == 1) hipLaunchKernelGGL((chan_uniform_kernel<false, 8, 4, 1>), dim3(grid), dim3(256), lds_bytes, stream, a);
-        else if (a.abl == 2) hipLaunchKernelGGL((chan_uniform_kernel<false, 8, 4, 2>), dim3(grid), dim3(256), lds_bytes, stream, a);
-        else if (a.abl == 8) hipLaunchKernelGGL((chan_uniform_kernel<false, 8, 4, 8>), dim3(grid), dim3(256), lds_bytes, stream, a);
-        else hipLaunchKernelGGL((chan_uniform_kernel<false, 8, 4, 3>), dim3(grid), dim3(256), lds_bytes, stream, a);
+        switch (a.abl) {
+#define QK_ABL(n) case n: if (a.st4) hipLaunchKernelGGL((chan_uniform_kernel<false, 8, 4, n, 4, true>), dim3(grid), dim3(256), lds_bytes, stream, a); \
+                          else hipLaunchKernelGGL((chan_uniform_kernel<false, 8, 4, n, 4, false>), dim3(grid), dim3(256), lds_bytes, stream, a); break;
+            QK_ABL(1) QK_ABL(2) QK_ABL(3) QK_ABL(4) QK_ABL(8) QK_ABL(32) QK_ABL(33)
+#undef QK_ABL
+            default: return -1;
+        }
         const hipError_t e = hipGetLastError();
         return e == hipSuccess ? 0 : -(int)e;
     }
@@ -386,6 +457,7 @@ int launch_chan_uniform(const ChanArgs& a, int grid, hipStream_t stream) {
         default: return -1;
     }
 #undef QK_CHAN
+#undef QK_CHAN2
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
 }

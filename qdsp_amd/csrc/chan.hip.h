@@ -18,8 +18,10 @@ struct ChanArgs {
     int Q;                     // ceil(ntaps / 64) <= 4
     int M;                     // decimation: 64 (critically sampled) or 8 / 16 / 32 (oversampled)
     int ntiles;                // wave tiles of 16 output times: ceil(nout / 16)
-    int nwg;                   // persistent workgroups of 4 independent waves (grid = nwg + 1: the last hands over history)
+    int nwg;                   // persistent workgroups of `waves` independent waves (grid = nwg + 1: the last hands over history)
+    int waves;                 // waves per workgroup: 4 (256 threads)
     int kcentre;               // tap index the per-channel deviation is evaluated at ((ntaps-1)/2)
+    int st4;                   // 1: `out` is 16-byte aligned and out_stride even: full tiles are written with 16-byte stores
     int abl;                   // diagnostic builds only (QDSP_HIP_CHAN_ABL): ablation mask, 0 = the product
     int quad;                  // 1: keep the second-order term of the per-output deviation rotation (15 max|theta_c| > 1e-4)
     int inv;                   // 1: channel spacing +1/64 turn/sample, 0: -1/64
@@ -29,7 +31,7 @@ struct ChanArgs {
     float gm1[64];                 // |phase_inc_c| - 1 (VOLK magnitude sawtooth), 0 = off
 };
 
-size_t chan_uniform_lds_bytes();
+size_t chan_uniform_lds_bytes(int waves);
 int launch_chan_uniform(const ChanArgs& a, int grid, hipStream_t stream);
 
 }  // namespace qk

@@ -97,8 +97,10 @@ int chan_launch_uniform(Chan* c, const void* d_in, int64_t count, int64_t nout, 
     a.Q = (c->ntaps + 63) / 64;
     a.M = c->decim;
     a.ntiles = (int)((nout + 15) / 16);
+    a.st4 = ((reinterpret_cast<uintptr_t>(d_out) & 15) == 0 && (out_stride & 1) == 0 && !qk::knob(qk::K_CHAN_NO_ST4, 0)) ? 1 : 0;
+    a.waves = 4;
     int nwg = 256 * qk::knob(qk::K_CHAN_WG_PER_CU, 48);  // 3 resident per CU, 16 rounds (round 3: 12 -> 48: -2 %, profiles/r03_chan_tuning.txt)
-    if (nwg > (a.ntiles + 3) / 4) nwg = (a.ntiles + 3) / 4;
+    if (nwg > (a.ntiles + a.waves - 1) / a.waves) nwg = (a.ntiles + a.waves - 1) / a.waves;
     if (nwg < 1) nwg = 1;
     a.nwg = nwg;
     a.kcentre = (c->ntaps - 1) / 2;
@@ -114,14 +116,14 @@ int chan_launch_uniform(Chan* c, const void* d_in, int64_t count, int64_t nout, 
         a.quad = 15.0 * (double)dmax * (double)a.M * 3.4061215800865545e-19 > 1e-4 || qk::knob(qk::K_CHAN_QUAD, 0);
     }
     a.abl = qk::knob(qk::K_CHAN_ABL, 0);
-    const size_t lds = qk::chan_uniform_lds_bytes();
+    const size_t lds = qk::chan_uniform_lds_bytes(a.waves);
     int rc = qk::launch_chan_uniform(a, nwg + 1, s);
     if (rc) return rc;
     c->cur ^= 1;
     for (int i = 0; i < 64; i++) c->vfo[i]->phase += (unsigned long long)count * c->vfo[i]->dphase;
     c->last.name = "chan_uniform_kernel";
     c->last.grid = nwg + 1;
-    c->last.block = 256;
+    c->last.block = 64 * a.waves;
     c->last.lds = (int)lds;
     return 0;
 }

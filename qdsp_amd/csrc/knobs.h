@@ -13,7 +13,7 @@ namespace qk {
 #define QDSP_HIP_KNOBS(X) \
     X(ANY_MIN_SPLIT_TILE) X(ANY_NO_LDS_TAPS) X(ANY_NO_PAD) X(ANY_NO_SPLIT) X(ANY_NO_XCD) X(ANY_SMALL_CALL_TILES) \
     X(ANY_SPLIT_MIN_TAPS) X(ANY_TILE) X(ANY_WG_PER_CU) X(CHAN_ABL) X(CHAN_BATCH_MAX_COUNT) X(CHAN_QUAD) \
-    X(CHAN_WG_PER_CU) X(CORE_MAX_DECIM) X(DIRECT_OUT_MAX_BYTES) X(FFT1K_MAX_COUNT) X(FFT_ABL) X(FFT_DMA) \
+    X(CHAN_NO_ST4) X(CHAN_WG_PER_CU) X(CORE_MAX_DECIM) X(DIRECT_OUT_MAX_BYTES) X(FFT1K_MAX_COUNT) X(FFT_ABL) X(FFT_DMA) \
     X(FFT_GROUP_MIN_UNITS) X(FFT_MIN_COUNT) X(FFT_MIN_TAPS) X(FFT_MIN_TAPS_DECIM) X(FFT_MIN_TAPS_REAL) \
     X(FFT_MIN_TAPS_SMALL) X(FFT_NOVEC) X(FFT_NT) X(FFT_PRUNE2_MAX_COUNT) X(FFT_WG_PER_CU) X(FIR_LAT_MAX_WORK) X(FIR_MODE) X(FORCE_ANY) \
     X(MF_BATCH_MIN_WORK) X(MF_DEPTH) X(MF_MIN_COUNT) X(MF_MIN_DECIM) X(MF_NO_KEEP2) X(MF_NO_QS2) X(MF_TASKS) \

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Register / scratch usage of every gfx950 kernel the library ships, from hipcc's own remarks.
 
-    python scripts/resource_usage.py            # writes profiles/r03_resource_usage.txt
+    python scripts/resource_usage.py            # writes profiles/r04_resource_usage.txt
 
 Each translation unit of qdsp_amd/csrc is compiled (device side only, no GPU needed) with
 -Rpass-analysis=kernel-resource-usage and the flags the Makefile builds it with; the table lists, per kernel instantiation:
@@ -16,7 +16,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "qdsp_amd", "csrc")
-OUT = os.path.join(ROOT, "profiles", "r03_resource_usage.txt")
+OUT = os.path.join(ROOT, "profiles", "r04_resource_usage.txt")
 UNITS = {"qdsp_hip": "", "chan_ops": "", "misc_ops": "", "fft_fir": "-fno-slp-vectorize", "fft1k_fir": "-fno-slp-vectorize", "chan": "-fno-slp-vectorize",
          "pfb_dec": "-fno-slp-vectorize", "mf_dec": "", "rm_resamp": "", "fir_lat": ""}
 

@@ -104,7 +104,7 @@ def test_bench_starts_its_own_ranks_before_touching_the_gpu(monkeypatch):
 
 
 def test_no_kernel_uses_scratch():
-    """profiles/r03_resource_usage.txt (scripts/resource_usage.py: hipcc's kernel-resource-usage remarks for every kernel instantiation
+    """profiles/r04_resource_usage.txt (scripts/resource_usage.py: hipcc's kernel-resource-usage remarks for every kernel instantiation
     of the shipped library) was made from the sources as they are now, and no kernel has scratch memory or spilled VGPRs
     (ten instantiations spilled)."""
     import importlib.util

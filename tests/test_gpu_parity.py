@@ -674,6 +674,44 @@ def test_channelizer_64_channels(ops, gold, dec):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("dec", [8, 16, 32, 64])
+def test_channelizer_store_forms_agree_bit_for_bit(ops, gold, dec, monkeypatch):
+    """Round 4: full tiles are written with 16-byte stores (neighbouring lanes trade one result each) whenever the output is
+    16-byte aligned with an even row stride; QDSP_HIP_CHAN_NO_ST4=1 keeps the 8-byte form, which misaligned outputs take on
+    their own.  Same arithmetic, so the two must agree in every bit -- on aligned rows, on rows of odd stride (8-byte form
+    either way) and when the last tile of a call is partial."""
+    import torch
+
+    from qdsp_amd import capi
+
+    taps = gold["taps256"]
+    incs = [ops.phase_delta(1.0, -(c - 31.5) / 64) for c in range(64)]
+    n = dec * (16 * 200 + 7)                                  # 200 full tiles + a partial one
+    x = dev(O.synth_iq(0, n, seed=4100 + dec))
+    outs = {}
+    for st4 in (1, 0):
+        for pad in (32, 33):                                  # even / odd row stride
+            if st4:
+                monkeypatch.delenv("QDSP_HIP_CHAN_NO_ST4", raising=False)
+            else:
+                monkeypatch.setenv("QDSP_HIP_CHAN_NO_ST4", "1")
+            capi.reload_env()
+            ch = ops.Channelizer(taps, 1, dec, incs, max_block=0)
+            out = torch.full((64, n // dec + pad), 7.0 + 7.0j, dtype=torch.complex64, device="cuda")
+            ch.process(x, out)
+            torch.cuda.synchronize()
+            assert kname(ch) == "chan_uniform_kernel"
+            o = out.cpu().numpy()
+            assert np.all(o[:, n // dec:] == 7.0 + 7.0j)      # nothing written past a row's data
+            outs[(st4, pad)] = o[:, : n // dec]
+            ch.close()
+    monkeypatch.delenv("QDSP_HIP_CHAN_NO_ST4", raising=False)
+    capi.reload_env()
+    ref = outs[(0, 32)]
+    for k, o in outs.items():
+        assert np.array_equal(o.view(np.uint32), ref.view(np.uint32)), k
+
+
 @pytest.mark.parametrize("dec", [8, 32, 64])
 def test_channelizer_small_and_ragged_blocks(ops, gold, dec):
     """Blocks shorter than one wave tile (16 output times x dec samples + 256 of window), an empty block, and
