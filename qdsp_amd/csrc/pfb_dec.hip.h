@@ -30,7 +30,7 @@ constexpr int kPfbF = 512;        // transform length per column
 constexpr int kPfbSeg = 4096;     // input samples per segment
 constexpr int kPfbNT = 256;       // 4 waves per workgroup, each on its own segments
 constexpr int kPfbRow = 10;       // LDS / table row pitch in complex values (80 B: 16-byte aligned, conflict-free, see pfb_dec.hip)
-constexpr int kPfbMaxQ = 128;     // taps per column the dispatch accepts (>= 385 valid outputs per 512)
+constexpr int kPfbMaxQ = 136;     // taps per column the dispatch accepts (>= 377 valid outputs per 512; 1024 taps at decimation 4 need 129)
 
 struct PfbArgs {
     const float2* in;

@@ -7,7 +7,14 @@
 //   graph_check fir    <in.cf32> <out.cf32> <block> <taps.f32>
 //   graph_check fir63  <in.cf32> <out.cf32> <block>   BlackmanWindow(0.1 fs, 4 fs/63, fs=1)
 //   graph_check firf   <in.f32>  <out.f32>  <block> <taps.f32>          (FIR<float>)
+//   graph_check firrrc <in.cf32> <out.cf32> <block> <tapCount> <sampleRate> <baudRate> <alpha>
+//                      FIR<complex_t>(RRCTaps): the matched filter of the reference's PSKDemod (demodulator.h:586-587); an EVEN
+//                      tapCount makes RRCTaps design tapCount + 1 taps (window.h:183) of which the FIR keeps the first tapCount
+//   graph_check firbp  <in.f32>  <out.f32>  <block> <cutoff> <transWidth> <offset> <sampleRate>
+//                      FIR<float>(BlackmanBandpassWindow): the pilot filter of the reference's StereoFMDemod (demodulator.h:216-217)
 //   graph_check resamp <in.cf32> <out.cf32> <block> <inSR> <outSR> <cutoff> <trans>
+//   graph_check resampst <in.cf32> <out.cf32> <block> <inSR> <outSR> <cutoff> <trans>
+//                      the same through PolyphaseResampler<stereo_t> (resampling.h:120: a float pair with real taps)
 //   graph_check xlate  <in.cf32> <out.cf32> <block> <sampleRate> <freq>
 //   graph_check vfo    <in.cf32> <out.cf32> <block> <offset> <inSR> <outSR> <bw>
 //   graph_check wavfir <in.wav>  <out.cf32> <block>   config 1: int16 IQ WAV -> 63-tap FIR
@@ -377,6 +384,19 @@ int main(int argc, char** argv) {
     if (mode == "firf" && argc >= 6) {
         FileTaps taps(argv[5]);
         return runGraph<float>(in, out, block, [&](stream<float>* s) { return new FIR<float>(s, &taps); });
+    }
+    if (mode == "firrrc" && argc >= 9) {
+        RRCTaps rrc(atoi(argv[5]), (float)atof(argv[6]), (float)atof(argv[7]), (float)atof(argv[8]));
+        return runGraph<complex_t>(in, out, block, [&](stream<complex_t>* s) { return new FIR<complex_t>(s, &rrc); });
+    }
+    if (mode == "firbp" && argc >= 9) {
+        filter_window::BlackmanBandpassWindow bp((float)atof(argv[5]), (float)atof(argv[6]), (float)atof(argv[7]), (float)atof(argv[8]));
+        return runGraph<float>(in, out, block, [&](stream<float>* s) { return new FIR<float>(s, &bp); });
+    }
+    if (mode == "resampst" && argc >= 9) {
+        filter_window::BlackmanWindow win((float)atof(argv[7]), (float)atof(argv[8]), (float)atof(argv[5]));
+        const float inSR = (float)atof(argv[5]), outSR = (float)atof(argv[6]);
+        return runGraph<stereo_t>(in, out, block, [&](stream<stereo_t>* s) { return new PolyphaseResampler<stereo_t>(s, &win, inSR, outSR); });
     }
     if (mode == "resamp" && argc >= 9) {
         filter_window::BlackmanWindow win((float)atof(argv[7]), (float)atof(argv[8]), (float)atof(argv[5]));

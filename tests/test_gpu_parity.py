@@ -317,8 +317,7 @@ def test_polyphase_overlap_save_decimator_vs_oracle(ops, monkeypatch, ntaps, rot
     8192 samples."""
     import torch
 
-    if dec == 4 and ntaps == 1024:
-        pytest.skip("129 taps per column with the odd outputs' delay: one past the kernel's range (kPfbMaxQ)")
+    # (dec 4, 1024 taps: 129 taps per column with the odd outputs' delay -- kPfbMaxQ was 128 until round 4 and these two cases were skipped)
     monkeypatch.setenv("QDSP_HIP_PFB_MIN_COUNT", "0")
     taps = O.lowpass_taps_f64(ntaps, 0.5 / dec).astype(np.float32) if ntaps > 8 else np.arange(1, ntaps + 1, dtype=np.float32)
     x = O.synth_iq(0, 500_000, seed=800 + ntaps)
@@ -550,6 +549,28 @@ def test_xlator_long_stream_exact_phase(ops):
     w3 = O.Xlator(48000.0, -7000.0, exact=True, volk_gain=True).process(x[1:10_001])
     assert np.abs(y3 - w3).max() < 6e-7
     torch.cuda.synchronize()
+
+
+def test_xlator_deviation_from_the_reference_recursion_is_the_references_own_drift(ops):
+    """The documented NCO deviation (INTEGRATION.md "NCO", SURVEY H2) as numbers, on the stream tests/test_oracle.py::
+    test_rotator_drift_vs_exact uses (fs 48 kHz, f -7 kHz, 1e6 samples of ones, one call).  The reference's FrequencyXlator
+    (processing.h:64) is VOLK's RECURSIVE float phasor; the device NCO is an exact 64-bit phase with VOLK's magnitude sawtooth.
+    So against the recursion the device output differs by 1e-3 .. 5e-2 after 1e6 samples -- and that difference IS the
+    recursion's own drift from the exact phase: device-vs-recursion equals exact-vs-recursion sample for sample to the 6e-7
+    the device holds against the exact yardstick.  Inside the first 4096 samples all three agree to 1e-5 (the north_star bar)."""
+    n = 1_000_000
+    x = np.ones(n, np.complex64)
+    y = ops.Xlator(48000.0, -7000.0).process(dev(x)).cpu().numpy()
+    rec = O.Xlator(48000.0, -7000.0).process(x)                                   # what a qdsp user's CPU emits (VOLK generic)
+    exact = O.Xlator(48000.0, -7000.0, exact=True, volk_gain=True).process(x)     # the FP64-phase yardstick
+    dev_vs_rec, ref_drift = np.abs(y - rec), np.abs(exact - rec)
+    assert np.abs(y - exact).max() < 6e-7
+    assert dev_vs_rec[:4096].max() < 1e-5
+    assert 1e-3 < dev_vs_rec.max() < 5e-2                                         # the same window test_oracle.py pins for the reference
+    assert np.abs(dev_vs_rec - ref_drift).max() < 6e-7                            # ... and it is that drift, nothing else
+    # the drift is phase, not magnitude: |y| and |rec| stay within 2e-5 of each other over the whole stream (each within 1e-5 of 1:
+    # the renormalised recursion's magnitude error and the emulated sawtooth are both of that size), 100x below the phase drift
+    assert np.abs(np.abs(y) - np.abs(rec)).max() < 2e-5
 
 
 # ------------------------------------------------------------------------------ fused VFO

@@ -153,6 +153,46 @@ def test_graph_resampler_xlator_vfo(harness, data):
 
 
 @gpu
+def test_graph_callers_filter_setups(harness, data):
+    """The filter set-ups of the reference's own callers, through the GPU graph (missing #3 / #4):
+    * FIR<complex_t> fed by RRCTaps (PSKDemod's matched filter, demodulator.h:586-587) -- with an EVEN requested tap count, where
+      RRCTaps::createTaps does `tapCount |= 1` (window.h:183) and designs tapCount + 1 taps, normalised over all of them, of which
+      the FIR (tapCount = getTapCount(), filter.h:24-26) uses the first tapCount; the odd case beside it;
+    * FIR<float> fed by BlackmanBandpassWindow (StereoFMDemod's 19 kHz pilot filter, demodulator.h:216-217);
+    * PolyphaseResampler<stereo_t> (resampling.h:120: the complex kernel on a float pair)."""
+    d, x = data
+    for n_req in (32, 31):
+        run([harness, "firrrc", str(d / "x.cf32"), str(d / "yrrc.cf32"), "4096", str(n_req), "4", "1", "0.35"])
+        y = np.fromfile(d / "yrrc.cf32", dtype=np.complex64)
+        taps = O.rrc_taps(n_req | 1, 4.0, 1.0, 0.35)[:n_req]       # what the reference's createTaps leaves in taps[0 .. n_req)
+        assert len(taps) == n_req
+        assert np.array_equal(y, blocks(O.Fir(taps, acc=O.ACC_FMA), x, 4096)), n_req       # small blocks: direct form, bit-exact
+        run([harness, "firrrc", str(d / "x.cf32"), str(d / "yrrc2.cf32"), "100000", str(n_req), "4", "1", "0.35"])
+        y2 = np.fromfile(d / "yrrc2.cf32", dtype=np.complex64)
+        assert rel_rms(y2, O.Fir(taps, acc=O.ACC_F64).process(x)) < 2e-6, n_req
+    # pilot filter: BlackmanBandpassWindow(cutoff 300, trans 100, offset 19000, 48000) on a real stream
+    xr = np.ascontiguousarray(x.real)
+    nbp = O.blackman_tap_count(300.0, 100.0, 48000.0)
+    tbp = O.blackman_bandpass_taps(300.0, 19000.0, 48000.0, nbp)
+    for blk in (1000, 50000):
+        run([harness, "firbp", str(d / "x.f32"), str(d / "ybp.f32"), str(blk), "300", "100", "19000", "48000"])
+        ybp = np.fromfile(d / "ybp.f32", dtype=np.float32)
+        want = blocks(O.Fir(tbp, complex_data=False, acc=O.ACC_F64), xr, blk)
+        # (1919 taps: a k-ordered FP32 sum of that length sits near 1e-6 of the FP64 value by itself)
+        assert nbp == 1919 and len(ybp) == len(want) and rel_rms(ybp, want) < 5e-6, (blk, rel_rms(ybp, want))
+    # PolyphaseResampler<stereo_t>(BlackmanWindow(12k, 6k, 48k), 48k -> 32k): (l, r) pairs == (re, im) pairs
+    b = 50_000
+    run([harness, "resampst", str(d / "x.cf32"), str(d / "yst.cf32"), str(b), "48000", "32000", "12000", "6000"])
+    yst = np.fromfile(d / "yst.cf32", dtype=np.complex64)
+    L, M = O.resamp_ratio(48000.0, 32000.0)
+    n = O.blackman_tap_count(12000.0, 6000.0, 48000.0)
+    want = blocks(O.Resampler(O.blackman_taps(12000.0, 48000.0, n, factor=float(L)), L, M), x, b)
+    assert len(yst) == len(want) and rel_rms(yst, want) < 2e-6
+    run([harness, "resamp", str(d / "x.cf32"), str(d / "ycx.cf32"), str(b), "48000", "32000", "12000", "6000"])
+    assert np.array_equal(yst, np.fromfile(d / "ycx.cf32", dtype=np.complex64))      # same kernel, same bits
+
+
+@gpu
 def test_graph_wav_config1(harness, tmp_path):
     """BASELINE configs[0]: 16-bit stereo (I,Q) WAV -> 63-tap lowpass FIR (SURVEY 8d config 1:
     two tones + uniform noise, mt19937(1234), 2.4 Msps, 2^20 frames, blocks of 65536)."""
