@@ -231,7 +231,9 @@ static int streamSelfTest() {
         filter_window::BlackmanWindow w(0.1f, 4.0f / 63.0f, 1.0f);
         if (w.getTapCount() != 63) { printf("FAIL tap count %d\n", w.getTapCount()); return 1; }
     }
-    static_assert(STREAM_BUFFER_SIZE == 1000000, "stream capacity is part of the contract");
+#ifndef QDSP_GRAPH_CHECK_BIG_BLOCKS
+    static_assert(STREAM_BUFFER_SIZE == 1000000, "stream capacity is part of the contract (src/dsp/stream.h:7)");
+#endif
     printf("stream/block self-test ok\n");
     return 0;
 }

@@ -18,7 +18,7 @@ BIN = os.path.join(HOST, "build", "graph_check")
 
 @pytest.fixture(scope="module")
 def harness():
-    if not os.path.exists(BIN) or not os.path.exists(os.path.join(os.path.dirname(BIN), "patch_b_fir")):
+    if not all(os.path.exists(os.path.join(os.path.dirname(BIN), b)) for b in ("graph_check", "graph_check_big", "patch_b_fir")):
         subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL, timeout=300)
     return BIN
 
@@ -190,6 +190,31 @@ def test_graph_callers_filter_setups(harness, data):
     assert len(yst) == len(want) and rel_rms(yst, want) < 2e-6
     run([harness, "resamp", str(d / "x.cf32"), str(d / "ycx.cf32"), str(b), "48000", "32000", "12000", "6000"])
     assert np.array_equal(yst, np.fromfile(d / "ycx.cf32", dtype=np.complex64))      # same kernel, same bits
+
+
+@gpu
+def test_graph_with_larger_stream_buffers(harness, tmp_path):
+    """STREAM_BUFFER_SIZE is a build-time choice of the graph (dsp/stream.h; the reference's 1e6, src/dsp/stream.h:7, is the default):
+    the same harness compiled with -DSTREAM_BUFFER_SIZE=16777216 hands 4 000 000-sample blocks to the library -- one call of the
+    chip-filling kernels instead of four latency-bound ones -- and the results still follow the oracle fed the same blocks."""
+    big = os.path.join(os.path.dirname(harness), "graph_check_big")
+    n, b = 9_000_000, 4_000_000
+    x = O.synth_iq(0, n, seed=424)
+    x.tofile(tmp_path / "x.cf32")
+    taps = O.lowpass_taps_f64(256, 1 / 16)
+    taps.tofile(tmp_path / "t256.f32")
+    run([big, "fir", str(tmp_path / "x.cf32"), str(tmp_path / "y.cf32"), str(b), str(tmp_path / "t256.f32")], timeout=600)
+    y = np.fromfile(tmp_path / "y.cf32", dtype=np.complex64)
+    want = O.Fir(taps).process(x)                                    # (an FIR's output does not depend on the block cut)
+    assert len(y) == n and rel_rms(y, want) < 2e-6
+    # VFO(offset 300k, 2.4M -> 240k, bw 200k): per-block phase restart of the resampler, NCO carried across the blocks
+    run([big, "vfo", str(tmp_path / "x.cf32"), str(tmp_path / "yv.cf32"), str(b), "300000", "2400000", "240000", "200000"], timeout=600)
+    yv = np.fromfile(tmp_path / "yv.cf32", dtype=np.complex64)
+    wv = blocks(O.Vfo(300e3, 2.4e6, 240e3, 200e3, exact_nco=True, volk_gain=True), x, b)
+    assert len(yv) == len(wv) and rel_rms(yv, wv) < 2e-6
+    # the default build refuses such a block (it does not fit its streams)
+    r = subprocess.run([harness, "fir", str(tmp_path / "x.cf32"), str(tmp_path / "y2.cf32"), str(b), str(tmp_path / "t256.f32")], capture_output=True, text=True)
+    assert r.returncode != 0
 
 
 @gpu
