@@ -121,7 +121,9 @@ int qdsp_hip_fir_cf32_set_taps(void* h, const float* taps, int ntaps);
  * with one fused multiply-add each (bit-identical to a k-ordered fmaf chain).
  * QDSP_HIP_FIR_FFT: 4096-point overlap-save fast convolution (~135 FLOP/sample instead of
  * 4*ntaps; FP32 FFT rounding, ~3e-7 RMS relative to the direct form).  QDSP_HIP_FIR_AUTO
- * (default): FFT for >= 8 taps on calls of >= 65536 samples (it runs at copy speed whatever the
+ * (default): FIR<complex_t> follows a measured table (qdsp_amd/csrc/dispatch_table.inc: call size x taps -> the fastest of the
+ * latency direct form, the direct form, the one-wave 1024-point and the 4096-point overlap-save kernels); other data types:
+ * FFT for >= 8 taps on calls of >= 65536 samples (it runs at copy speed whatever the
  * taps; measured crossover), direct form otherwise. */
 #define QDSP_HIP_FIR_AUTO 0
 #define QDSP_HIP_FIR_DIRECT 1

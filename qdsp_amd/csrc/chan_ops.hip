@@ -113,7 +113,7 @@ int chan_launch_uniform(Chan* c, const void* d_in, int64_t count, int64_t nout, 
     {   // second-order term of the per-output deviation rotation: only when 15 output times turn a channel by more than 1e-4 rad
         long long dmax = 0;
         for (int i = 0; i < 64; i++) dmax = std::max(dmax, a.ddelta[i] < 0 ? -a.ddelta[i] : a.ddelta[i]);
-        a.quad = 15.0 * (double)dmax * (double)a.M * 3.4061215800865545e-19 > 1e-4 || qk::knob(qk::K_CHAN_QUAD, 0);
+        a.quad = 15.0 * (double)dmax * (double)a.M * 3.4061215800865545e-19 > 1e-4 || 0;
     }
     a.abl = qk::knob(qk::K_CHAN_ABL, 0);
     const size_t lds = qk::chan_uniform_lds_bytes(a.waves);
@@ -267,7 +267,7 @@ int chan_launch_batch(Chan* c, const void* d_in, int64_t count, int64_t nout, vo
     a.in = d_in;
     a.phases = c->d_phases;
     // persistent workgroups per channel: the grid's x extent times the channels should fill the chip a few times over
-    int nwg = (256 * qk::knob(qk::K_ANY_WG_PER_CU, 8) + c->nchan - 1) / c->nchan;
+    int nwg = (256 * 8 + c->nchan - 1) / c->nchan;
     if (nwg > a.nblocks) nwg = a.nblocks;
     if (nwg < 1) nwg = 1;
     a.nwg = nwg;
@@ -310,7 +310,7 @@ int chan_launch_batch(Chan* c, const void* d_in, int64_t count, int64_t nout, vo
 bool chan_batch_wins(const Chan* c, int64_t count) {
     if (c->nchan < 2 || qk::knob(qk::K_NO_CHAN_BATCH, 0)) return false;
     const Engine* e = c->vfo[0];
-    if (count <= (int64_t)qk::knob(qk::K_CHAN_BATCH_MAX_COUNT, 1 << 22)) return true;
+    if (count <= (int64_t)(1 << 22)) return true;
     if (e->d_taps_mf && !qk::knob(qk::K_NO_MF, 0) && !qk::knob(qk::K_NO_MF_BATCH, 0)) return true;   // what each channel would run anyway
     const bool dedicated = (fft_eligible(e, count) || use_win(e) || use_core(e) || use_lm(e));
     return !dedicated;
@@ -435,7 +435,7 @@ int64_t qdsp_hip_chan_cf32_process_links(void* h, const void* in, int in_link, i
     const size_t out_bytes = (size_t)nout * sizeof(float2);
     for (int i = 0; i < c->nchan; i++) {
         if (out_links[i] == QDSP_HIP_LINK_HOST_DEFERRED || out_links[i] == QDSP_HIP_LINK_HOST) {
-            if (out_bytes > (size_t)qk::knob(qk::K_DIRECT_OUT_MAX_BYTES, 1 << 20)) return QDSP_HIP_ESIZE;
+            if (out_bytes > (size_t)(1 << 20)) return QDSP_HIP_ESIZE;
             void* m = out_bytes ? mapped_host_ptr(outs[i]) : outs[i];
             if (!m) return QDSP_HIP_ESIZE;
             dst[i] = m;

@@ -91,6 +91,7 @@ struct Engine {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // overlap-save fast convolution (FIR<complex_t> with many taps), fft_fir.hip.h
     int fir_mode = 0;           // 0 auto, 1 direct form, 2 overlap-save FFT
+    int auto_pick = 0;          // FIR<complex_t>, AUTO: the kernel family the measured table names for this call (dispatch_table.inc), 0 = the rule chain
     float2* d_fft_H = nullptr;  // spectrum of the reversed taps / F, digit-reversed
     float2* d_fft_TA = nullptr;
     float2* d_fft_TB = nullptr;
@@ -251,7 +252,7 @@ template <class ARGS> void fill_stage_rot(ARGS& a, int NT) {
 template <class ARGS> int fill_stage_rot(Engine* e, ARGS& a, int NT, long long S, long long first, long long ntiles) {
     fill_stage_rot(a, NT);
     a.nco_tab = nullptr;
-    if (!e->rotate || qk::knob(qk::K_NO_NCO_TABLES, 0)) return 0;
+    if (!e->rotate || 0) return 0;
     const int na = (int)((ntiles + 255) / 256) + 1;
     if (na > 65536) return 0;
     int rc = nco_tables(e, S, NT, na, &a.nco_tab);

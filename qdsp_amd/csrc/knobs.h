@@ -11,17 +11,16 @@
 namespace qk {
 
 #define QDSP_HIP_KNOBS(X) \
-    X(ANY_MIN_SPLIT_TILE) X(ANY_NO_LDS_TAPS) X(ANY_NO_PAD) X(ANY_NO_SPLIT) X(ANY_NO_XCD) X(ANY_SMALL_CALL_TILES) \
-    X(ANY_SPLIT_MIN_TAPS) X(ANY_TILE) X(ANY_WG_PER_CU) X(CHAN_ABL) X(CHAN_BATCH_MAX_COUNT) X(CHAN_QUAD) \
-    X(CHAN_NO_ST4) X(CHAN_WG_PER_CU) X(CORE_MAX_DECIM) X(DIRECT_OUT_MAX_BYTES) X(FFT1K_MAX_COUNT) X(FFT_ABL) X(FFT_DMA) \
-    X(FFT_GROUP_MIN_UNITS) X(FFT_MIN_COUNT) X(FFT_MIN_TAPS) X(FFT_MIN_TAPS_DECIM) X(FFT_MIN_TAPS_REAL) \
-    X(FFT_MIN_TAPS_SMALL) X(FFT_NOVEC) X(FFT_NT) X(FFT_PRUNE2_MAX_COUNT) X(FFT_WG_PER_CU) X(FIR_LAT_MAX_WORK) X(FIR_MODE) X(FORCE_ANY) \
-    X(MF_BATCH_MIN_WORK) X(MF_DEPTH) X(MF_MIN_COUNT) X(MF_MIN_DECIM) X(MF_NO_KEEP2) X(MF_NO_QS2) X(MF_TASKS) \
-    X(MF_TASK_MAX) X(NO_ANY_POLICY) X(NO_CHAN_BATCH) X(NO_FFT1K) X(NO_FFT1K_REAL) X(NO_FIR_LAT) X(NO_LM) \
-    X(NO_LM_SMALL_CALL_RULE) X(NO_MF) X(NO_MF_BATCH) X(NO_NCO_TABLES) X(NO_PFB) X(NO_PFB4) X(NO_RAW_CARRY) X(NO_REAL_BIG_CALL_RULE) X(NO_RM) X(NO_RM_EXT) X(NO_RM_SMALL) \
-    X(NO_WIN) X(NO_WIN_BIG_CALL_RULE) X(NO_WIN_SMALL_CALL_RULE) X(NT) X(PFB_MIN_COUNT) X(PFB_WG_PER_CU) X(R) X(RM_MIN_COUNT) X(RM_MIN_INTERP) \
-    X(RM_WAVES_PER_SIMD) X(SYNC_SPIN_US) X(WIN_MAX_TAPS) X(WIN_R) X(XLATE_WG_PER_CU)
-
+    X(ANY_SMALL_CALL_TILES) \
+    X(CHAN_ABL) \
+    X(CHAN_NO_ST4) X(CHAN_WG_PER_CU) X(FFT1K_MAX_COUNT) X(FFT_ABL) X(FFT_DMA) \
+    X(FFT_MIN_TAPS) X(FFT_MIN_TAPS_DECIM) X(FFT_MIN_TAPS_REAL) \
+    X(FFT_MIN_TAPS_SMALL) X(FFT_NT) X(FFT_PRUNE2_MAX_COUNT) X(FFT_WG_PER_CU) X(FIR_LAT_MAX_WORK) X(FIR_MODE) X(FIR_PICK) X(FORCE_ANY) \
+    X(MF_BATCH_MIN_WORK) X(MF_DEPTH) X(MF_MIN_COUNT) X(MF_MIN_DECIM) \
+    X(MF_TASK_MAX) X(NO_CHAN_BATCH) X(NO_FFT1K) X(NO_FFT1K_REAL) X(NO_FIR_LAT) X(NO_FIR_TABLE) X(NO_LM) \
+    X(NO_LM_SMALL_CALL_RULE) X(NO_MF) X(NO_MF_BATCH) X(NO_PFB) X(NO_RM) X(NO_RM_EXT) \
+    X(NO_WIN) X(NT) X(PFB_MIN_COUNT) X(PFB_WG_PER_CU) X(R) X(RM_MIN_COUNT) X(RM_MIN_INTERP) \
+    X(RM_WAVES_PER_SIMD) X(WIN_MAX_TAPS) X(WIN_R) 
 enum Knob {
 #define X(n) K_##n,
     QDSP_HIP_KNOBS(X)

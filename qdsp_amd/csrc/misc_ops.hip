@@ -150,7 +150,7 @@ int qdsp_hip_event_destroy(void* ev) {
 int qdsp_hip_event_wait(void* ev) {
     if (!ev) return QDSP_HIP_EINVAL;
     hipEvent_t e = static_cast<hipEvent_t>(ev);
-    static const int spin_us = qk::knob(qk::K_SYNC_SPIN_US, 200);
+    static const int spin_us = 200;
     if (spin_us > 0) {
         const auto t0 = std::chrono::steady_clock::now();
         do {

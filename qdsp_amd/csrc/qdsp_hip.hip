@@ -19,7 +19,7 @@ Engine* as_engine(void* h, Kind k) {
 // longer than the kernels of a reference-sized block take: poll the stream for a bounded time first
 // (QDSP_HIP_SYNC_SPIN_US, default 200; 0 = always block).
 hipError_t wait_stream(hipStream_t s) {
-    static const int spin_us = qk::knob(qk::K_SYNC_SPIN_US, 200);
+    static const int spin_us = 200;
     if (spin_us > 0) {
         const auto t0 = std::chrono::steady_clock::now();
         do {
@@ -36,7 +36,7 @@ hipError_t wait_stream(hipStream_t s) {
 hipError_t wait_event(hipEvent_t ev, hipStream_t s) {
     hipError_t rc = hipEventRecord(ev, s);
     if (rc != hipSuccess) return rc;
-    static const int spin_us = qk::knob(qk::K_SYNC_SPIN_US, 200);
+    static const int spin_us = 200;
     if (spin_us > 0) {
         const auto t0 = std::chrono::steady_clock::now();
         do {
@@ -120,7 +120,7 @@ int64_t out_size(const Engine* e, int64_t count) {
 // fir_core_kernel (de-interleaved tile): FIR and decimations up to 8.  From 9 on the general kernel with its
 // staged-as-it-lies tile is 2-3x faster (scripts/tune_large_decim.py: M = 9..16, 31-255 taps: 0.12-0.38 ms per
 // 2^26 samples against 0.26-0.54).
-bool use_core(const Engine* e) { return e->L == 1 && e->M <= qk::knob(qk::K_CORE_MAX_DECIM, 8) && !qk::knob(qk::K_FORCE_ANY, 0); }
+bool use_core(const Engine* e) { return e->L == 1 && e->M <= 8 && !qk::knob(qk::K_FORCE_ANY, 0); }
 
 // decimators served by decim_win_kernel (kernels.hip.h): interp 1, short filters.  Outputs per lane and the
 // tap limit from scripts/tune_win.py / tune_small.py (2^26 samples): chunks of M*R <= 10 samples are the sweet
@@ -168,11 +168,11 @@ bool mf_plan(const Engine* e, int* KJ, int* QS, int* keep2) {
     if (M < qk::knob(qk::K_MF_MIN_DECIM, 9)) return false;
     // decimations 130-256 (even): the kernel runs rows of M / 2 samples -- the decimator by M / 2 with the same taps -- and
     // keeps every other output; twice the matrix work for the outputs that count, on a unit that has the room
-    const int k2 = (M > 8 * qk::kMfMaxKJ && M <= 16 * qk::kMfMaxKJ && M % 2 == 0 && !qk::knob(qk::K_MF_NO_KEEP2, 0)) ? 1 : 0;
+    const int k2 = (M > 8 * qk::kMfMaxKJ && M <= 16 * qk::kMfMaxKJ && M % 2 == 0 && !0) ? 1 : 0;
     const int Mk = k2 ? M / 2 : M;
     if (Mk > 8 * qk::kMfMaxKJ) return false;
     const int Q = (P + Mk - 1) / Mk;                  // taps per column: one set of 16 rows of the A operand, or two
-    if (Q > qk::kMfMaxQ || (Q > 16 && qk::knob(qk::K_MF_NO_QS2, 0))) return false;
+    if (Q > qk::kMfMaxQ || (Q > 16 && 0)) return false;
     if (Q > 16 && M < 12) return false;      // (two tap sets on rows of < 12 samples: 0.44 ms per 2^27 at decimation 10 against 0.36 overlap-save, round 3)
     if (M < 14 && P < 12 * M) return false;
     if (P < M) return false;                          // (fewer taps than the decimation: most of each row meets no tap, the general kernel is 5-16 % ahead)
@@ -265,7 +265,7 @@ int upload_taps(Engine* e, const float* taps, int ntaps) {
     // between period quads and run within +-15 % of the general kernel, which keeps them (QDSP_HIP_RM_MIN_INTERP lowers
     // the bar).
     bool rm_wanted = e->L >= qk::knob(qk::K_RM_MIN_INTERP, 33) || (e->M == 1 && e->L >= 6 && !use_lm(e));
-    if (use_lm(e) && e->L >= 2 && !qk::knob(qk::K_NO_RM_SMALL, 0))
+    if (use_lm(e) && e->L >= 2 && !0)
         rm_wanted = rm_wanted || (e->M >= 5 && e->P <= (e->L == 10 ? 36 : 24)) || (e->L == 10 && e->M >= 3 && e->P <= 24);
     // Round 3 (scripts/sweep_rm_grid.py, profiles/r03_sweep_rm_grid.txt: 130 ratios x 8-32 taps per phase on 2^26-sample calls): the block
     // form is ahead of the general direct kernel on nearly every ratio from 14 taps per phase on (x 0.5-0.9 of its time; 72 of 79 ratios at
@@ -693,14 +693,14 @@ AnyPlan any_plan(int L, int M, int P, int ch, long long nout) {
     p.Pp = (P + 3) & ~3;
     if (((p.Pp >> 2) & 1) == 0) p.Pp += 4;
     const long long tap_bytes = (long long)L * p.Pp * (long long)sizeof(float);
-    const bool lt = tap_bytes <= kMaxDynLds / 2 && qk::knob(qk::K_ANY_NO_LDS_TAPS, 0) == 0;
+    const bool lt = tap_bytes <= kMaxDynLds / 2 && 0 == 0;
     p.tap_bytes = lt ? (int)tap_bytes : 0;
     // Tile = as many outputs as keep the staged input span inside what is left of the LDS budget.
     const long long max_elems = (kMaxDynLds - p.tap_bytes) / (ch * (int)sizeof(float));
-    long long tile = (long long)qk::knob(qk::K_ANY_TILE, 8) * NT;
+    long long tile = (long long)8 * NT;
     // interp 1 with a decimation that is a multiple of 4: lane windows M samples apart share LDS banks (4-way and
     // worse) -> one pad element per M samples
-    p.pad = L == 1 && (M & 3) == 0 && M <= 65536 && qk::knob(qk::K_ANY_NO_PAD, 0) == 0;
+    p.pad = L == 1 && (M & 3) == 0 && M <= 65536 && 0 == 0;
     auto span_of = [&](long long t) {
         const long long sp = ((t - 1) * M) / L + P + 2;
         return p.pad ? sp + sp / M + 1 : sp;
@@ -709,7 +709,7 @@ AnyPlan any_plan(int L, int M, int P, int ch, long long nout) {
     // sums behind the samples).  Two lanes per output (tile 128) measured no better than one: the extra barrier
     // and LDS round trip cost what the halved tap loop saves (M = 50, 201 taps: 0.162 vs 0.145 ms).
     constexpr int kSplitTile = NT / 4;
-    const bool ks_ok = L == 1 && P >= 64 && qk::knob(qk::K_ANY_NO_SPLIT, 0) == 0;
+    const bool ks_ok = L == 1 && P >= 64 && 0 == 0;
     auto need = [&](long long t) { return span_of(t) + ((ks_ok && t <= kSplitTile) ? NT : 0); };
     while (tile > 1 && need(tile) > max_elems) tile /= 2;
     // reference-sized calls (nout known): 2048 outputs per tile leave a 1e6-sample block of a 24/125 audio resampler on 94
@@ -724,7 +724,7 @@ AnyPlan any_plan(int L, int M, int P, int ch, long long nout) {
             // (... and as long as the halved tiles still fit one round of the chip: the NCO variant keeps 3 workgroups per CU
             // resident, and a 769th workgroup waits for a whole round -- 401-513 taps / 40-64 on 1e6 samples: 9.4-9.5 us with
             // 783-978 tiles against 7.3-7.4 with 392-490)
-            const long long tmin = qk::knob(qk::K_ANY_MIN_SPLIT_TILE, 16);
+            const long long tmin = 16;
             while (tile > tmin && tile <= kSplitTile && (nout + tile - 1) / tile < want && (nout + tile / 2 - 1) / (tile / 2) <= 768 &&
                    P / (2 * NT / tile) >= 16)
                 tile /= 2;
@@ -732,7 +732,7 @@ AnyPlan any_plan(int L, int M, int P, int ch, long long nout) {
     }
     // a half-workgroup tile with a long tap loop: the quarter tile with four lanes per output is faster (M = 50,
     // 401 taps: 0.24 -> 0.17 ms) unless it stages too little per lane (M = 32: 9 samples in batches of 8)
-    if (ks_ok && tile == 2 * kSplitTile && P >= qk::knob(qk::K_ANY_SPLIT_MIN_TAPS, 192) && M >= 40) tile = kSplitTile;
+    if (ks_ok && tile == 2 * kSplitTile && P >= 192 && M >= 40) tile = kSplitTile;
     p.tile = need(tile) > max_elems ? 0 : tile;
     p.span = span_of(tile);
     p.ks_lanes = p.ks_shift = p.ks_chunk = 0;
@@ -774,12 +774,12 @@ template <int CH, bool ROT> int launch_any(Engine* e, qk::AnyArgs& a, hipStream_
     if (lds == 0) return QDSP_HIP_EINVAL;  // taps per phase beyond LDS
     // persistent workgroups, 8 per CU (measured on the M = 50, 401-tap VFO, 32 KB of LDS each: 5 per CU -- what is
     // resident at once -- 0.41 ms per 2^27 samples, 8 .. 64 per CU 0.345-0.358)
-    int nwg = 256 * qk::knob(qk::K_ANY_WG_PER_CU, 8);
+    int nwg = 256 * 8;
     if (nwg > a.nblocks) nwg = a.nblocks;
     if (nwg < 1) nwg = 1;
     a.nwg = nwg;
     // full persistent grids only: a contiguous tile range per XCD (kernels.hip.h)
-    a.xcd_tiles = (nwg >= 2048 && (nwg & 7) == 0 && !qk::knob(qk::K_ANY_NO_XCD, 0)) ? (a.nblocks + 7) / 8 : 0;
+    a.xcd_tiles = (nwg >= 2048 && (nwg & 7) == 0 && !0) ? (a.nblocks + 7) / 8 : 0;
     fill_stage_rot(a, NT);
     if (pad) {
         if (lt) hipLaunchKernelGGL((qk::resamp_any_kernel<CH, NT, ROT, true, true>), dim3(nwg + 1), dim3(NT), lds, s, a);
@@ -819,6 +819,28 @@ int fft_dec(const Engine* e) {
 
 int mode_of(const Engine* e) { return e->fir_mode ? e->fir_mode : qk::knob(qk::K_FIR_MODE, 0); }
 
+// ---- FIR<complex_t>, AUTO: which kernel family serves a call of `count` samples with `ntaps` taps -------------------------------------------
+// Round 4: this one choice is DATA, not an if-chain.  scripts/sweep_fir_table.py times the four families on a grid of
+// call sizes x tap counts (each forced with QDSP_HIP_FIR_PICK), scripts/gen_dispatch_table.py turns the committed sweep
+// (profiles/r04_sweep_fir_table.txt) into dispatch_table.inc -- one byte per cell: the fastest family -- tests/test_capi_cpu.py checks that the
+// table is the sweep's, tests/test_gpu_dispatch.py re-measures a fixed sample of cells and fails when the default is > 10 % behind an alternative.
+// A call takes the nearest cell (log2 of the count, log of the taps); a family that cannot serve the shape (structural limits in the *_eligible
+// predicates) hands the call back to the rule chain.
+enum FirPick { PICK_NONE = 0, PICK_LAT = 1, PICK_CORE = 2, PICK_FFT1K = 3, PICK_FFT4K = 4 };
+#include "dispatch_table.inc"
+int fir_table_pick(int64_t count, int ntaps) {
+    if (count <= 0 || ntaps < kFirPickTaps[0]) return PICK_NONE;
+    int lg = 0;
+    while ((int64_t(1) << (lg + 1)) <= count) lg++;                   // floor(log2 count)
+    if (count - (int64_t(1) << lg) > (int64_t(1) << lg) * 0.41421356) lg++;   // nearest power of two on a log scale (sqrt 2)
+    int row = lg - kFirPickLog2Min;
+    row = row < 0 ? 0 : row >= kFirPickRows ? kFirPickRows - 1 : row;
+    int col = 0;
+    for (int c = 1; c < kFirPickCols; c++)                            // nearest grid point on a log scale: the geometric mean is the border
+        if ((double)ntaps * ntaps >= (double)kFirPickTaps[c - 1] * kFirPickTaps[c]) col = c;
+    return kFirPick[row][col];
+}
+
 // Large decimations (the VFO's usual job: 2.4 Msps -> 48 kHz is M = 50) with the few taps per output such
 // filters have: the general direct kernel streams the input once and does P/M MACs per input sample, while the
 // overlap-save form pays a full 4096-point transform pair whatever M (0.20-0.22 ms per 2^26 samples, 0.25-0.28
@@ -827,7 +849,7 @@ int mode_of(const Engine* e) { return e->fir_mode ? e->fir_mode : qk::knob(qk::K
 // tile * M samples), and the NCO costs it 0.015 ms instead of 0.055; 2-way bank conflicts (M = 2 mod 4) move
 // the crossover down.
 bool any_direct_wins(const Engine* e) {
-    if (e->L != 1 || e->ch != 2 || qk::knob(qk::K_NO_ANY_POLICY, 0)) return false;
+    if (e->L != 1 || e->ch != 2 || 0) return false;
     const AnyPlan pl = any_plan(1, e->M, e->P, e->ch);
     if (pl.tile == 0) return false;
     // tiles of 64 outputs and fewer (M >= 64 or so) split every output's taps over 4-16 lanes: 0.12-0.26 ms up to
@@ -845,6 +867,7 @@ bool fft_eligible(const Engine* e, int64_t count) {
     int mode = e->fir_mode ? e->fir_mode : qk::knob(qk::K_FIR_MODE, 0);
     if (mode == 1) return false;
     if (mode == 2) return true;
+    if (e->auto_pick) return e->auto_pick == PICK_FFT1K || e->auto_pick == PICK_FFT4K;
     // auto: calls big enough to fill the chip with 4096-point segments, and filters past the measured
     // crossover of the two forms
     // real data (two segments per transform, 305 Gs/s whatever the taps at 2^26 samples): the direct form
@@ -857,7 +880,7 @@ bool fft_eligible(const Engine* e, int64_t count) {
         // length; against it the direct form stays ahead to 64 taps (FIR), 128-192 taps at decimation 2-5, 384 at decimation 8, the
         // strided-window kernel to its own limits at decimation 10 / 12 / 16 -- and nothing else serves the decimations in between:
         // round 2's 32 taps per unit of decimation left decimate-by-10 with 256 taps on the general kernel at 0.56 ms (now 0.26).
-        const bool big = count >= (1 << 22) && !qk::knob(qk::K_NO_REAL_BIG_CALL_RULE, 0);
+        const bool big = count >= (1 << 22) && !0;
         min_taps = qk::knob(qk::K_FFT_MIN_TAPS_REAL, big && e->M == 1 ? 64 : 96);
         if (e->M > 1) {
             int need = 32 * e->M;
@@ -907,7 +930,7 @@ bool fft_eligible(const Engine* e, int64_t count) {
         const int64_t by_work = (1 << 21) / e->ntaps;
         min_count = by_work < 1024 ? 1024 : by_work;
     }
-    return e->ntaps >= min_taps && count >= qk::knob(qk::K_FFT_MIN_COUNT, (int)min_count);
+    return e->ntaps >= min_taps && count >= ((int)min_count);
 }
 
 // Spectrum of a short sequence zero-padded to F = 2^m points, FP64 radix-2 (twiddles from sincosl, rounded once): what the
@@ -1014,6 +1037,7 @@ bool fft1k_eligible(const Engine* e, int64_t count) {
     if (e->ch != 2 && (e->kind == KIND_VFO || e->rotate || qk::knob(qk::K_NO_FFT1K_REAL, 0))) return false;   // real data: two real segments per wave
     const int mode = e->fir_mode ? e->fir_mode : qk::knob(qk::K_FIR_MODE, 0);
     if (mode != 0 || qk::knob(qk::K_NO_FFT1K, 0)) return false;
+    if (e->auto_pick) return e->auto_pick == PICK_FFT1K;
     const int forced = qk::knob(qk::K_FFT1K_MAX_COUNT, -1);
     if (forced >= 0) return count <= forced;
     // measured crossovers against the 4096-point kernels (scripts/tune_fft1k.py, profiles/r02_tune_fft1k.txt): the
@@ -1174,7 +1198,7 @@ bool pfb_eligible(const Engine* e, int64_t count) {
     if (e->ch != 2 || e->L != 1 || (e->M != qk::kPfbD && e->M != 4) || e->ntaps < 2) return false;
     if (e->kind != KIND_DECIM && e->kind != KIND_VFO) return false;
     if (pfb_Q(e) > qk::kPfbMaxQ) return false;
-    if (qk::knob(qk::K_NO_PFB, 0) || (e->M == 4 && qk::knob(qk::K_NO_PFB4, 0))) return false;
+    if (qk::knob(qk::K_NO_PFB, 0) || (e->M == 4 && 0)) return false;
     // measured crossover (scripts/tune_pfb_threshold.py, 256 taps): a lone segment takes a wave ~7 us (15 us per call
     // with the table load) where fir_fft_kernel<8> needs 8 us, so the per-segment kernels keep the reference-sized
     // calls; from 2^23 samples (decimator) / 2^24 (fused VFO) on this form is ahead, 1.2x at 2^27
@@ -1294,7 +1318,7 @@ int raw_history(Engine* e, hipStream_t s, const float2** hist, float2** hist_raw
         e->hist_raw_cap = e->H;
         e->raw_valid = false;
     }
-    if (!e->raw_valid || qk::knob(qk::K_NO_RAW_CARRY, 0)) {
+    if (!e->raw_valid || 0) {
         const unsigned long long ph_first = e->phase - (unsigned long long)e->H * e->dphase;   // phase of history sample 0
         const Launch keep = e->last;
         const int rc = launch_xlate_inc(e, e->d_hist[e->cur], e->H, e->d_hist_raw[e->cur], 0ULL - ph_first, 0ULL - e->dphase, 0.0f, s);
@@ -1406,10 +1430,10 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
         a.seg_shift = a.ov + 2;
         a.L = qk::kFftN - a.ov;
         a.nblocks = (int)((count + 2 + a.L - 1) / a.L);
-        a.vec = (((uintptr_t)d_in) & 15) == 0 && !qk::knob(qk::K_FFT_NOVEC, 0);
+        a.vec = (((uintptr_t)d_in) & 15) == 0 && !0;
     } else if (a.dec == 1) {
         a.ov = (e->ntaps - 1 + 1) & ~1;   // FIR: out index == stream position; even so segments stay 16-byte aligned
-        a.vec = ((((uintptr_t)d_in) | ((uintptr_t)d_out)) & 15) == 0 && !qk::knob(qk::K_FFT_NOVEC, 0);
+        a.vec = ((((uintptr_t)d_in) | ((uintptr_t)d_out)) & 15) == 0 && !0;
         a.seg_shift = a.ov;
         a.L = qk::kFftN - a.ov;
         a.nblocks = (int)((count + a.L - 1) / a.L);
@@ -1424,7 +1448,7 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
     if (e->ch == 1) {   // real data: one workgroup iteration = a PAIR of real segments
         a.real2 = 1;
         // 8-byte pair accesses: segments start on even samples (L, ov, seg_shift are even) of 8-byte aligned buffers
-        a.vec = ((((uintptr_t)d_in) | ((uintptr_t)d_out)) & 7) == 0 && !qk::knob(qk::K_FFT_NOVEC, 0);
+        a.vec = ((((uintptr_t)d_in) | ((uintptr_t)d_out)) & 7) == 0 && !0;
         a.nblocks = (a.nblocks + 1) / 2;
     }
     // FIR: 4 workgroups resident per CU (124 VGPRs, 37 KB LDS), 16 queued per CU for balance.
@@ -1436,7 +1460,7 @@ int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
     a.abl = qk::knob(qk::K_FFT_ABL, 0);
     a.stamps = reinterpret_cast<unsigned*>(qk::knobs_snapshot()->fft_stamps);   // diagnostic: scripts/stamp_fir_fft.py
     a.dma = (a.dec == 1 && !a.strided && !a.rot && e->ch == 2 && a.vec && a.ov <= 2048) ? qk::knob(qk::K_FFT_DMA, 1) : 0;   // 1: scalar arithmetic, 2: packed
-    const bool grouped = a.dec >= 4 && (a.nblocks + a.dec - 1) / a.dec >= qk::knob(qk::K_FFT_GROUP_MIN_UNITS, 1024);
+    const bool grouped = a.dec >= 4 && (a.nblocks + a.dec - 1) / a.dec >= 1024;
     a.grouped = grouped ? 1 : 0;
     const int per_cu = qk::knob(qk::K_FFT_WG_PER_CU, grouped ? 4 : 16);
     const int units = grouped ? (a.nblocks + a.dec - 1) / a.dec : a.nblocks;
@@ -1502,7 +1526,7 @@ int launch_xlate_inc(Engine* e, const void* d_in, int64_t count, void* d_out, un
     long long grid = (npairs + NT - 1) / NT;
     // one pair per lane up to 2^27 samples: measured 0.345 ms per 2^27 samples against 0.46 ms with 16 blocks per CU
     // looping 64 times (the per-lane FP64 sincos is cheaper than the lost memory-level parallelism)
-    { const long long cap = 256LL * qk::knob(qk::K_XLATE_WG_PER_CU, 1024); if (grid > cap) grid = cap; }
+    { const long long cap = 256LL * 1024; if (grid > cap) grid = cap; }
     unit_of_fx_c(dphase, 1.0L, &a.rot_one.x, &a.rot_one.y);
     unit_of_fx_c(dphase, (long double)(2 * grid * NT), &a.rot_stride.x, &a.rot_stride.y);
     a.vec = (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0;   // d_in == nullptr (SineSource) counts as aligned
@@ -1519,7 +1543,7 @@ int launch_xlate_inc(Engine* e, const void* d_in, int64_t count, void* d_out, un
 // outputs per wave task: a task reads one tile of 16 rows beyond its own (T = 256: 6 %); small calls take shorter
 // tasks so that a reference-sized block still spreads over the chip (1e6 samples at decimation 50: 20 000 outputs)
 void mf_tasks(qk::MfArgs& a, int64_t nout, int nchan, bool rot) {
-    long long T = nout * nchan / qk::knob(qk::K_MF_TASKS, 2048);      // (one round of the chip: 3072 wave slots; 8192 left a 4M-sample call at T = 16 -- half of every task's reads its neighbour's -- and 18 us instead of 14)
+    long long T = nout * nchan / 2048;      // (one round of the chip: 3072 wave slots; 8192 left a 4M-sample call at T = 16 -- half of every task's reads its neighbour's -- and 18 us instead of 14)
     T = (T + 15) / 16 * 16;
     const long long tmax = qk::knob(qk::K_MF_TASK_MAX, rot ? 256 : 128);
     if (T > tmax) T = tmax;
@@ -1544,6 +1568,7 @@ void mf_rot_tables(unsigned long long dphase, int M, int KJ, double2* step, floa
 bool fir_lat_eligible(const Engine* e, int64_t count) {
     if (e->kind != KIND_FIR || e->ch != 2 || !e->has_filter || e->L != 1 || e->M != 1) return false;
     if (e->ntaps > 1024 || qk::knob(qk::K_NO_FIR_LAT, 0)) return false;
+    if (e->auto_pick) return e->auto_pick == PICK_LAT && count > 0;      // the measured table has spoken (dispatch_table.inc)
     // (a wave walks all taps of its 64 outputs: 600 taps take 9.3 us on 4096 samples, the one-wave overlap-save kernel 5.6)
     if (e->ntaps > 320 && fft1k_eligible(e, count)) return false;
     // measured: 2.5 us + 1.7e-7 us per tap and sample (63 / 127 / 256 taps at 65 536 samples: 2.9 / 3.6 / 5.3 us); what it
@@ -1680,7 +1705,7 @@ bool lm_yields_to_any(const Engine* e, int64_t nout) {
 // the one-wave overlap-save kernel takes 5.5 whatever the taps; from ~1e6 samples on the window kernel is ahead again
 // (profiles/r02_tune_fft1k.txt).
 bool win_yields_to_fft1k(const Engine* e, int64_t count) {
-    if (e->ch != 2 || e->ntaps < 96 || count > (1 << 19) || qk::knob(qk::K_NO_WIN_SMALL_CALL_RULE, 0)) return false;   // (real data: 5.6-6.8 us against 7.1-8.3)
+    if (e->ch != 2 || e->ntaps < 96 || count > (1 << 19) || 0) return false;   // (real data: 5.6-6.8 us against 7.1-8.3)
     return fft1k_eligible(e, count);
 }
 
@@ -1690,7 +1715,7 @@ bool win_yields_to_fft1k(const Engine* e, int64_t count) {
 // crossovers the big calls go there (decimation 8, 160 taps: 0.30 -> 0.25 ms, fused VFO 0.35 -> 0.25; decimation 2, 144 taps:
 // 0.57 -> 0.48).  use_win()'s limits, measured on 2^26-sample calls in round 1, keep the smaller calls.
 bool win_yields_to_fft_big(const Engine* e, int64_t count) {
-    if (e->ch != 2 || qk::knob(qk::K_NO_WIN_BIG_CALL_RULE, 0)) return false;
+    if (e->ch != 2 || 0) return false;
     const int M = e->M, P = e->P;
     if (M == 8) return pfb_eligible(e, count) && P >= (e->rotate ? 56 : 88);
     // (at 2^24 samples the window kernel is still ahead at decimation 3-5 -- 0.046-0.049 against 0.053-0.055 ms at 112-160 taps --
@@ -1706,7 +1731,7 @@ bool win_yields_to_fft_big(const Engine* e, int64_t count) {
 // strided window does (decimation 2: 0.14-0.25 against 0.18-0.36 ms at 32-128 taps; decimation 4: 0.12-0.18 against 0.15-0.23), and from
 // ~100 taps at decimation 5 / 8.
 bool real_win_yields_to_core_big(const Engine* e, int64_t count) {
-    if (e->ch != 1 || count < (1 << 22) || !use_core(e) || qk::knob(qk::K_NO_REAL_BIG_CALL_RULE, 0)) return false;
+    if (e->ch != 1 || count < (1 << 22) || !use_core(e) || 0) return false;
     return e->M == 2 || e->M == 4 || (e->M == 5 && e->P >= 96) || (e->M == 8 && e->P >= 128);
 }
 
@@ -1738,6 +1763,15 @@ int64_t process_dev(Engine* e, const void* d_in, int64_t count, void* d_out, voi
     const int64_t nout = out_size(e, count);
     int rc = 0;
     bool took_fft = false;
+    e->auto_pick = PICK_NONE;
+    if (e->kind == KIND_FIR && e->ch == 2 && e->has_filter && mode_of(e) == 0) {
+        const int forced = qk::knob(qk::K_FIR_PICK, 0);               // 1..4: the sweep and the regression test force a family
+        e->auto_pick = forced >= PICK_LAT && forced <= PICK_FFT4K ? forced : qk::knob(qk::K_NO_FIR_TABLE, 0) ? PICK_NONE : fir_table_pick(count, e->ntaps);
+        // structural limits of the family named: none for the direct form; the others fall back to the rule chain
+        if ((e->auto_pick == PICK_LAT && e->ntaps > 1024) || (e->auto_pick == PICK_FFT1K && e->ntaps > 769) ||
+            ((e->auto_pick == PICK_FFT1K || e->auto_pick == PICK_FFT4K) && !fft_dec(e)))
+            e->auto_pick = PICK_NONE;
+    }
     if (!e->has_filter) {
         rc = launch_xlate(e, d_in, count, d_out, s);
     } else if (mode_of(e) == 0 && fir_lat_eligible(e, count)) {
@@ -1875,7 +1909,7 @@ int64_t process_ex(Engine* e, const void* in, int in_dev, int count, void* out, 
     bool direct_out = false;
     if (!out_dev && count > 0) {
         const size_t out_bytes = (size_t)out_size(e, count) * e->ch * sizeof(float);
-        if (out_bytes > 0 && out_bytes <= (size_t)qk::knob(qk::K_DIRECT_OUT_MAX_BYTES, 1 << 20)) {
+        if (out_bytes > 0 && out_bytes <= (size_t)(1 << 20)) {
             void* mapped = mapped_host_ptr(out);
             if (mapped) { dst = mapped; direct_out = true; }
         }

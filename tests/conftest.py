@@ -95,3 +95,31 @@ def kname(op):
     tests that pin "the 4096-point overlap-save kernel" mean the family (test_fft_fir_dma_forms_agree tells the members apart)."""
     name = op.last_kernel()["name"]
     return "fir_fft_kernel" if name in ("fir_fft_dma_kernel", "fir_fft_dmapk_kernel") else name
+
+
+def fir_auto_family(count: int, ntaps: int) -> str:
+    """Kernel family FIR<complex_t> takes in AUTO mode: the measured table qdsp_amd/csrc/dispatch_table.inc read the way
+    fir_table_pick() (qdsp_hip.hip) reads it -- nearest cell on log scales, a family that cannot serve the shape falls back to the
+    rule chain (None here: the caller states that case itself).  Test helper: the expectations follow the committed table."""
+    import math
+    import os
+    import re
+
+    inc = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "qdsp_amd", "csrc", "dispatch_table.inc")).read()
+    lmin = int(re.search(r"kFirPickLog2Min = (\d+)", inc).group(1))
+    taps = [int(v) for v in re.search(r"kFirPickTaps\[kFirPickCols\] = \{([^}]*)\}", inc).group(1).split(",")]
+    rows = [[int(v) for v in m.group(1).split(",")] for m in re.finditer(r"\*/ \{([^}]*)\},", inc)]
+    if count <= 0 or ntaps < taps[0]:
+        return None
+    lg = int(math.floor(math.log2(count)))
+    if count - (1 << lg) > (1 << lg) * 0.41421356:
+        lg += 1
+    row = min(max(lg - lmin, 0), len(rows) - 1)
+    col = 0
+    for c in range(1, len(taps)):
+        if ntaps * ntaps >= taps[c - 1] * taps[c]:
+            col = c
+    pick = rows[row][col]
+    if (pick == 1 and ntaps > 1024) or (pick == 3 and ntaps > 769):
+        return None
+    return {1: "fir_lat_kernel", 2: "fir_core_kernel", 3: "fir_fft1k_kernel", 4: "fir_fft_kernel"}[pick]

@@ -122,3 +122,16 @@ def test_no_kernel_uses_scratch():
     occ = {r[8]: int(r[6]) for r in rows}
     assert occ["qk::fir_fft_dma_kernel"] == 4 and occ["qk::pfb_dec8_kernel<true>"] == 2
     assert all(v == 3 for k, v in occ.items() if k.startswith("qk::chan_uniform_kernel<") and ", 0>" in k and "64" not in k)
+
+
+def test_fir_dispatch_table_is_what_the_committed_sweep_gives():
+    """qdsp_amd/csrc/dispatch_table.inc (FIR<complex_t>, AUTO: fastest kernel family per (call size, taps) cell) is generated from
+    profiles/r04_sweep_fir_table.txt by scripts/gen_dispatch_table.py; an edited table or a new sweep without a regenerated table fails here
+    (tests/test_gpu_dispatch.py re-measures a sample of cells on the GPU)."""
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gen_dispatch_table.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    inc = open(os.path.join(ROOT, "qdsp_amd", "csrc", "dispatch_table.inc")).read()
+    assert "GENERATED" in inc and "kFirPick[kFirPickRows][kFirPickCols]" in inc

@@ -1,0 +1,115 @@
+"""The AUTO choice of FIR<complex_t> against its alternatives, re-measured.
+
+qdsp_amd/csrc/dispatch_table.inc names, per (call size, tap count) cell, the fastest of the four kernel families as measured by
+scripts/sweep_fir_table.py (profiles/r04_sweep_fir_table.txt).  This test times a FIXED sample of 40 shapes -- grid cells and shapes between
+them -- with the default dispatch and with every family forced (QDSP_HIP_FIR_PICK), and fails when the default is more than 10 % slower
+than the best alternative (round 3's if-chain was 12-15 % behind on two cells of profiles/r03_sweep_fir_mid.txt).  Results are also checked
+to agree between the families (same filter: the direct forms bit for bit, the overlap-save forms to 2e-6)."""
+import numpy as np
+import pytest
+
+import oracle as O
+from conftest import rel_rms
+
+pytestmark = pytest.mark.gpu
+
+EXPECT = {1: ("fir_lat_kernel",), 2: ("fir_core_kernel",), 3: ("fir_fft1k_kernel",), 4: ("fir_fft_dma_kernel", "fir_fft_kernel", "fir_fft_dmapk_kernel")}
+
+
+def _shapes():
+    rng = np.random.default_rng(20260405)
+    grid = [(1 << lg, t) for lg in (14, 16, 18, 19, 20, 21, 22, 23, 24) for t in (16, 32, 64, 256)][:24]
+    grid += [(1 << 20, 16), (1 << 20, 32)]                      # the two cells round 3 lost
+    between = []
+    while len(between) < 14:
+        n = int(2 ** rng.uniform(14, 24.5))
+        t = int(2 ** rng.uniform(3, 9.5))
+        between.append((n - n % 2, max(8, t)))
+    return (grid + between)[:40]
+
+
+def test_default_fir_dispatch_is_within_10_percent_of_the_best_family():
+    import torch
+
+    from bench import lowpass_taps
+    from qdsp_amd import capi, ops
+
+    worst, report = 0.0, []
+    warm = ops.Fir(lowpass_taps(256, 0.2), max_block=0)
+    xw = ops.synth_iq(1 << 24, seed=1)
+    ow = torch.empty((1 << 24) + 8, dtype=torch.complex64, device="cuda")
+    warm.time_dev(xw, ow, 200)                                   # clocks up before anything is compared
+    warm.close()
+    del xw, ow
+    for n, nt in _shapes():
+        taps = lowpass_taps(nt, 0.2)
+        x = ops.synth_iq(n, seed=5)
+        out = torch.empty(n + 8, dtype=torch.complex64, device="cuda")
+        reps = max(5, min(100, int(1e-2 / max(2e-6, n * nt * 2.5e-13))))
+        cands = [0] + [p for p in (1, 2, 3, 4) if not (p <= 2 and n * nt > (1 << 31))]
+        op = ops.Fir(taps, max_block=0)                          # (QDSP_HIP_FIR_PICK is read per call: one handle serves every candidate)
+        times, names, y0 = {}, {}, None
+        try:
+            for rnd in range(4):                                 # interleaved rounds, minimum per candidate: calls of 3-10 us are noisy
+                for pick in cands:
+                    capi.setenv("QDSP_HIP_FIR_PICK", str(pick) if pick else None)
+                    op.reset()                                   # (same zero history for every candidate's checked call)
+                    op.process(x, out)
+                    name = op.last_kernel()["name"]
+                    if pick and name not in EXPECT[pick]:
+                        continue                                 # the family declined the shape
+                    if rnd == 0:
+                        y = out[: min(n, 20000)].cpu().numpy().copy()
+                        if pick == 0:
+                            y0 = y
+                        else:
+                            assert rel_rms(y, y0) < 2e-6, (n, nt, pick)
+                    op.time_dev(x, out, max(3, reps // 4))
+                    t = op.time_dev(x, out, reps)
+                    times[pick] = min(times.get(pick, 1e9), t)
+                    names[pick] = name
+        finally:
+            capi.setenv("QDSP_HIP_FIR_PICK", None)
+            op.close()
+        best = min(t for p, t in times.items() if p)
+        ratio = times[0] / best
+        worst = max(worst, ratio)
+        report.append(f"{n:9d} x {nt:4d} taps: default {names[0]} {times[0] * 1e3:7.1f} us, best alternative {best * 1e3:7.1f} us ({ratio:.3f})")
+        assert ratio <= 1.10, "\n".join(report[-3:])
+    print("\n".join(report))
+    print(f"worst default / best = {worst:.3f}")
+    torch.cuda.synchronize()
+
+
+def test_table_rows_are_reachable_and_forced_picks_fall_back_when_they_cannot_serve():
+    """A forced family that cannot serve the shape (1024 taps for the one-wave overlap-save form) hands the call back to the rule chain;
+    QDSP_HIP_NO_FIR_TABLE=1 restores the round-3 chain; explicit modes (FIR_DIRECT / FIR_FFT) are not touched by the table."""
+    import torch
+
+    from bench import lowpass_taps
+    from qdsp_amd import capi, ops
+
+    x = ops.synth_iq(1 << 16, seed=6)
+    xh = x.cpu().numpy()
+    taps = lowpass_taps(1024, 0.2)
+    capi.setenv("QDSP_HIP_FIR_PICK", "3")
+    try:
+        f = ops.Fir(taps, max_block=0)
+        y = f.process(x).cpu().numpy()
+        assert f.last_kernel()["name"] != "fir_fft1k_kernel"
+        assert rel_rms(y, O.Fir(taps, acc=O.ACC_F64).process(xh)) < 2e-6
+    finally:
+        capi.setenv("QDSP_HIP_FIR_PICK", None)
+    t64 = lowpass_taps(64, 0.2)
+    d = ops.Fir(t64, max_block=0)
+    d.set_mode(d.DIRECT)
+    yd = d.process(x).cpu().numpy()
+    assert d.last_kernel()["name"] == "fir_core_kernel" and np.array_equal(yd, O.Fir(t64, acc=O.ACC_FMA).process(xh))
+    capi.setenv("QDSP_HIP_NO_FIR_TABLE", "1")
+    try:
+        a = ops.Fir(t64, max_block=0)
+        ya = a.process(x).cpu().numpy()
+        assert rel_rms(ya, yd) < 2e-6
+    finally:
+        capi.setenv("QDSP_HIP_NO_FIR_TABLE", None)
+    torch.cuda.synchronize()

@@ -63,8 +63,9 @@ def _dev(x):
 # (what, interp, decim, ntaps, nco, call sizes and the kernel family each call must land on)
 DIRECTED = [
     ("fir", 1, 1, 63, False, [(65_536, "fir_lat_kernel")]),
-    ("fir", 1, 1, 15, False, [(2_000_000, "fir_core_kernel")]),
-    ("fir", 1, 1, 256, False, [(16_384, "fir_lat_kernel"), (1_000_000, "fir_fft1k_kernel"), (5 << 20, "fir_fft_dma_kernel")]),
+    # (round 4: FIR<complex_t> follows the measured table, qdsp_amd/csrc/dispatch_table.inc -- cells chosen away from its borders)
+    ("fir", 1, 1, 15, False, [(1_000_000, "fir_core_kernel"), (2_000_000, "fir_fft1k_kernel")]),
+    ("fir", 1, 1, 256, False, [(16_384, "fir_lat_kernel"), (1_000_000, "fir_fft1k_kernel"), (1 << 26, "fir_fft_dma_kernel")]),
     ("res", 1, 8, 256, False, [(1_000_000, "fir_fft1k_kernel"), ((1 << 23) + 8, "pfb_dec8_kernel")]),
     ("res", 1, 8, 256, True, [((1 << 24) + 16, "pfb_dec8_kernel")]),
     # round 3's big-call rule: past the measured crossovers the strided-window decimator hands chip-filling calls to the overlap-save forms

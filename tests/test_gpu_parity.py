@@ -18,7 +18,7 @@ import numpy as np
 import pytest
 
 import oracle as O
-from conftest import kname, rel_rms
+from conftest import fir_auto_family, kname, rel_rms
 
 pytestmark = pytest.mark.gpu
 
@@ -113,8 +113,27 @@ def test_fir_tap_counts_bit_exact(ops, ntaps):
     rng = np.random.default_rng(ntaps)
     taps = rng.standard_normal(ntaps).astype(np.float32)
     x = O.synth_iq(0, 5000, seed=ntaps)
+    want = O.Fir(taps, acc=O.ACC_FMA).process(x)
+    if ntaps < 300:
+        y = run_blocks(ops.Fir(taps), x, [2049, 2951])           # AUTO: the latency arrangement of the direct form
+        assert np.array_equal(y, want)
+        return
+    # 1000 taps: a wave of the latency kernel walks all taps of its 64 outputs (15 us), so the measured table (round 4,
+    # qdsp_amd/csrc/dispatch_table.inc) sends even a 2049-sample call to an overlap-save kernel (10 us): AUTO is held to the FP64
+    # oracle; both direct forms -- forced -- stay bit-exact
+    from qdsp_amd import capi
+
     y = run_blocks(ops.Fir(taps), x, [2049, 2951])
-    assert np.array_equal(y, O.Fir(taps, acc=O.ACC_FMA).process(x))
+    assert rel_rms(y, O.Fir(taps, acc=O.ACC_F64).process(x)) < TOL_FFT
+    d = ops.Fir(taps)
+    d.set_mode(d.DIRECT)
+    assert np.array_equal(run_blocks(d, x, [2049, 2951]), want) and kname(d) == "fir_core_kernel"
+    capi.setenv("QDSP_HIP_FIR_PICK", "1")
+    try:
+        la = ops.Fir(taps)
+        assert np.array_equal(run_blocks(la, x, [2049, 2951]), want) and kname(la) == "fir_lat_kernel"
+    finally:
+        capi.setenv("QDSP_HIP_FIR_PICK", None)
 
 
 def test_fir_device_path_and_block_invariance(ops, gold):
@@ -235,10 +254,10 @@ def test_fft_fir_golden_and_auto_mode(ops, gold):
     n = 400_000
     x = O.synth_iq(0, n, seed=21)
     taps = gold["taps256"]
-    f = ops.Fir(taps)           # AUTO: 256 taps, >= 65536 samples per call -> FFT
+    f = ops.Fir(taps)           # AUTO: 256 taps, 400 000 samples per call -> an overlap-save kernel (which one: the measured table)
     y = f.process(dev(x))
     torch.cuda.synchronize()
-    assert kname(f) == "fir_fft_kernel"
+    assert kname(f) == fir_auto_family(n, 256) and kname(f) in ("fir_fft_kernel", "fir_fft1k_kernel")
     want = O.Fir(taps).process(x)
     assert rel_rms(y.cpu().numpy(), want) < TOL_FFT
     # small calls stay on the direct form (bit-exact; the latency arrangement of it) and share the same history
@@ -1711,8 +1730,9 @@ def test_fft1k_small_calls_vs_oracle(ops, kind, M, ntaps):
     # which calls the 1024-point form takes: from 2^14 samples on, wherever the overlap-save path is AUTO's choice
     # (FIR from 24 taps; decimators and the VFO where neither the short-filter nor the large-decimation direct kernels win)
     if kind == "fir":
-        # (the latency-arranged direct form keeps the calls of up to 2^24 tap-samples: bit-exact, and quicker there)
-        want = ["fir_lat_kernel" if (b - a) * ntaps <= 1 << 24 and ntaps <= 320 else "fir_fft1k_kernel" for a, b in zip(cuts, cuts[1:])]
+        # (round 4: the measured table, qdsp_amd/csrc/dispatch_table.inc -- the latency-arranged direct form keeps the small calls
+        # of short and medium filters: bit-exact, and quicker there)
+        want = [fir_auto_family(b - a, ntaps) for a, b in zip(cuts, cuts[1:])]
         assert names == want, (names, want)
         assert "fir_fft1k_kernel" in names or ntaps < 97
     if kind != "fir" and ntaps >= 255 and M <= 8:
@@ -1736,9 +1756,11 @@ def test_fft1k_thresholds_and_exclusions(ops, gold, monkeypatch):
     x = ops.synth_iq(5 << 20, seed=3)
     out = torch.empty(5 << 20, dtype=torch.complex64, device="cuda")
     f = ops.Fir(taps, max_block=0)
-    for n, want in ((1 << 14, "fir_lat_kernel"), (1 << 17, "fir_fft1k_kernel"), (1_000_000, "fir_fft1k_kernel"), (4 << 20, "fir_fft1k_kernel"), (5 << 20, "fir_fft_kernel")):
+    # (FIR<complex_t>: the measured table; the 4096-point kernels take over from 2^26 samples at 256 taps -- tests/test_gpu_fuzz.py's
+    # directed plan runs that size)
+    for n, want in ((1 << 14, "fir_lat_kernel"), (1 << 17, "fir_fft1k_kernel"), (1_000_000, "fir_fft1k_kernel"), (4 << 20, "fir_fft1k_kernel"), (5 << 20, "fir_fft1k_kernel")):
         f.process(x[:n], out[:n])
-        assert kname(f) == want, (n, f.last_kernel())
+        assert kname(f) == want == fir_auto_family(n, 256), (n, f.last_kernel())
     f.set_mode(f.FFT)
     f.process(x[:1_000_000], out[:1_000_000])
     assert kname(f) == "fir_fft_kernel"
@@ -1755,11 +1777,16 @@ def test_fft1k_thresholds_and_exclusions(ops, gold, monkeypatch):
     # filters past 320 taps (a wave would walk 600 taps for each of its 64 outputs: 9.3 us on 4096 samples against 5.6)
     long_taps = np.resize(taps, 600).astype(np.float32)
     g = ops.Fir(long_taps, max_block=0)
-    for n, want in ((4096, "fir_fft1k_kernel"), (1 << 19, "fir_fft1k_kernel"), (1_000_000, "fir_fft_kernel")):
+    for n, want in ((4096, "fir_fft1k_kernel"), (1 << 19, "fir_fft1k_kernel"), (1_000_000, "fir_fft1k_kernel"), (5 << 20, "fir_fft1k_kernel")):
         g.process(x[:n], out[:n])
-        assert kname(g) == want, (n, g.last_kernel())
+        assert kname(g) == want == fir_auto_family(n, 600), (n, g.last_kernel())
     g.close()
     g = ops.Fir(np.resize(taps, 800).astype(np.float32), max_block=0)
+    g.process(x[:100_000], out[:100_000])
+    # (the table's 768-tap column names the one-wave form, whose own limit is 769 taps: the call falls back to the rule chain)
+    assert fir_auto_family(100_000, 800) is None and kname(g) == "fir_fft_kernel"
+    g.close()
+    g = ops.Fir(np.resize(taps, 1000).astype(np.float32), max_block=0)
     g.process(x[:100_000], out[:100_000])
     assert kname(g) == "fir_fft_kernel"
     g.close()
