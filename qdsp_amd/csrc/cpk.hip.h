@@ -58,7 +58,7 @@ template <bool CONJ> __device__ __forceinline__ v2f pk_cmul2(v2f a, v2f b) {   /
 __device__ __forceinline__ v2f pk_cmac2(v2f a, v2f b, v2f c) {
     v2f r = c;
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
-        : "+v"(r) : "v"(a), "v"(b));
+        : "+&v"(r) : "v"(a), "v"(b));      // early clobber: the first FMA writes r while a and b are still to be read by the second
     return r;
 }
 

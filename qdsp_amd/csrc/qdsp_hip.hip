@@ -886,7 +886,8 @@ bool fft_eligible(const Engine* e, int64_t count) {
             int need = 32 * e->M;
             if (big) {
                 static const int t[9] = {0, 0, 144, 128, 192, 176, 224, 224, 384};
-                need = e->M <= 8 ? t[e->M] : win_limit(e->M) ? win_limit(e->M) + 1 : 128;
+                // (swept: decimations 1-5, 8, 10, 12, 16 -- profiles/r03_sweep_real.txt; past 16 the round-2 rule stays: ADVICE round 3)
+                need = e->M <= 8 ? t[e->M] : win_limit(e->M) ? win_limit(e->M) + 1 : e->M <= 16 ? 128 : 32 * e->M;
             }
             if (min_taps < need) min_taps = need;
         }

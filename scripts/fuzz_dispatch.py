@@ -20,8 +20,8 @@ KNOBS = ("QDSP_HIP_NO_FFT1K_REAL", "QDSP_HIP_NO_FFT1K", "QDSP_HIP_MF_BATCH_MIN_W
          "QDSP_HIP_RM_MIN_INTERP", "QDSP_HIP_NO_LM_SMALL_CALL_RULE", "QDSP_HIP_PFB_MIN_COUNT")
 
 
-def run(budget, seed, default_only=False, verbose=True):
-    """Random cases for `budget` seconds; returns (cases, worst relative RMS error, {kernel family: cases}).  default_only: the
+def run(budget, seed, default_only=False, verbose=True, max_cases=None):
+    """Random cases for `budget` seconds (max_cases: stop after that many cases instead -- a count does not depend on the box's speed); returns (cases, worst relative RMS error, {kernel family: cases}).  default_only: the
     library's own thresholds throughout (no QDSP_HIP_* variable is touched) -- what tests/test_gpu_fuzz.py runs; otherwise one
     case in two or three has a size rule switched off so that both sides of every crossover keep being exercised."""
     def knob(name, value):
@@ -35,7 +35,7 @@ def run(budget, seed, default_only=False, verbose=True):
     t_end = time.time() + budget
     n_cases, kernels, worst = 0, {}, 0.0
     t_note = time.time()
-    while time.time() < t_end:
+    while (time.time() < t_end) if max_cases is None else (n_cases < max_cases):
         if time.time() - t_note > 30:
             t_note = time.time()
             print(f"... {n_cases} cases, worst {worst:.2e}", flush=True) if verbose else None

@@ -38,12 +38,62 @@ def demangle(names):
         return names
 
 
+def dma_wait_check(asm: str):
+    """Kernels that prefetch by LDS-DMA count their own vector-memory operations: `s_waitcnt vmcnt(N)` (inline asm) waits for the DMA and leaves
+    the N stores issued after it in flight (fft_fir.hip, chan.hip).  N is written by hand; what hipcc emits is checked here:
+    for every such N the kernel must contain N global stores in one stretch of adjacent basic blocks that hold stores and no vector-memory
+    load -- the full tile / segment's store sequence (one block when the stores are unconditional; one block per store when each is
+    predicated, as the FIR's overlap test makes them; hipcc also tail-merges the last store of two unrolled copies).  A split 16-byte store
+    or a spilled register would change the count.  Returns [(kernel, N, ok)]."""
+    out = []
+    for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end", asm, re.S | re.M):
+        name, body = m.group(1), m.group(2)
+        if "global_load_lds" not in body:
+            continue
+        waits = sorted({int(n) for n in re.findall(r";;#ASMSTART\n\s*s_waitcnt vmcnt\((\d+)\)", body)} - {0})
+        if not waits:
+            continue
+        runs, stores, loads = [], 0, 0
+        for ln in body.splitlines():
+            t = ln.strip()
+            if not t or t.startswith(";"):
+                continue
+            if t.endswith(":") or t.startswith(("s_cbranch", "s_branch", "s_endpgm")):
+                runs.append((stores, loads))
+                stores = loads = 0
+            elif t.startswith(("global_store", "buffer_store", "scratch_store")):
+                stores += 1
+            elif t.startswith(("global_load", "buffer_load", "scratch_load", "global_atomic")):
+                loads += 1
+        runs.append((stores, loads))
+        def found(n):
+            for i in range(len(runs)):
+                tot = 0
+                for st, ld in runs[i:]:
+                    if ld or not st:
+                        break
+                    tot += st
+                    if tot == n:
+                        return True
+                    if tot > n:
+                        break
+            return False
+
+        for n in waits:
+            out.append((name, n, found(n)))
+    return out
+
+
 def main():
-    rows = []
+    rows, dma = [], []
     for unit, extra in UNITS.items():
+        asm_path = f"/tmp/qdsp_ru_{unit}.s"
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", *extra.split(), "-S", "--cuda-device-only",
-               "-Rpass-analysis=kernel-resource-usage", "-o", "/dev/null", f"{unit}.hip"]
+               "-Rpass-analysis=kernel-resource-usage", "-o", asm_path, f"{unit}.hip"]
         err = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True).stderr
+        if os.path.exists(asm_path):
+            dma += dma_wait_check(open(asm_path).read())
+            os.remove(asm_path)
         cur = None
         for line in err.splitlines():
             m = re.search(r"remark: (?:Function Name: (\S+)|\s+(\S[^:]*): (\d+))", line)
@@ -57,11 +107,15 @@ def main():
     names = demangle([r["name"] for r in rows])
     with open(OUT, "w") as f:
         f.write(f"# sources {source_hash()}  (qdsp_amd/csrc: *.hip, *.hip.h)  -- scripts/resource_usage.py, hipcc -Rpass-analysis=kernel-resource-usage, gfx950\n")
+        dnames = demangle([d[0] for d in dma])
+        for (_, n, ok), dn in zip(dma, dnames):
+            f.write(f"# dma-wait {'ok ' if ok else 'BAD'} s_waitcnt vmcnt({n}): {n} stores in adjacent load-free blocks {'found' if ok else 'NOT FOUND'} in {dn}\n")
         f.write(f"# {len(rows)} kernel instantiations; columns: unit, VGPRs, SGPRs, SGPRs spilled (to VGPR lanes), VGPRs spilled, scratch bytes/lane, waves/SIMD, LDS bytes (static), kernel\n")
         for r, n in zip(rows, names):
             f.write(f"{r['unit']:10s} {r.get('VGPRs', -1):4d} {r.get('TotalSGPRs', -1):4d} {r.get('SGPRs Spill', -1):4d} {r.get('VGPRs Spill', -1):4d} "
                     f"{r.get('ScratchSize [bytes/lane]', -1):5d} {r.get('Occupancy [waves/SIMD]', -1):2d} {r.get('LDS Size [bytes/block]', -1):6d}  {n}\n")
     bad = [n for r, n in zip(rows, names) if r.get("ScratchSize [bytes/lane]", 1) != 0 or r.get("VGPRs Spill", 1) != 0]
+    bad += [f"dma-wait vmcnt({n}) of {k}" for k, n, ok in dma if not ok]
     print(f"{len(rows)} kernels -> {OUT}; with scratch or spilled VGPRs: {len(bad)}")
     for n in bad:
         print("  ", n)

@@ -116,6 +116,9 @@ def test_no_kernel_uses_scratch():
     assert lines[0].split()[2] == ru.source_hash(), "qdsp_amd/csrc changed: run `python scripts/resource_usage.py` and commit the table"
     rows = [ln.split(None, 8) for ln in lines if ln and not ln.startswith("#")]
     assert len(rows) > 300
+    # hand-counted `s_waitcnt vmcnt(N)` behind the LDS-DMA prefetches: N matches the stores hipcc emitted
+    waits = [ln for ln in lines if ln.startswith("# dma-wait")]
+    assert len(waits) >= 4 and all(ln.startswith("# dma-wait ok") for ln in waits), [ln for ln in waits if "BAD" in ln]
     bad = [r[8] for r in rows if int(r[4]) != 0 or int(r[5]) != 0]
     assert not bad, f"kernels with spilled VGPRs / scratch: {bad}"
     # the kernels of the bench legs keep the occupancy DESIGN.md quotes

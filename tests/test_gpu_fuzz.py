@@ -177,12 +177,19 @@ def test_directed_channel_banks_default_thresholds(ops):
 
 
 def test_random_slice_default_thresholds_covers_every_family(ops):
-    """60 s of scripts/fuzz_dispatch.py (seed fixed) with no threshold touched, then: every kernel family of the dispatch has
-    been exercised by this module."""
+    """A fixed NUMBER of cases of scripts/fuzz_dispatch.py (seed fixed; a count, not a wall-clock budget, so a slower box runs the same
+    cases) with no threshold touched, then: every kernel family of the dispatch has been exercised.  Self-contained: the
+    directed plans above are run from here when this test is selected on its own (-k, xdist) and their families are not on record yet."""
     import fuzz_dispatch
 
     assert _no_overrides()
-    n, worst, kernels = fuzz_dispatch.run(float(os.environ.get("QDSP_TEST_FUZZ_SECONDS", "60")), 20260403, default_only=True, verbose=False)
+    if not _SEEN:
+        for plan in DIRECTED:
+            test_directed_plans_default_thresholds(ops, plan)
+        for plan in REAL_DIRECTED:
+            test_directed_real_plans_default_thresholds(ops, plan)
+        test_directed_channel_banks_default_thresholds(ops)
+    n, worst, kernels = fuzz_dispatch.run(600.0, 20260403, default_only=True, verbose=False, max_cases=int(os.environ.get("QDSP_TEST_FUZZ_CASES", "1500")))
     assert n >= 20 and worst < TOL, (n, worst, kernels)
     seen = _SEEN | set(kernels)
     print(f"fuzz slice: {n} cases, worst {worst:.2e}; families seen by this module: {sorted(seen)}")
