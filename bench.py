@@ -353,7 +353,7 @@ def run_workload(name: str, args, ctx) -> dict:
     x = ops.synth_iq(n, first_sample=rank * n, seed=1234, device=local_rank)
     nout = n // w["decim"] * w.get("interp", 1)
     # channel rows 32 samples (256 bytes) longer than the data: with a power-of-two row stride (2^24 samples at M = 8) the 64 lines a
-    # tile writes -- one per channel -- fall on the same memory channel (chan64m8: 2.85 ms, 2.46 with the pad).  The
+    # tile writes -- one per channel -- fall on the same memory channel (chan64m8: 2.85 ms, 2.46 with the pad; EXPERIMENTS.md section 4).  The
     # stride is the caller's to choose (qdsp_hip_chan_cf32_process_dev's out_stride argument); reported in config.out_row_stride.
     out = torch.empty((w["nchan"], nout + CHAN_ROW_PAD) if is_chan else nout, dtype=torch.complex64, device=dev)
     ring = RingStream(op, n, rank, world, transport="host" if rehearse else "device", align=align,
@@ -683,7 +683,7 @@ def main():
                              "hbm_roofline_msps": leg["hbm_roofline_msps"], "frac_of_hbm_roofline_msps": leg["frac_of_hbm_roofline_msps"],
                              **({"rccl": leg["rccl"]} if "rccl" in leg else {})}
         if world == 1 and not args.no_block_call:
-            # what a block of the reference's graph gets per call (latency-bound: DESIGN.md "Reference-sized calls")
+            # what a block of the reference's graph gets per call (latency-bound: DESIGN.md section 5, EXPERIMENTS.md "Reference-sized calls")
             line["block_call"] = block_call(args.workload, ctx)
             if chain is not None:
                 line["chain"]["block_call"] = block_call("xlate_fir_decim8", ctx)

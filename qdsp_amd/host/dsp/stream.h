@@ -33,7 +33,7 @@
 #include "qdsp_hip.h"
 
 // Elements per buffer: the reference's value (src/dsp/stream.h:7) unless the build says otherwise.  It is also the most a block hands
-// to the library per call, and a GPU call costs 5-10 us whatever its size (DESIGN.md "Through the block graph"): a graph that is
+// to the library per call, and a GPU call costs 5-10 us whatever its size (EXPERIMENTS.md "Through the block graph"): a graph that is
 // free to choose its block size gets more of the kernels' rate with -DSTREAM_BUFFER_SIZE=4194304 or 16777216
 // (profiles/r04_graph_bench.txt; qdsp_amd/host/Makefile builds graph_check_big that way).  Every block of a graph must be compiled
 // with the same value.

@@ -124,7 +124,9 @@ def test_no_kernel_uses_scratch():
     # the kernels of the bench legs keep the occupancy DESIGN.md quotes
     occ = {r[8]: int(r[6]) for r in rows}
     assert occ["qk::fir_fft_dma_kernel"] == 4 and occ["qk::pfb_dec8_kernel<true>"] == 2
-    assert all(v == 3 for k, v in occ.items() if k.startswith("qk::chan_uniform_kernel<") and ", 0>" in k and "64" not in k)
+    # (the channelizer's oversampled forms are held to three workgroups per CU by their LDS, whatever the registers allow; M = 64 needs four)
+    chan = {k: v for k, v in occ.items() if k.startswith("qk::chan_uniform_kernel<")}
+    assert len(chan) == 32 and all(v >= 3 for v in chan.values()) and all(v == 4 for k, v in chan.items() if ", 64, " in k)
 
 
 def test_fir_dispatch_table_is_what_the_committed_sweep_gives():
