@@ -4,6 +4,8 @@
 //
 //   graph_check taps   <out.f32>                      window designers -> tap tables (no GPU)
 //   graph_check stream                                stream/block protocol self-test (no GPU)
+//   graph_check fail                                  a block whose GPU handle could not be created: its worker ends, the failure is
+//                                                     visible through dsp::hipBlockErrors() / hipBlockLastError()
 //   graph_check fir    <in.cf32> <out.cf32> <block> <taps.f32>
 //   graph_check fir63  <in.cf32> <out.cf32> <block>   BlackmanWindow(0.1 fs, 4 fs/63, fs=1)
 //   graph_check firf   <in.f32>  <out.f32>  <block> <taps.f32>          (FIR<float>)
@@ -243,6 +245,28 @@ int main(int argc, char** argv) {
     const std::string mode = argv[1];
     if (mode == "taps" && argc >= 3) { return dumpTaps(argv[2]); }
     if (mode == "stream") { return streamSelfTest(); }
+    if (mode == "fail") {
+        // an empty tap table cannot make a handle (QDSP_HIP_EINVAL): init reports it, the worker's first run() ends the block
+        struct NoTaps : filter_window::generic_window {
+            int getTapCount() override { return 0; }
+            void createTaps(float*, int, float) override {}
+        } none;
+        const long before = hipBlockErrors();
+        HandlerSource<complex_t> src([](complex_t* d, void*) { d[0] = complex_t{1.0f, 0.0f}; return 1; }, nullptr);
+        FIR<complex_t> fir(&src.out, &none);
+        NullSink<complex_t> sink(&fir.out);
+        sink.start();
+        fir.start();
+        src.start();
+        std::this_thread::sleep_for(std::chrono::milliseconds(50));
+        src.stop();
+        fir.stop();
+        sink.stop();
+        const char* who = nullptr;
+        const int code = hipBlockLastError(&who);
+        printf("errors %ld code %d who %s\n", hipBlockErrors() - before, code, who ? who : "-");
+        return (hipBlockErrors() > before && code != 0 && who) ? 0 : 1;
+    }
     if (mode == "sine" && argc >= 7) {
         const int bs = atoi(argv[3]), nb = atoi(argv[4]);
         SineSource src(bs, (float)atof(argv[5]), (float)atof(argv[6]));

@@ -96,6 +96,15 @@ def blocks(op, x, b):
     return np.concatenate([op.process(x[i:i + b]) for i in range(0, len(x), b)])
 
 
+def test_block_failures_are_counted_where_a_host_can_poll_them(harness):
+    """A block whose GPU call fails reports once on stderr and ends its worker (the reference has no error channel, block.h:55-57); the
+    failure is also counted process-wide: dsp::hipBlockErrors() / hipBlockLastError().  Runs with or without a GPU: an empty tap table
+    (or, here, no device at all) cannot make a handle."""
+    r = subprocess.run([harness, "fail"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "errors 1" in r.stdout and "FIR::init" in r.stdout and "[qdsp_hip] FIR::init" in r.stderr
+
+
 @gpu
 def test_graph_fir63(harness, data):
     d, x = data
