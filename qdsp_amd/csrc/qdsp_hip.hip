@@ -1768,6 +1768,11 @@ int64_t process_dev(Engine* e, const void* d_in, int64_t count, void* d_out, voi
     if (e->kind == KIND_FIR && e->ch == 2 && e->has_filter && mode_of(e) == 0) {
         const int forced = qk::knob(qk::K_FIR_PICK, 0);               // 1..4: the sweep and the regression test force a family
         e->auto_pick = forced >= PICK_LAT && forced <= PICK_FFT4K ? forced : qk::knob(qk::K_NO_FIR_TABLE, 0) ? PICK_NONE : fir_table_pick(count, e->ntaps);
+        // (QDSP_HIP_FFT1K_MAX_COUNT, the tests' way of pinning the 4096-point kernels at oracle-sized inputs, outranks the table)
+        if (e->auto_pick == PICK_FFT1K && !forced) {
+            const int cap = qk::knob(qk::K_FFT1K_MAX_COUNT, -1);
+            if ((cap >= 0 && count > cap) || qk::knob(qk::K_NO_FFT1K, 0)) e->auto_pick = PICK_FFT4K;
+        }
         // structural limits of the family named: none for the direct form; the others fall back to the rule chain
         if ((e->auto_pick == PICK_LAT && e->ntaps > 1024) || (e->auto_pick == PICK_FFT1K && e->ntaps > 769) ||
             ((e->auto_pick == PICK_FFT1K || e->auto_pick == PICK_FFT4K) && !fft_dec(e)))

@@ -257,7 +257,9 @@ def test_fft_fir_golden_and_auto_mode(ops, gold):
     f = ops.Fir(taps)           # AUTO: 256 taps, 400 000 samples per call -> an overlap-save kernel (which one: the measured table)
     y = f.process(dev(x))
     torch.cuda.synchronize()
-    assert kname(f) == fir_auto_family(n, 256) and kname(f) in ("fir_fft_kernel", "fir_fft1k_kernel")
+    # (this module pins the 4096-point kernels at oracle-sized inputs -- conftest: QDSP_HIP_FFT1K_MAX_COUNT=0 outranks the measured table,
+    # which names the one-wave form here; the table itself is followed by the default_dispatch tests and tests/test_gpu_dispatch.py)
+    assert kname(f) == "fir_fft_kernel" and fir_auto_family(n, 256) == "fir_fft1k_kernel"
     want = O.Fir(taps).process(x)
     assert rel_rms(y.cpu().numpy(), want) < TOL_FFT
     # small calls stay on the direct form (bit-exact; the latency arrangement of it) and share the same history
