@@ -81,6 +81,12 @@ struct Engine {
     int cur = 0;
     hipStream_t last_stream = nullptr;   // process_ex / generate: the stream of the previous call (its own or the shared one)
     hipEvent_t done_ev = nullptr;        // QDSP_HIP_LINK_HOST_DEFERRED: recorded behind the call's work instead of waiting for it
+    // Host input of a block-graph call (process_ex, round 4): the upload runs on its OWN stream, ordered behind the previous call's kernel (which read
+    // the staging buffer) and in front of this call's kernel by events -- so block k + 1's host-to-device copy overlaps block k's device-to-host copy
+    // (two DMA directions, two streams) and the call returns as soon as the input buffer has been read.
+    hipStream_t up_stream = nullptr;
+    hipEvent_t ev_up = nullptr, ev_kernel = nullptr;
+    bool kernel_recorded = false;
     size_t hist_cap = 0;        // samples
     // host-pointer path
     hipStream_t stream = nullptr;

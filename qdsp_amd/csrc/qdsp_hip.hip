@@ -488,6 +488,9 @@ void destroy(Engine* e) {
     if (e->d_out) (void)hipFree(e->d_out);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->ev_up) (void)hipEventDestroy(e->ev_up);
+    if (e->ev_kernel) (void)hipEventDestroy(e->ev_kernel);
+    if (e->up_stream) (void)hipStreamDestroy(e->up_stream);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     e->magic = 0;
     delete e;
@@ -1899,7 +1902,23 @@ int64_t process_ex(Engine* e, const void* in, int in_dev, int count, void* out, 
     if (e->last_stream && e->last_stream != st) HIPCHK(hipStreamSynchronize(e->last_stream));   // (links re-plumbed)
     e->last_stream = st;
     const void* src = in;
-    if (!in_dev) {
+    // Host input + deferred host output into pinned memory (HandlerSource -> block -> sink on the mirror's pinned streams): see Engine::up_stream
+    const bool split_upload = !in_dev && count > 0 && out_dev == QDSP_HIP_LINK_HOST_DEFERRED && e->done_ev && mapped_host_ptr(out) && mapped_host_ptr(const_cast<void*>(in)) &&
+                              !qk::knob(qk::K_NO_SPLIT_UPLOAD, 0);
+    if (split_upload) {
+        if (!e->up_stream) {
+            HIPCHK(hipStreamCreateWithFlags(&e->up_stream, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&e->ev_up, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&e->ev_kernel, hipEventDisableTiming));
+        }
+        if (e->kernel_recorded) HIPCHK(hipStreamWaitEvent(e->up_stream, e->ev_kernel, 0));      // the previous kernel has read d_in
+        HIPCHK(hipMemcpyAsync(e->d_in, in, (size_t)count * e->ch * sizeof(float), hipMemcpyHostToDevice, e->up_stream));
+        HIPCHK(hipEventRecord(e->ev_up, e->up_stream));
+        HIPCHK(hipStreamWaitEvent(st, e->ev_up, 0));
+        src = e->d_in;
+    } else if (!in_dev) {
+        // (an earlier split upload of this handle may still be in flight on the other stream: same staging buffer)
+        if (e->up_stream && e->kernel_recorded) HIPCHK(hipStreamWaitEvent(st, e->ev_up, 0));
         if (count) HIPCHK(hipMemcpyAsync(e->d_in, in, (size_t)count * e->ch * sizeof(float), hipMemcpyHostToDevice, st));
         src = e->d_in;
     }
@@ -1922,6 +1941,10 @@ int64_t process_ex(Engine* e, const void* in, int in_dev, int count, void* out, 
     }
     const int64_t nout = process_dev(e, src, count, dst, st);
     if (nout < 0) return nout;
+    if (split_upload) {
+        HIPCHK(hipEventRecord(e->ev_kernel, st));
+        e->kernel_recorded = true;
+    }
     if (!out_dev && !direct_out && nout)
         HIPCHK(hipMemcpyAsync(out, e->d_out, (size_t)nout * e->ch * sizeof(float), hipMemcpyDeviceToHost, st));
     // a block handed to a pipelined link need not be complete; a host input must have left its buffer, though
@@ -1932,6 +1955,11 @@ int64_t process_ex(Engine* e, const void* in, int in_dev, int count, void* out, 
         // (a device input from a producer outside the shared stream must have been read before this call returns
         // and the block flushes it: only a pipelined input lets the call go without waiting)
         if (in_dev == QDSP_HIP_LINK_PIPELINED && (direct_out || nout == 0 || mapped_host_ptr(out))) return nout;
+        if (split_upload) {
+            // the input buffer is the caller's again once the upload has read it; the results travel behind done_ev
+            HIPCHK(hipEventSynchronize(e->ev_up));
+            return nout;
+        }
         HIPCHK(hipEventSynchronize(e->done_ev));
         return nout;
     }

@@ -27,10 +27,12 @@
 //                      blocks in a row, the two links between them device-resident
 //   graph_check math   <in.cf32> <out.cf32> <block> add|sub|mul <sampleRate> <freq>
 //                      source -> Splitter -> { FrequencyXlator, identity } -> Add | Substract | Multiply -> sink
-//   graph_check bench  vfo|chain|split<n> <blockSize> <nblocks> <inSR> <outSR>
+//   graph_check bench  vfo|chain|split<n>|hostfir|hostvfo <blockSize> <nblocks> <inSR> <outSR>
 //                      throughput of a live graph: SineSource -> VFO -> sink, or SineSource -> FrequencyXlator ->
 //                      PolyphaseResampler -> sink (the same two blocks unfused, device-resident link between them);
-//                      prints input Msamples/s and microseconds per block
+//                      prints input Msamples/s and microseconds per block.  hostfir / hostvfo: a HOST source (HandlerSource whose handler
+//                      leaves the pinned block as it is) -> FIR<complex_t> (256 taps) / VFO -> host sink: what an unmodified qdsp
+//                      graph with host-resident streams gets -- the PCIe link both ways
 //   graph_check split  <in.cf32> <out_prefix> <block> <n> <inSR> <outSR> <bw>
 //                      source -> Splitter -> n x VFO(offset_i = (i - (n-1)/2) * inSR/n) -> sinks
 //   graph_check splitretune <in.cf32> <out_prefix> <block> <n> <inSR> <outSR> <bw> <K> <newOffset> [reconf]
@@ -361,7 +363,42 @@ int main(int argc, char** argv) {
             for (auto* v : vfos) { delete v; }
             for (auto* l : legs) { delete l; }
             return 0;
-        } else { fprintf(stderr, "bench kind: vfo | chain | split<n>\n"); return 2; }
+        } else if (kind == "hostfir" || kind == "hostvfo") {
+            struct Blk { int n; } blk{bs};
+            HandlerSource<complex_t> hsrc([](complex_t* d, void* c) { d[0] = complex_t{1.0f, 0.0f}; return static_cast<Blk*>(c)->n; }, &blk);
+            struct Flat : filter_window::generic_window {
+                int getTapCount() override { return 256; }
+                void createTaps(float* t, int n, float f = 1.0f) override { for (int i = 0; i < n; i++) { t[i] = f / (float)n; } }
+            } flat;
+            FIR<complex_t>* hfir = kind == "hostfir" ? new FIR<complex_t>(&hsrc.out, &flat) : nullptr;
+            VFO* hvfo = kind == "hostvfo" ? new VFO(&hsrc.out, inSR * 0.1f, inSR, outSR, outSR) : nullptr;
+            HandlerSink<complex_t> hsink(hfir ? &hfir->out : hvfo->out, Count::push, &cnt);
+            hsink.start();
+            if (hfir) { hfir->start(); } else { hvfo->start(); }
+            hsrc.start();
+            auto wait_n = [&](long n) {
+                const auto t0 = std::chrono::steady_clock::now();
+                while (cnt.blocks.load() < n) {
+                    std::this_thread::sleep_for(std::chrono::microseconds(200));
+                    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) { return false; }
+                }
+                return true;
+            };
+            if (!wait_n(nb / 10 + 2)) { fprintf(stderr, "bench graph timed out\n"); return 3; }
+            const long b0 = cnt.blocks.load();
+            const auto t0 = std::chrono::steady_clock::now();
+            if (!wait_n(b0 + nb)) { fprintf(stderr, "bench graph timed out\n"); return 3; }
+            const long b1 = cnt.blocks.load();
+            const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            hsrc.stop();
+            if (hfir) { hfir->stop(); } else { hvfo->stop(); }
+            hsink.stop();
+            printf("bench %s: %ld blocks of %d in %.4f s = %.1f Msamples/s in, %.1f us per block\n", kind.c_str(), b1 - b0, bs, sec,
+                   (double)(b1 - b0) * bs / sec / 1e6, sec / (double)(b1 - b0) * 1e6);
+            delete hfir;
+            delete hvfo;
+            return 0;
+        } else { fprintf(stderr, "bench kind: vfo | chain | split<n> | hostfir | hostvfo\n"); return 2; }
         HandlerSink<complex_t> sink(tail, Count::push, &cnt);
         sink.start();
         if (vfo) { vfo->start(); }

@@ -5,7 +5,7 @@
 set -u
 H=qdsp_amd/host/build
 echo "# graph_check bench <kind> <block> <nblocks> 2400000 48000: SineSource -> ... -> sinks on the block-graph mirror, one thread per block, device-resident links"
-for kind in vfo chain split4 split16; do
+for kind in vfo chain split4 split16 hostfir hostvfo; do
   for bs in 65536 1000000; do $H/graph_check bench $kind $bs 300 2400000 48000 2>/dev/null; done
   for bs in 1048576 2097152 4194304 8388608 16777216; do
     nb=$((300 * 1048576 / bs)); [ $nb -lt 20 ] && nb=20
