@@ -445,8 +445,9 @@ def run_workload(name: str, args, ctx) -> dict:
             "ring_ranks_requested": world,
             # what ncclCommCount says on rank 0, and the smallest / largest answer over all ranks
             "ring_comm_ranks": info.get("comm_ranks"),
-            "ring_comm_ranks_min": int(-ctrl_reduce(-float(info.get("comm_ranks", -1)))) if world > 1 else info.get("comm_ranks"),
-            "ring_comm_ranks_max": int(ctrl_reduce(float(info.get("comm_ranks", -1)))) if world > 1 else info.get("comm_ranks"),
+            # (no C ring -- rehearsal over gloo, or the torch p2p fallback -- : None; the reductions still run so that every rank issues the same collectives)
+            "ring_comm_ranks_min": (lambda v: int(v) if c_ring is not None else None)(-ctrl_reduce(-float(info.get("comm_ranks", -1)))) if world > 1 else info.get("comm_ranks"),
+            "ring_comm_ranks_max": (lambda v: int(v) if c_ring is not None else None)(ctrl_reduce(float(info.get("comm_ranks", -1)))) if world > 1 else info.get("comm_ranks"),
             "ring_comm_device": info.get("comm_device"),
             "rccl_version": info.get("rccl_version"),
             "halo_bytes": H * 8,
