@@ -97,6 +97,7 @@ struct Engine {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // overlap-save fast convolution (FIR<complex_t> with many taps), fft_fir.hip.h
     int fir_mode = 0;           // 0 auto, 1 direct form, 2 overlap-save FFT
+    int auto_veto = 0, auto_mode = 0;   // integer decimators / fused VFO, AUTO: per-call exceptions to the rule chain named by the measured table (decim_table.inc)
     int auto_pick = 0;          // FIR<complex_t>, AUTO: the kernel family the measured table names for this call (dispatch_table.inc), 0 = the rule chain
     float2* d_fft_H = nullptr;  // spectrum of the reversed taps / F, digit-reversed
     float2* d_fft_TA = nullptr;

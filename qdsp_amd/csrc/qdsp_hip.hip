@@ -120,6 +120,8 @@ int64_t out_size(const Engine* e, int64_t count) {
 // fir_core_kernel (de-interleaved tile): FIR and decimations up to 8.  From 9 on the general kernel with its
 // staged-as-it-lies tile is 2-3x faster (scripts/tune_large_decim.py: M = 9..16, 31-255 taps: 0.12-0.38 ms per
 // 2^26 samples against 0.26-0.54).
+// per-call exceptions the measured decimator table may raise against the rule chain (process_dev sets Engine::auto_veto / auto_mode)
+enum { VETO_WIN = 1, VETO_FFT1K = 2, VETO_PFB = 4, VETO_MF = 8 };
 bool use_core(const Engine* e) { return e->L == 1 && e->M <= 8 && !qk::knob(qk::K_FORCE_ANY, 0); }
 
 // decimators served by decim_win_kernel (kernels.hip.h): interp 1, short filters.  Outputs per lane and the
@@ -147,7 +149,7 @@ bool use_win(const Engine* e) {
     // 2 / 4 / 8 / 16 -- pruned inverse -- and 0.20-0.21 ms at every other decimation: full inverse, strided store)
     // ([1] = FIR<T> and equal-rate resamplers below the overlap-save threshold: 0.22 ms against 0.25 de-interleaved)
     const int max_taps = qk::knob(qk::K_WIN_MAX_TAPS, win_limit(M));
-    return e->P <= max_taps && qk::knob(qk::K_NO_WIN, 0) == 0;
+    return e->P <= max_taps && qk::knob(qk::K_NO_WIN, 0) == 0 && !(e->auto_veto & VETO_WIN);
 }
 
 // interp / decim pairs served by resamp_lm_kernel (kernels.hip.h)
@@ -820,7 +822,12 @@ int fft_dec(const Engine* e) {
     return 0;
 }
 
-int mode_of(const Engine* e) { return e->fir_mode ? e->fir_mode : qk::knob(qk::K_FIR_MODE, 0); }
+// explicit settings (set_mode, QDSP_HIP_FIR_MODE) outrank the table's per-call mode
+int mode_of(const Engine* e) {
+    if (e->fir_mode) return e->fir_mode;
+    const int k = qk::knob(qk::K_FIR_MODE, 0);
+    return k ? k : e->auto_mode;
+}
 
 // ---- FIR<complex_t>, AUTO: which kernel family serves a call of `count` samples with `ntaps` taps -------------------------------------------
 // Round 4: this one choice is DATA, not an if-chain.  scripts/sweep_fir_table.py times the four families on a grid of
@@ -831,6 +838,26 @@ int mode_of(const Engine* e) { return e->fir_mode ? e->fir_mode : qk::knob(qk::K
 // predicates) hands the call back to the rule chain.
 enum FirPick { PICK_NONE = 0, PICK_LAT = 1, PICK_CORE = 2, PICK_FFT1K = 3, PICK_FFT4K = 4 };
 #include "dispatch_table.inc"
+// The switch settings the decimator sweep tries (scripts/sweep_decim_table.py lists them in the same order): what each one vetoes / which mode it sets.
+constexpr int kDecimSettingVeto[16] = {0, VETO_WIN, VETO_FFT1K, VETO_WIN | VETO_FFT1K, 0, 0, VETO_PFB, VETO_PFB, VETO_MF, 0, 0, 0, 0, 0, 0, 0};
+constexpr int kDecimSettingMode[16] = {0, 0, 0, 0, 1, 2, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0};
+#include "decim_table.inc"
+int decim_table_setting(int rot, int M, int ntaps, int64_t count) {
+    if (qk::knob(qk::K_NO_DECIM_TABLE, 0) || count <= 0) return 0;
+    int mi = -1;
+    for (int i = 0; i < kDecimTabMs; i++)
+        if (kDecimTabM[i] == M) mi = i;
+    if (mi < 0 || ntaps < kDecimTabTaps[0] / 2) return 0;
+    int lg = 0;
+    while ((int64_t(1) << (lg + 1)) <= count) lg++;
+    if (count - (int64_t(1) << lg) > (int64_t(1) << lg) * 0.41421356) lg++;
+    int row = lg - kDecimTabLog2Min;
+    row = row < 0 ? 0 : row >= kDecimTabRows ? kDecimTabRows - 1 : row;
+    int col = 0;
+    for (int c = 1; c < kDecimTabCols; c++)
+        if ((double)ntaps * ntaps >= (double)kDecimTabTaps[c - 1] * kDecimTabTaps[c]) col = c;
+    return kDecimTab[rot][mi][row][col];
+}
 int fir_table_pick(int64_t count, int ntaps) {
     if (count <= 0 || ntaps < kFirPickTaps[0]) return PICK_NONE;
     int lg = 0;
@@ -867,7 +894,7 @@ bool fft1k_eligible(const Engine* e, int64_t count);
 
 bool fft_eligible(const Engine* e, int64_t count) {
     if (!fft_dec(e)) return false;
-    int mode = e->fir_mode ? e->fir_mode : qk::knob(qk::K_FIR_MODE, 0);
+    int mode = mode_of(e);
     if (mode == 1) return false;
     if (mode == 2) return true;
     if (e->auto_pick) return e->auto_pick == PICK_FFT1K || e->auto_pick == PICK_FFT4K;
@@ -1039,8 +1066,8 @@ bool fft1k_eligible(const Engine* e, int64_t count) {
     if (e->L != 1 || e->ntaps < 2 || e->ntaps > 769) return false;   // (769 taps: a quarter of every segment is new)
     if (e->kind != KIND_FIR && e->kind != KIND_DECIM && e->kind != KIND_VFO) return false;
     if (e->ch != 2 && (e->kind == KIND_VFO || e->rotate || qk::knob(qk::K_NO_FFT1K_REAL, 0))) return false;   // real data: two real segments per wave
-    const int mode = e->fir_mode ? e->fir_mode : qk::knob(qk::K_FIR_MODE, 0);
-    if (mode != 0 || qk::knob(qk::K_NO_FFT1K, 0)) return false;
+    const int mode = mode_of(e);
+    if (mode != 0 || qk::knob(qk::K_NO_FFT1K, 0) || (e->auto_veto & VETO_FFT1K)) return false;
     if (e->auto_pick) return e->auto_pick == PICK_FFT1K;
     const int forced = qk::knob(qk::K_FFT1K_MAX_COUNT, -1);
     if (forced >= 0) return count <= forced;
@@ -1202,7 +1229,7 @@ bool pfb_eligible(const Engine* e, int64_t count) {
     if (e->ch != 2 || e->L != 1 || (e->M != qk::kPfbD && e->M != 4) || e->ntaps < 2) return false;
     if (e->kind != KIND_DECIM && e->kind != KIND_VFO) return false;
     if (pfb_Q(e) > qk::kPfbMaxQ) return false;
-    if (qk::knob(qk::K_NO_PFB, 0) || (e->M == 4 && 0)) return false;
+    if (qk::knob(qk::K_NO_PFB, 0) || (e->auto_veto & VETO_PFB)) return false;
     // measured crossover (scripts/tune_pfb_threshold.py, 256 taps): a lone segment takes a wave ~7 us (15 us per call
     // with the table load) where fir_fft_kernel<8> needs 8 us, so the per-segment kernels keep the reference-sized
     // calls; from 2^23 samples (decimator) / 2^24 (fused VFO) on this form is ahead, 1.2x at 2^27
@@ -1768,6 +1795,17 @@ int64_t process_dev(Engine* e, const void* d_in, int64_t count, void* d_out, voi
     int rc = 0;
     bool took_fft = false;
     e->auto_pick = PICK_NONE;
+    e->auto_veto = 0;
+    e->auto_mode = 0;
+    if ((e->kind == KIND_DECIM || e->kind == KIND_VFO) && e->ch == 2 && e->has_filter && e->L == 1 && e->M >= 2 && e->fir_mode == 0 && qk::knob(qk::K_FIR_MODE, 0) == 0) {
+        // Integer decimators and the fused VFO on complex data: the rule chain below decides, EXCEPT where the measured table
+        // (decim_table.inc <- profiles/r04_sweep_decim_table.txt, scripts/gen_dispatch_table.py) found one of eight switch settings more than
+        // 4 % faster in the call's cell.  QDSP_HIP_DECIM_SETTING = 1..8 forces a setting (the sweep, the regression test), 0 = rules only.
+        const int forced = qk::knob(qk::K_DECIM_SETTING, -1);
+        const int setting = forced >= 0 ? forced : decim_table_setting(e->rotate ? 1 : 0, e->M, e->ntaps, count);
+        e->auto_veto = kDecimSettingVeto[setting & 15];
+        e->auto_mode = kDecimSettingMode[setting & 15];
+    }
     if (e->kind == KIND_FIR && e->ch == 2 && e->has_filter && mode_of(e) == 0) {
         const int forced = qk::knob(qk::K_FIR_PICK, 0);               // 1..4: the sweep and the regression test force a family
         e->auto_pick = forced >= PICK_LAT && forced <= PICK_FFT4K ? forced : qk::knob(qk::K_NO_FIR_TABLE, 0) ? PICK_NONE : fir_table_pick(count, e->ntaps);
@@ -1786,7 +1824,7 @@ int64_t process_dev(Engine* e, const void* d_in, int64_t count, void* d_out, voi
     } else if (mode_of(e) == 0 && fir_lat_eligible(e, count)) {
         rc = launch_fir_lat(e, d_in, count, d_out, s);
         if (rc == 0) e->cur ^= 1;
-    } else if (e->d_taps_mf && mode_of(e) == 0 && nout > 0 && count >= mf_min_count(e) && !qk::knob(qk::K_NO_MF, 0)) {
+    } else if (e->d_taps_mf && mode_of(e) == 0 && nout > 0 && count >= mf_min_count(e) && !qk::knob(qk::K_NO_MF, 0) && !(e->auto_veto & VETO_MF)) {
         // large integer decimations (the VFO's usual job) as an FP32 matrix product on the MFMA units (mf_dec.hip.h)
         rc = launch_mf(e, d_in, count, nout, d_out, s);
         if (rc == 0) e->cur ^= 1;

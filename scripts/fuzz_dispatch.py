@@ -17,7 +17,8 @@ def floor_of(x, taps):
 
 
 KNOBS = ("QDSP_HIP_NO_FFT1K_REAL", "QDSP_HIP_NO_FFT1K", "QDSP_HIP_MF_BATCH_MIN_WORK", "QDSP_HIP_MF_MIN_COUNT", "QDSP_HIP_RM_MIN_COUNT",
-         "QDSP_HIP_RM_MIN_INTERP", "QDSP_HIP_NO_LM_SMALL_CALL_RULE", "QDSP_HIP_PFB_MIN_COUNT")
+         "QDSP_HIP_RM_MIN_INTERP", "QDSP_HIP_NO_LM_SMALL_CALL_RULE", "QDSP_HIP_PFB_MIN_COUNT", "QDSP_HIP_DECIM_SETTING", "QDSP_HIP_FIR_PICK",
+         "QDSP_HIP_NO_FIR_TABLE", "QDSP_HIP_NO_DECIM_TABLE")
 
 
 def run(budget, seed, default_only=False, verbose=True, max_cases=None):

@@ -113,3 +113,72 @@ def test_table_rows_are_reachable_and_forced_picks_fall_back_when_they_cannot_se
     finally:
         capi.setenv("QDSP_HIP_NO_FIR_TABLE", None)
     torch.cuda.synchronize()
+
+
+def _decim_shapes():
+    rng = np.random.default_rng(20260406)
+    grid = [(rot, M, 1 << lg, t) for rot in (0, 1) for M, lg, t in ((10, 13, 1024), (16, 15, 1024), (10, 14, 256), (8, 24, 64), (3, 20, 128), (2, 22, 256), (4, 18, 64), (8, 20, 256),
+                                                                    (5, 16, 32), (8, 26, 256), (4, 26, 256), (16, 22, 128))]
+    between = []
+    while len(between) < 16:
+        M = int(rng.choice([2, 3, 4, 5, 8, 10, 16]))
+        n = int(2 ** rng.uniform(12, 25))
+        t = int(2 ** rng.uniform(4, 10))
+        between.append((int(rng.integers(0, 2)), M, n - n % M, max(8, t)))
+    return (grid + between)[:40]
+
+
+def test_default_decimator_dispatch_is_within_10_percent_of_the_best_setting():
+    """Integer decimators and the fused VFO (complex data): the rule chain + the measured exception table (qdsp_amd/csrc/decim_table.inc <-
+    profiles/r04_sweep_decim_table.txt) against the eight switch settings of the sweep, on 40 fixed shapes (cells where round 3's rules lost
+    30-45 %, grid cells, shapes in between).  The default must be within 10 % of the best setting; results must agree between settings."""
+    import torch
+
+    from bench import lowpass_taps
+    from qdsp_amd import capi, ops
+
+    inc = ops.phase_delta(1.0, 0.1234)
+    worst, report = 0.0, []
+    for rot, M, n, nt in _decim_shapes():
+        taps = lowpass_taps(nt, 0.45 / M)
+        x = ops.synth_iq(n, seed=7)
+        out = torch.empty(n // M + 8, dtype=torch.complex64, device="cuda")
+        op = ops.Vfo(taps, 1, M, inc, max_block=0) if rot else ops.Resampler(taps, 1, M, max_block=0)
+        times, names, y0 = {}, {}, None
+        try:
+            for rnd in range(3):
+                seen = set()
+                for k in [None] + list(range(9)):                # None = the shipped default (rules + table); 0 = rules only; 1..8 settings
+                    capi.setenv("QDSP_HIP_DECIM_SETTING", None if k is None else str(k))
+                    if k == 4 and n * nt // M > (1 << 30):
+                        continue
+                    op.reset()
+                    op.process(x, out)
+                    name = op.last_kernel()["name"]
+                    if k is not None and name in seen and k != 0:
+                        continue
+                    if k is not None:
+                        seen.add(name)
+                    if rnd == 0:
+                        y = out[: min(n // M, 20000)].cpu().numpy().copy()
+                        if k is None:
+                            y0 = y
+                        else:
+                            assert rel_rms(y, y0) < 4e-6, (rot, M, n, nt, k, name)
+                    work = n * (nt / M if name in ("fir_core_kernel", "decim_win_kernel", "resamp_any_kernel") else 16)
+                    reps = max(3, min(100, int(5e-3 / max(3e-6, work * 2.5e-13))))
+                    op.time_dev(x, out, max(2, reps // 4))
+                    t = op.time_dev(x, out, reps)
+                    times[k] = min(times.get(k, 1e9), t)
+                    names[k] = name
+        finally:
+            capi.setenv("QDSP_HIP_DECIM_SETTING", None)
+            op.close()
+        best = min(t for k, t in times.items() if k is not None)
+        ratio = times[None] / best
+        worst = max(worst, ratio)
+        report.append(f"rot {rot} M {M:2d} {n:9d} x {nt:4d} taps: default {names[None]} {times[None] * 1e3:7.1f} us, rules only {times[0] * 1e3:7.1f}, best {best * 1e3:7.1f} ({ratio:.3f})")
+        assert ratio <= 1.10, "\n".join(report[-3:])
+    print("\n".join(report))
+    print(f"worst default / best = {worst:.3f}")
+    torch.cuda.synchronize()

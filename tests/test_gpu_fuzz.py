@@ -69,14 +69,18 @@ DIRECTED = [
     ("res", 1, 8, 256, False, [(1_000_000, "fir_fft1k_kernel"), ((1 << 23) + 8, "pfb_dec8_kernel")]),
     ("res", 1, 8, 256, True, [((1 << 24) + 16, "pfb_dec8_kernel")]),
     # round 3's big-call rule: past the measured crossovers the strided-window decimator hands chip-filling calls to the overlap-save forms
-    ("res", 1, 8, 128, True, [(3_000_000, "decim_win_kernel"), ((1 << 24) + 8, "pfb_dec8_kernel")]),
+    # (round 4: the decimators' rule chain has measured exceptions, qdsp_amd/csrc/decim_table.inc -- e.g. the strided-window kernel keeps the
+    # 2^24-sample calls of this 128-tap fused VFO (34.7 us against 59.3 on the polyphase kernel), which takes over at 2^26)
+    ("res", 1, 8, 128, True, [(3_000_000, "decim_win_kernel"), ((1 << 24) + 8, "decim_win_kernel"), ((1 << 26) + 8, "pfb_dec8_kernel")]),
     # (... and decimate-by-2 changes form inside fir_fft_kernel at 2^25 samples: pruned inverse below, full inverse + every other output kept above)
     # fused VFO through the full inverse, big enough (> 4096 segments) that workgroups take a second segment: the segment phasor they
     # carry in LDS from one to the next (round 3's four-workgroup form of fir_fft_kernel<1, ROT>)
     ("res", 1, 3, 256, True, [((1 << 24) + 2 * 4096 + 3, "fir_fft_kernel")]),
-    ("res", 1, 2, 128, False, [(3_000_000, "decim_win_kernel"), ((1 << 24) + 2, "fir_fft_kernel"), ((1 << 25) + 6, "fir_fft_kernel")]),
+    ("res", 1, 2, 128, False, [(200_000, "fir_fft1k_kernel"), (3_000_000, "fir_core_kernel"), ((1 << 24) + 2, "fir_fft_kernel"), ((1 << 25) + 6, "fir_fft_kernel")]),
     ("res", 1, 4, 63, False, [(200_000, "decim_win_kernel")]),
-    ("res", 1, 4, 160, True, [(2_000_000, "decim_win_kernel"), ((1 << 26) + 4, "pfb_dec4_kernel")]),
+    ("res", 1, 4, 160, True, [(2_000_000, "fir_core_kernel"), ((1 << 26) + 4, "pfb_dec4_kernel")]),
+    ("res", 1, 10, 1024, False, [(8192, "resamp_any_kernel")]),      # (a table exception: 5.5 us against 10.2 on the overlap-save kernel the rules pick)
+    ("res", 1, 8, 63, False, [(100_000, "decim_win_kernel"), (3_000_000, "decim_win_kernel")]),
     ("res", 1, 16, 129, True, [(300_000, "decim_mfma_kernel")]),
     ("res", 1, 50, 401, True, [(100_000, "resamp_any_kernel"), (3_200_000, "decim_mfma_kernel")]),
     ("res", 3, 2, 36, False, [(100_000, "resamp_lm_kernel")]),
