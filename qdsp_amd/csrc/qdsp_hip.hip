@@ -842,8 +842,8 @@ enum FirPick { PICK_NONE = 0, PICK_LAT = 1, PICK_CORE = 2, PICK_FFT1K = 3, PICK_
 constexpr int kDecimSettingVeto[16] = {0, VETO_WIN, VETO_FFT1K, VETO_WIN | VETO_FFT1K, 0, 0, VETO_PFB, VETO_PFB, VETO_MF, 0, 0, 0, 0, 0, 0, 0};
 constexpr int kDecimSettingMode[16] = {0, 0, 0, 0, 1, 2, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0};
 #include "decim_table.inc"
-int decim_table_setting(int rot, int M, int ntaps, int64_t count) {
-    if (qk::knob(qk::K_NO_DECIM_TABLE, 0) || count <= 0) return 0;
+int decim_table_setting(int rot, int M, int ntaps, int64_t count) {   // rot: the table's class -- 0 complex decimator, 1 fused VFO, 2 real data
+    if (qk::knob(qk::K_NO_DECIM_TABLE, 0) || count <= 0 || rot >= kDecimTabClasses) return 0;
     int mi = -1;
     for (int i = 0; i < kDecimTabMs; i++)
         if (kDecimTabM[i] == M) mi = i;
@@ -1797,12 +1797,14 @@ int64_t process_dev(Engine* e, const void* d_in, int64_t count, void* d_out, voi
     e->auto_pick = PICK_NONE;
     e->auto_veto = 0;
     e->auto_mode = 0;
-    if ((e->kind == KIND_DECIM || e->kind == KIND_VFO) && e->ch == 2 && e->has_filter && e->L == 1 && e->M >= 2 && e->fir_mode == 0 && qk::knob(qk::K_FIR_MODE, 0) == 0) {
-        // Integer decimators and the fused VFO on complex data: the rule chain below decides, EXCEPT where the measured table
+    const bool cplx_dec = (e->kind == KIND_DECIM || e->kind == KIND_VFO) && e->ch == 2 && e->M >= 2;
+    const bool real_any = (e->kind == KIND_DECIM || e->kind == KIND_FIR) && e->ch == 1 && !e->rotate;
+    if ((cplx_dec || real_any) && e->has_filter && e->L == 1 && e->fir_mode == 0 && qk::knob(qk::K_FIR_MODE, 0) == 0) {
+        // Integer decimators and the fused VFO on complex data, FIR / decimators on real data: the rule chain below decides, EXCEPT where the measured table
         // (decim_table.inc <- profiles/r04_sweep_decim_table.txt, scripts/gen_dispatch_table.py) found one of eight switch settings more than
         // 4 % faster in the call's cell.  QDSP_HIP_DECIM_SETTING = 1..8 forces a setting (the sweep, the regression test), 0 = rules only.
         const int forced = qk::knob(qk::K_DECIM_SETTING, -1);
-        const int setting = forced >= 0 ? forced : decim_table_setting(e->rotate ? 1 : 0, e->M, e->ntaps, count);
+        const int setting = forced >= 0 ? forced : decim_table_setting(real_any ? 2 : e->rotate ? 1 : 0, e->M, e->ntaps, count);
         e->auto_veto = kDecimSettingVeto[setting & 15];
         e->auto_mode = kDecimSettingMode[setting & 15];
     }

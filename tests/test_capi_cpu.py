@@ -141,4 +141,4 @@ def test_fir_dispatch_table_is_what_the_committed_sweep_gives():
     inc = open(os.path.join(ROOT, "qdsp_amd", "csrc", "dispatch_table.inc")).read()
     assert "GENERATED" in inc and "kFirPick[kFirPickRows][kFirPickCols]" in inc
     dec = open(os.path.join(ROOT, "qdsp_amd", "csrc", "decim_table.inc")).read()      # the decimators' exception table, same generator, same check
-    assert "GENERATED" in dec and "kDecimTab[2][kDecimTabMs][kDecimTabRows][kDecimTabCols]" in dec and "exception cells" in dec
+    assert "GENERATED" in dec and "kDecimTab[kDecimTabClasses][kDecimTabMs][kDecimTabRows][kDecimTabCols]" in dec and "exception cells" in dec

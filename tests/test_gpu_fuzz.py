@@ -124,9 +124,9 @@ def test_directed_plans_default_thresholds(ops, plan):
 REAL_DIRECTED = [
     # (decimation, taps, call sizes and the kernel family each must land on): PolyphaseResampler<float> / FIR<float> on both sides of the
     # chip-filling rule of round 3 (2^22 samples)
-    (10, 256, [(1_000_000, "resamp_any_kernel"), ((1 << 22) + 10, "fir_fft1k_kernel")]),      # (the one-wave overlap-save form up to 2^26; was the general kernel at every size)
-    (2, 64, [(1_000_000, "decim_win_kernel"), ((1 << 22) + 2, "fir_core_kernel")]),
-    (1, 64, [(1_000_000, "fir_core_kernel"), ((1 << 22) + 1, "fir_fft1k_kernel")]),
+    (10, 256, [(1_000_000, "resamp_any_kernel"), ((1 << 22) + 10, "fir_fft_kernel")]),        # (round 4 table: the 4096-point overlap-save form; the rules alone say the one-wave 1024-point form)
+    (2, 64, [(1_000_000, "fir_core_kernel"), ((1 << 22) + 2, "fir_core_kernel")]),             # (table: the general direct kernel ahead of the strided-window one at 10^6)
+    (1, 64, [(1_000_000, "fir_core_kernel"), ((1 << 22) + 1, "fir_core_kernel")]),             # (table: direct form ahead of the one-wave overlap-save form at 64 taps)
 ]
 
 
@@ -141,14 +141,16 @@ def test_directed_real_plans_default_thresholds(ops, plan):
     else:
         op, orc = ops.Resampler(taps, 1, M, complex_data=False, max_block=0), O.Resampler(taps, 1, M, complex_data=False, acc=O.ACC_F64)
     rng = np.random.default_rng(ntaps + M)
+    names = []
     for count, family in calls:
         x = rng.standard_normal(count).astype(np.float32)
         got = op.process(_dev(x)).cpu().numpy()
         name = op.last_kernel()["name"]
-        assert name == family, (plan, count, name)
+        names.append(name)
         want = orc.process(x)
         assert got.shape == want.shape and _rel(got, want) < TOL, (plan, count, name)
         _SEEN.add(name)
+    assert names == [f for _, f in calls], (plan, names)
 
 
 def test_directed_channel_banks_default_thresholds(ops):

@@ -1912,11 +1912,14 @@ def test_long_decimators_on_short_calls_take_the_one_wave_overlap_save(ops, gold
 @pytest.mark.default_dispatch
 @pytest.mark.parametrize("M", [1, 2, 3, 8])
 @pytest.mark.parametrize("ntaps", [97, 256, 513])
-def test_fft1k_real_data(ops, M, ntaps):
+def test_fft1k_real_data(ops, M, ntaps, monkeypatch):
     """FIR<float> / PolyphaseResampler<float> (interp 1) on the one-wave overlap-save kernel: two consecutive real segments ride
     one 1024-point complex transform as re / im.  Ragged block sequence (odd lengths, a block shorter than the history, one
-    that ends inside the first segment of a pair), small members on the direct kernels, against the FP64 oracle."""
+    that ends inside the first segment of a pair), small members on the direct kernels, against the FP64 oracle.  Rules alone: the
+    measured exceptions of round 4 (decim_table.inc class 2) hand some of these 150 000-sample calls to the direct kernels."""
     import torch
+
+    monkeypatch.setenv("QDSP_HIP_NO_DECIM_TABLE", "1")
 
     rng = np.random.default_rng(4100 + ntaps + M)
     taps = (rng.standard_normal(ntaps) / np.sqrt(ntaps)).astype(np.float32)
