@@ -139,8 +139,26 @@ template <int KJ, bool ROT, int DEPTH, int QS> __device__ __forceinline__ void d
         if (plainb[d]) load_tile(d, xb[d]);
     }
     float carry_re = 0.0f, carry_im = 0.0f, carry2_re = 0.0f, carry2_im = 0.0f;
+    // The outputs of a tile are stored one tile LATER, behind an explicit wait for the next tile's samples.  gfx950 counts loads and stores on
+    // one counter (vmcnt) and the store sits behind a lane test, so hipcc's wait for the next tile's samples is vmcnt(0): issued at the end of
+    // its own tile the store was the youngest request in flight at that wait and every tile paid a write round trip (rounds 2-3).  Issued
+    // here it is a whole tile's arithmetic old when the next wait comes (profiles/r04_mf_deferred_store.txt: -1 ... -10 % from 2^22 samples on; a
+    // reference-sized call, two or three tiles per wave, is 0.2 us quicker the old way: a.defer_store, wave-uniform).
+    float pend_re = 0.0f, pend_im = 0.0f;
+    auto store_tile = [&](int tt) {                           // the outputs tile tt completed (those of tile tt - QS)
+        const long long n = n0 + 16LL * (tt - QS) + l;
+        if (tt >= QS && l < 16 && n < n1) {
+            // keep2: the kernel runs at half the decimation (rows of M / 2 samples: decimations 130-256) and every other output is the call's
+            if (!a.keep2) a.out[n] = make_float2(pend_re, pend_im);
+            else if (!(n & 1)) a.out[n >> 1] = make_float2(pend_re, pend_im);
+        }
+    };
     auto do_tile = [&](int tt, float2 (&xn)[NI], bool& plain) {
         const long long g0 = gbase + (long long)E * tt;
+        if (a.defer_store) {
+            __builtin_amdgcn_s_waitcnt(0x0f70);               // vmcnt(0): this tile's samples (and stores that are a tile old)
+            if (tt > 0) store_tile(tt - 1);
+        }
         // NCO: lane phasor of the tile (FP64 recurrence, rounded once) x the FP32 table exp(j 64 i dphase) inside it,
         // x VOLK's magnitude sawtooth 1 + (g mod 512) gm1 (rotate(), kernels.hip.h): g advances by 64 per load, so the
         // sawtooth takes 8 values per lane and tile, folded into 8 copies of the lane phasor
@@ -225,18 +243,16 @@ template <int KJ, bool ROT, int DEPTH, int QS> __device__ __forceinline__ void d
         o_im += __shfl_xor(o_im, 16);
         o_re += __shfl_xor(o_re, 32);
         o_im += __shfl_xor(o_im, 32);
-        const long long n = n0 + 16LL * (tt - QS) + l;
-        if (tt >= QS && l < 16 && n < n1) {
-            // keep2: the kernel runs at half the decimation (rows of M / 2 samples: decimations 130-256) and every other output is the call's
-            if (!a.keep2) a.out[n] = make_float2(o_re, o_im);
-            else if (!(n & 1)) a.out[n >> 1] = make_float2(o_re, o_im);
-        }
+        pend_re = o_re;
+        pend_im = o_im;
+        if (!a.defer_store) store_tile(tt);
     };
     for (int tt = 0; tt < ntiles; tt += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; d++)
             if (tt + d < ntiles) do_tile(tt + d, xb[d], plainb[d]);
     }
+    if (a.defer_store && ntiles > 0) store_tile(ntiles - 1);
 }
 
 template <int KJ, bool ROT, int DEPTH, int QS>

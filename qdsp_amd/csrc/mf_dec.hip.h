@@ -50,6 +50,7 @@ struct MfArgs {
     double2 rot_step;             // exp(j 2pi 16 M dphase): one tile further
     float2 rot_k[2 * kMfMaxKJ];   // exp(j 2pi 64 i dphase): load i of a tile
     float gm1;
+    int defer_store;              // 1: a tile's outputs are stored one tile later, behind the wait for the next tile's samples (chip-filling calls: mf_dec.hip)
 };
 
 // N channels of one filter design in one launch (blockIdx.y = channel): the non-uniform channelizer and the

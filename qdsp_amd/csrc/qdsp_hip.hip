@@ -1582,6 +1582,7 @@ void mf_tasks(qk::MfArgs& a, int64_t nout, int nchan, bool rot) {
     a.T = (int)T;
     a.ntasks = (int)((nout + T - 1) / T);
     a.minv = (unsigned)(((1ull << 32) + a.M - 1) / a.M);
+    a.defer_store = (long long)a.count * nchan >= (1LL << 22);      // (profiles/r04_mf_deferred_store.txt)
 }
 // NCO tables: one tile (16 M samples) further in FP64, load i of a tile (64 i samples) in FP32
 void mf_rot_tables(unsigned long long dphase, int M, int KJ, double2* step, float2* rot_k) {
