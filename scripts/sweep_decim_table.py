@@ -19,7 +19,7 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 from qdsp_amd import capi, ops  # noqa: E402
 
-MS = [2, 3, 4, 5, 8, 10, 16]
+MS = [2, 3, 4, 5, 8, 10, 16, 20, 25, 32, 50, 64, 100]      # (20 ... 100: the VFO's usual decimations, 2.4 Msps -> 48 kHz is 50)
 TAPS = [16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 512, 768, 1024]
 LOG2 = list(range(12, 28))
 NSET = 9
@@ -34,8 +34,11 @@ def main():
     xr = torch.view_as_real(xall)[:, 0].contiguous()          # real samples for class 2 (FIR<float> / PolyphaseResampler<float>)
     orl = torch.empty((1 << LOG2[-1]) + 64, dtype=torch.float32, device="cuda")
     classes = [int(c) for c in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0", "1", "2"])]
+    only_ms = [int(m) for m in sys.argv[2].split(",")] if len(sys.argv) > 2 else None      # (a partial sweep: merge its lines into the profile file)
     for rot in classes:
         for M in ([1] + MS if rot == 2 else MS):
+            if only_ms is not None and M not in only_ms:
+                continue
             for nt in TAPS:
                 taps = bench.lowpass_taps(nt, 0.45 / M)
                 if rot == 2:
