@@ -844,10 +844,19 @@ constexpr int kDecimSettingMode[16] = {0, 0, 0, 0, 1, 2, 0, 2, 0, 0, 0, 0, 0, 0,
 #include "decim_table.inc"
 int decim_table_setting(int rot, int M, int ntaps, int64_t count) {   // rot: the table's class -- 0 complex decimator, 1 fused VFO, 2 real data
     if (qk::knob(qk::K_NO_DECIM_TABLE, 0) || count <= 0 || rot >= kDecimTabClasses) return 0;
+    // the decimation's row: below 10 the swept decimation itself or none (the kernel families change from one small decimation to the next: 6 on
+    // 5's row lost 40 % where the rules were right); from 10 on -- general direct kernel, overlap-save, MFMA decimator at every decimation -- the
+    // swept decimation nearest on a log scale (12 -> 10, 40 -> 32, 80 -> 64), inside the swept range.  The settings only take kernels AWAY from
+    // the rule chain or name the family, so a neighbour's setting is always valid; tests/test_gpu_dispatch.py holds unswept decimations to
+    // the same 10 % as swept ones.
+    if (M < kDecimTabM[0] || M > kDecimTabM[kDecimTabMs - 1] || ntaps < kDecimTabTaps[0] / 2) return 0;
     int mi = -1;
     for (int i = 0; i < kDecimTabMs; i++)
         if (kDecimTabM[i] == M) mi = i;
-    if (mi < 0 || ntaps < kDecimTabTaps[0] / 2) return 0;
+    for (int i = 1; i < kDecimTabMs && mi < 0; i++)
+        if (kDecimTabM[i - 1] >= 10 && M > kDecimTabM[i - 1] && M < kDecimTabM[i])
+            mi = (long long)M * M >= (long long)kDecimTabM[i - 1] * kDecimTabM[i] ? i : i - 1;      // (the geometric mean is the border)
+    if (mi < 0) return 0;
     int lg = 0;
     while ((int64_t(1) << (lg + 1)) <= count) lg++;
     if (count - (int64_t(1) << lg) > (int64_t(1) << lg) * 0.41421356) lg++;

@@ -128,12 +128,15 @@ def _decim_shapes():
     # the VFO's usual decimations (20 ... 100, swept later in round 4): cells where the rules alone lose 1.9-2.0x, the 2.4 Msps -> 48 kHz shape, in-between shapes
     big = [(0, 64, 1 << 15, 1024), (1, 25, 1 << 14, 1024), (0, 50, 1 << 13, 1024), (1, 50, 1000000, 401), (0, 32, 1 << 16, 768), (1, 100, 1 << 22, 801), (0, 20, 1 << 20, 200),
            (1, 64, 1 << 24, 512)]
-    return (grid + between)[:40] + big
+    # decimations the sweep does NOT hold: from 10 on they read the row of the nearest swept one, below that the rules alone (decim_table_setting, qdsp_hip.hip)
+    unswept = [(0, 12, 3 << 12, 1024), (1, 40, 5 << 11, 1024), (0, 6, 3 << 19, 128), (1, 7, 7 << 18, 64), (0, 14, 7 << 11, 896), (0, 24, 3 << 20, 256), (1, 80, 5 << 18, 640), (0, 48, 3 << 13, 768),
+               (1, 13, 13 << 16, 208)]
+    return (grid + between)[:40] + big + unswept
 
 
 def test_default_decimator_dispatch_is_within_10_percent_of_the_best_setting():
     """Integer decimators and the fused VFO (complex data): the rule chain + the measured exception table (qdsp_amd/csrc/decim_table.inc <-
-    profiles/r04_sweep_decim_table.txt) against the eight switch settings of the sweep, on 48 fixed shapes (cells where round 3's rules lost
+    profiles/r04_sweep_decim_table.txt) against the eight switch settings of the sweep, on 57 fixed shapes (cells where round 3's rules lost
     30-45 %, grid cells, shapes in between).  The default must be within 10 % of the best setting; results must agree between settings."""
     import torch
 
@@ -198,7 +201,8 @@ def test_default_real_data_dispatch_is_within_10_percent_of_the_best_setting():
 
     shapes = [(10, 1 << 14, 1024), (16, 1 << 14, 1024), (10, 1 << 13, 384), (16, 1 << 17, 1024), (10, 1 << 12, 512), (1, 1 << 20, 64),
               (1, 1 << 24, 256), (2, 1 << 22, 128), (3, 3 << 18, 96), (4, 1 << 24, 64), (5, 5 << 16, 256), (8, 1 << 26, 128),
-              (25, 25 << 9, 1024), (32, 1 << 14, 1024), (20, 5 << 15, 1024), (50, 1000000, 401)]
+              (25, 25 << 9, 1024), (32, 1 << 14, 1024), (20, 5 << 15, 1024), (50, 1000000, 401),
+              (12, 3 << 12, 1024), (40, 5 << 12, 768), (6, 3 << 20, 128), (7, 7 << 15, 512)]      # (the last four: unswept decimations, nearest row)
     rng = np.random.default_rng(4)
     for _ in range(12):
         M = int(rng.choice([1, 2, 3, 4, 5, 8, 10, 16]))
