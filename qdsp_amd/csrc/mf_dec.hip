@@ -1,5 +1,6 @@
 // mf_dec.hip -- MFMA decimator for large integer decimations (design notes: mf_dec.hip.h).
 #include "mf_dec.hip.h"
+#include <type_traits>
 #include "kernels.hip.h"
 
 namespace qk {
@@ -58,26 +59,38 @@ __device__ __forceinline__ void diag_sum(const f32x4 d, float& cur, float& prev)
 }  // namespace
 
 // rot_k: the NCO table exp(j 64 i dphase) -- the kernel arguments' (one channel) or the channel's row of the device table
-template <int KJ, bool ROT, int DEPTH, int QS> __device__ __forceinline__ void decim_mfma_body(const MfArgs& a, const float2* __restrict__ rot_k) {
-    constexpr int K = 8 * KJ, PITCH = K + 2, NI = 2 * KJ;
+// RD (round 4): REAL data -- PolyphaseResampler<float> with interp 1 (src/dsp/resampling.h:113-118).  A sample is one float: the same rows, the
+// same A operands (tapk) and k order, half the bytes, half the LDS traffic and only the "re" products -- the even and the odd columns of a step
+// accumulate in two registers sets (two independent MFMA chains, as re / im are in the complex form) that are added at the end.
+template <int KJ, bool ROT, int DEPTH, int QS, bool RD = false> __device__ __forceinline__ void decim_mfma_body(const MfArgs& a, const float2* __restrict__ rot_k) {
+    static_assert(!(RD && ROT), "the NCO is a complex operator");
+    using S = typename std::conditional<RD, float, float2>::type;      // one sample
+    // row pitch in samples: K + 2 complex = 4 x odd dwords (every ds_read_b128 group on 16 distinct 4-bank groups); K + 4 real = 4 x odd dwords
+    // as well (the ds_read_b64 of 32 lanes -- 16 rows x 2 column pairs -- on 32 distinct bank pairs)
+    constexpr int K = 8 * KJ, PITCH = RD ? K + 4 : K + 2, NI = 2 * KJ;
     const int t = threadIdx.x, l = t & 63;
     const int P = a.P, M = a.M;
+    const S* __restrict__ in_s = reinterpret_cast<const S*>(a.in);
+    const S* __restrict__ hist_s = reinterpret_cast<const S*>(a.hist);
+    S* __restrict__ out_s = reinterpret_cast<S*>(a.out);
+    auto zero_s = [] { if constexpr (RD) return 0.0f; else return make_float2(0.0f, 0.0f); };
     if ((int)blockIdx.x == (a.ntasks + 3) / 4) {
         // history hand-over (resampling.h:129): last P samples of hist ++ in, rotated for the fused VFO
+        S* hist_next_s = reinterpret_cast<S*>(a.hist_next);
         for (int i = t; i < P; i += 256) {
             const long long g = a.count - P + i;
-            float2 v;
-            if (g < 0) v = a.hist[g + P];
+            S v;
+            if (g < 0) v = hist_s[g + P];
             else {
-                v = a.in[g];
-                if (ROT) v = rotate(v, phasor_fx(a.phase0 + (unsigned long long)g * a.dphase), g, a.gm1);
+                v = in_s[g];
+                if constexpr (ROT) v = rotate(v, phasor_fx(a.phase0 + (unsigned long long)g * a.dphase), g, a.gm1);
             }
-            a.hist_next[i] = v;
+            hist_next_s[i] = v;
         }
         return;
     }
-    __shared__ __attribute__((aligned(16))) float2 tile_all[4][16 * PITCH + 64];      // + a spare slot per lane
-    float2* tile = tile_all[t >> 6];
+    __shared__ __attribute__((aligned(16))) S tile_all[4][16 * PITCH + 64];      // + a spare slot per lane
+    S* tile = tile_all[t >> 6];
     const int task = (int)blockIdx.x * 4 + (t >> 6);
     if (task >= a.ntasks) return;
     const long long n0 = (long long)task * a.T;
@@ -89,7 +102,7 @@ template <int KJ, bool ROT, int DEPTH, int QS> __device__ __forceinline__ void d
     // columns M..K-1 of the rows are never written: they meet zero taps, but must hold finite values
     for (int i = l; i < 16 * (K - M); i += 64) {
         const int row = i / (K - M);
-        tile[row * PITCH + M + (i - row * (K - M))] = make_float2(0.0f, 0.0f);
+        tile[row * PITCH + M + (i - row * (K - M))] = zero_s();
     }
 
     // tap set s = tap rows 16 s .. 16 s + 15 (QS = 2: up to 32 taps per column)
@@ -111,23 +124,24 @@ template <int KJ, bool ROT, int DEPTH, int QS> __device__ __forceinline__ void d
         woff[i] = idx < E ? row * PITCH + (idx - row * M) : 16 * PITCH + l;
     }
     const int e1 = min(64 * (NI - 2) + l, E - 1), e2 = min(64 * (NI - 1) + l, E - 1);
-    // B operand of this lane: row l % 16, columns 8 jj + 2 (l / 16) + {0, 1}
-    const float4* brd = reinterpret_cast<const float4*>(tile + (l & 15) * PITCH + 2 * (l >> 4));
+    // B operand of this lane: row l % 16, columns 8 jj + 2 (l / 16) + {0, 1} -- one ds_read_b128 (complex) / ds_read_b64 (real) per step
+    using B2 = typename std::conditional<RD, float2, float4>::type;
+    const B2* brd = reinterpret_cast<const B2*>(tile + (l & 15) * PITCH + 2 * (l >> 4));
 
     const long long gbase = (long long)M * n0 - P;            // sample index (relative to in[0]) of tile 0's element 0
     double2 pd;
     if (ROT) pd = phasor_fx(a.phase0 + (unsigned long long)(gbase + l) * a.dphase);
 
     // DEPTH tiles are in flight in registers ahead of the one being multiplied
-    float2 xb[DEPTH][NI];
+    S xb[DEPTH][NI];
     bool plainb[DEPTH];
     const bool tail = 64 * (NI - 1) < E;                      // wave-uniform: the last load holds samples of the tile at all
     auto tile_plain = [&](int tt) {                           // wave-uniform: the whole tile is plain input
         const long long g0 = gbase + (long long)E * tt;
         return tt < ntiles && g0 >= 0 && g0 + E <= a.count;
     };
-    auto load_tile = [&](int tt, float2 (&xn)[NI]) {
-        const float2* __restrict__ p = a.in + (gbase + (long long)E * tt);
+    auto load_tile = [&](int tt, S (&xn)[NI]) {
+        const S* __restrict__ p = in_s + (gbase + (long long)E * tt);
 #pragma unroll
         for (int i = 0; i < NI - 2; i++) xn[i] = p[64 * i + l];
         xn[NI - 2] = p[e1];
@@ -149,11 +163,13 @@ template <int KJ, bool ROT, int DEPTH, int QS> __device__ __forceinline__ void d
         const long long n = n0 + 16LL * (tt - QS) + l;
         if (tt >= QS && l < 16 && n < n1) {
             // keep2: the kernel runs at half the decimation (rows of M / 2 samples: decimations 130-256) and every other output is the call's
-            if (!a.keep2) a.out[n] = make_float2(pend_re, pend_im);
-            else if (!(n & 1)) a.out[n >> 1] = make_float2(pend_re, pend_im);
+            S o;
+            if constexpr (RD) o = pend_re; else o = make_float2(pend_re, pend_im);
+            if (!a.keep2) out_s[n] = o;
+            else if (!(n & 1)) out_s[n >> 1] = o;
         }
     };
-    auto do_tile = [&](int tt, float2 (&xn)[NI], bool& plain) {
+    auto do_tile = [&](int tt, S (&xn)[NI], bool& plain) {
         const long long g0 = gbase + (long long)E * tt;
         if (a.defer_store) {
             __builtin_amdgcn_s_waitcnt(0x0f70);               // vmcnt(0): this tile's samples (and stores that are a tile old)
@@ -163,7 +179,7 @@ template <int KJ, bool ROT, int DEPTH, int QS> __device__ __forceinline__ void d
         // x VOLK's magnitude sawtooth 1 + (g mod 512) gm1 (rotate(), kernels.hip.h): g advances by 64 per load, so the
         // sawtooth takes 8 values per lane and tile, folded into 8 copies of the lane phasor
         f32x2 pg[8];
-        if (ROT) {
+        if constexpr (ROT) {
             const f32x2 pf = {(float)pd.x, (float)pd.y};
             const int m0 = (int)((g0 + l) & 511);
 #pragma unroll
@@ -177,7 +193,10 @@ template <int KJ, bool ROT, int DEPTH, int QS> __device__ __forceinline__ void d
         if (plain) {
 #pragma unroll
             for (int i = 0; i < NI; i++)
-                if (i < NI - 1 || tail) tile[woff[i]] = ROT ? spin(xn[i], i) : xn[i];
+                if (i < NI - 1 || tail) {
+                    if constexpr (ROT) tile[woff[i]] = spin(xn[i], i);
+                    else tile[woff[i]] = xn[i];
+                }
         } else {
             // a tile that touches the history or the end of the call (the first and the last of a call): rolled, guarded
 #pragma unroll 1
@@ -185,11 +204,11 @@ template <int KJ, bool ROT, int DEPTH, int QS> __device__ __forceinline__ void d
                 const int idx = 64 * i + l;
                 if (idx < E) {
                     const long long g = g0 + idx;
-                    float2 v = make_float2(0.0f, 0.0f);
-                    if (g < 0) { if (g + P >= 0) v = a.hist[g + P]; }               // (history is already rotated)
+                    S v = zero_s();
+                    if (g < 0) { if (g + P >= 0) v = hist_s[g + P]; }               // (history is already rotated)
                     else if (g < a.count) {
-                        v = a.in[g];
-                        if (ROT) v = rotate_f(v, make_float2((float)pd.x, (float)pd.y), rot_k[i], g, a.gm1);
+                        v = in_s[g];
+                        if constexpr (ROT) v = rotate_f(v, make_float2((float)pd.x, (float)pd.y), rot_k[i], g, a.gm1);
                     }
                     const int row = (int)__umulhi((unsigned)idx, a.minv);
                     tile[row * PITCH + (idx - row * M)] = v;
@@ -208,18 +227,27 @@ template <int KJ, bool ROT, int DEPTH, int QS> __device__ __forceinline__ void d
         }
 #pragma unroll
         for (int jj = 0; jj < KJ; jj++) {
-            const float4 b = brd[4 * jj];                                        // 8 samples = 64 B further per step
+            const B2 b = brd[4 * jj];                                            // 8 samples further per step
 #pragma unroll
             for (int s = 0; s < QS; s++) {
-                zr[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[s][jj][0], b.x, zr[s], 0, 0, 0);
-                zi[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[s][jj][0], b.y, zi[s], 0, 0, 0);
-                zr[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[s][jj][1], b.z, zr[s], 0, 0, 0);
-                zi[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[s][jj][1], b.w, zi[s], 0, 0, 0);
+                if constexpr (RD) {
+                    zr[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[s][jj][0], b.x, zr[s], 0, 0, 0);      // even columns
+                    zi[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[s][jj][1], b.y, zi[s], 0, 0, 0);      // odd columns: the second chain
+                } else {
+                    zr[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[s][jj][0], b.x, zr[s], 0, 0, 0);
+                    zi[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[s][jj][0], b.y, zi[s], 0, 0, 0);
+                    zr[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[s][jj][1], b.z, zr[s], 0, 0, 0);
+                    zi[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[s][jj][1], b.w, zi[s], 0, 0, 0);
+                }
             }
         }
-        float cur_re, prev_re, cur_im, prev_im;
+        if constexpr (RD) {
+#pragma unroll
+            for (int s = 0; s < QS; s++) zr[s] += zi[s];
+        }
+        float cur_re, prev_re, cur_im = 0.0f, prev_im = 0.0f;
         diag_sum(zr[0], cur_re, prev_re);
-        diag_sum(zi[0], cur_im, prev_im);
+        if constexpr (!RD) diag_sum(zi[0], cur_im, prev_im);
         float o_re, o_im;
         if (QS == 1) {
             o_re = carry_re + prev_re;                                           // outputs of the previous tile, complete
@@ -229,9 +257,9 @@ template <int KJ, bool ROT, int DEPTH, int QS> __device__ __forceinline__ void d
         } else {
             // the second tap set reaches 16 rows further back: its in-tile part belongs to the previous tile's outputs, its
             // carried part to the tile before that, which this tile completes
-            float c1_re, p1_re, c1_im, p1_im;
+            float c1_re, p1_re, c1_im = 0.0f, p1_im = 0.0f;
             diag_sum(zr[QS - 1], c1_re, p1_re);
-            diag_sum(zi[QS - 1], c1_im, p1_im);
+            if constexpr (!RD) diag_sum(zi[QS - 1], c1_im, p1_im);
             o_re = carry2_re + p1_re;
             o_im = carry2_im + p1_im;
             carry2_re = carry_re + prev_re + c1_re;
@@ -240,9 +268,9 @@ template <int KJ, bool ROT, int DEPTH, int QS> __device__ __forceinline__ void d
             carry_im = cur_im;
         }
         o_re += __shfl_xor(o_re, 16);
-        o_im += __shfl_xor(o_im, 16);
+        if constexpr (!RD) o_im += __shfl_xor(o_im, 16);
         o_re += __shfl_xor(o_re, 32);
-        o_im += __shfl_xor(o_im, 32);
+        if constexpr (!RD) o_im += __shfl_xor(o_im, 32);
         pend_re = o_re;
         pend_im = o_im;
         if (!a.defer_store) store_tile(tt);
@@ -258,6 +286,10 @@ template <int KJ, bool ROT, int DEPTH, int QS> __device__ __forceinline__ void d
 template <int KJ, bool ROT, int DEPTH, int QS>
 __global__ __launch_bounds__(256, KJ * DEPTH * QS <= 8 ? 4 : (KJ * DEPTH * QS <= 12 ? 3 : 2)) void decim_mfma_kernel(const MfArgs a) {
     decim_mfma_body<KJ, ROT, DEPTH, QS>(a, a.rot_k);
+}
+template <int KJ, int DEPTH, int QS>
+__global__ __launch_bounds__(256, KJ * DEPTH * QS <= 8 ? 4 : (KJ * DEPTH * QS <= 14 ? 3 : 2)) void decim_mfma_real_kernel(const MfArgs a) {
+    decim_mfma_body<KJ, false, DEPTH, QS, true>(a, a.rot_k);
 }
 
 template <int KJ, int DEPTH>
@@ -303,8 +335,16 @@ int launch_mf_dec_batch(const MfBatchArgs& b, int nchan, int KJ, int depth, hipS
     return -1;
 }
 
-template <int K> static void launch_mf_k(const MfArgs& a, dim3 grid, bool rot, int depth, int qs, hipStream_t stream) {
+template <int K> static void launch_mf_k(const MfArgs& a, dim3 grid, bool rot, int depth, int qs, bool real, hipStream_t stream) {
     const dim3 block(256);
+    if (real) {
+        if (qs == 2) { hipLaunchKernelGGL((decim_mfma_real_kernel<K, 1, 2>), grid, block, 0, stream, a); return; }
+        if constexpr (K <= kMfDepth2MaxKJ) {
+            if (depth == 2) { hipLaunchKernelGGL((decim_mfma_real_kernel<K, 2, 1>), grid, block, 0, stream, a); return; }
+        }
+        hipLaunchKernelGGL((decim_mfma_real_kernel<K, 1, 1>), grid, block, 0, stream, a);
+        return;
+    }
     if (qs == 2 && rot) { hipLaunchKernelGGL((decim_mfma_kernel<K, true, 1, 2>), grid, block, 0, stream, a); return; }
     if (qs == 2) { hipLaunchKernelGGL((decim_mfma_kernel<K, false, 1, 2>), grid, block, 0, stream, a); return; }
     if constexpr (K <= kMfDepth2MaxKJ) {
@@ -315,11 +355,12 @@ template <int K> static void launch_mf_k(const MfArgs& a, dim3 grid, bool rot, i
     else hipLaunchKernelGGL((decim_mfma_kernel<K, false, 1, 1>), grid, block, 0, stream, a);
 }
 
-int launch_mf_dec(const MfArgs& a, int KJ, bool rot, int depth, int qs, hipStream_t stream) {
+int launch_mf_dec(const MfArgs& a, int KJ, bool rot, int depth, int qs, bool real, hipStream_t stream) {
+    if (real && rot) return -1;
     const dim3 grid((a.ntasks + 3) / 4 + 1);
 #define QK_MF(k)                                            \
     if (KJ == k) {                                          \
-        launch_mf_k<k>(a, grid, rot, depth, qs, stream);    \
+        launch_mf_k<k>(a, grid, rot, depth, qs, real, stream); \
         const hipError_t e = hipGetLastError();             \
         return e == hipSuccess ? 0 : -(int)e;               \
     }

@@ -78,6 +78,6 @@ struct MfBatchArgs {
 // KJ = ceil(M / 8) in 2..16; returns -1 for other shapes
 int launch_mf_dec_batch(const MfBatchArgs& b, int nchan, int KJ, int depth, hipStream_t stream);
 // qs: tap sets of 16 rows (1, or 2 for 17-32 taps per column: one tile in flight)
-int launch_mf_dec(const MfArgs& a, int KJ, bool rot, int depth, int qs, hipStream_t stream);
+int launch_mf_dec(const MfArgs& a, int KJ, bool rot, int depth, int qs, bool real, hipStream_t stream);      // real: float samples (in / out / hist reinterpreted), never with rot
 
 }  // namespace qk

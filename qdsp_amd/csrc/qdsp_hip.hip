@@ -165,7 +165,8 @@ bool use_lm(const Engine* e) {
 // the tiles get small and it only wins over the strided-window / general kernels from ~12 taps per unit of decimation,
 // and the strided-window kernel keeps the short filters at decimation 16.
 bool mf_plan(const Engine* e, int* KJ, int* QS, int* keep2) {
-    if (e->ch != 2 || e->L != 1 || !e->has_filter || e->kind == KIND_FIR) return false;
+    // (ch == 1, round 4: PolyphaseResampler<float> -- decim_mfma_real_kernel, the same plan on float rows)
+    if ((e->ch != 2 && e->ch != 1) || (e->ch == 1 && e->rotate) || e->L != 1 || !e->has_filter || e->kind == KIND_FIR) return false;
     const int M = e->M, P = e->P;
     if (M < qk::knob(qk::K_MF_MIN_DECIM, 9)) return false;
     // decimations 130-256 (even): the kernel runs rows of M / 2 samples -- the decimator by M / 2 with the same taps -- and
@@ -1710,12 +1711,12 @@ int launch_mf(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d_
         a.gm1 = e->volk_gain ? e->gm1 : 0.0f;
         mf_rot_tables(e->dphase, a.M, e->mf_KJ, &a.rot_step, a.rot_k);
     }
-    const int rc = qk::launch_mf_dec(a, e->mf_KJ, e->rotate, qk::knob(qk::K_MF_DEPTH, (e->mf_KJ <= 8 && !(e->rotate && e->mf_KJ >= 5)) ? 2 : 1)      /* (fused VFO from decimation 33 on: one tile ahead = 118 VGPRs = four waves per SIMD, 1-3 % ahead of two tiles at three: 0.232 -> 0.229 ms at decimation 50; the plain decimator the other way round) */, e->mf_QS, s);
+    const int rc = qk::launch_mf_dec(a, e->mf_KJ, e->rotate, qk::knob(qk::K_MF_DEPTH, (e->mf_KJ <= 8 && !(e->rotate && e->mf_KJ >= 5)) ? 2 : 1)      /* (fused VFO from decimation 33 on: one tile ahead = 118 VGPRs = four waves per SIMD, 1-3 % ahead of two tiles at three: 0.232 -> 0.229 ms at decimation 50; the plain decimator the other way round) */, e->mf_QS, e->ch == 1, s);
     if (rc) return rc < 0 && rc != -1 ? rc : QDSP_HIP_EINVAL;
-    e->last.name = "decim_mfma_kernel";
+    e->last.name = e->ch == 1 ? "decim_mfma_real_kernel" : "decim_mfma_kernel";
     e->last.grid = (a.ntasks + 3) / 4 + 1;
     e->last.block = 256;
-    e->last.lds = 4 * (16 * (8 * e->mf_KJ + 2) + 64) * (int)sizeof(float2);
+    e->last.lds = e->ch == 1 ? 4 * (16 * (8 * e->mf_KJ + 4) + 64) * (int)sizeof(float) : 4 * (16 * (8 * e->mf_KJ + 2) + 64) * (int)sizeof(float2);
     return 0;
 }
 

@@ -202,7 +202,8 @@ def test_default_real_data_dispatch_is_within_10_percent_of_the_best_setting():
     shapes = [(10, 1 << 14, 1024), (16, 1 << 14, 1024), (10, 1 << 13, 384), (16, 1 << 17, 1024), (10, 1 << 12, 512), (1, 1 << 20, 64),
               (1, 1 << 24, 256), (2, 1 << 22, 128), (3, 3 << 18, 96), (4, 1 << 24, 64), (5, 5 << 16, 256), (8, 1 << 26, 128),
               (25, 25 << 9, 1024), (32, 1 << 14, 1024), (20, 5 << 15, 1024), (50, 1000000, 401),
-              (12, 3 << 12, 1024), (40, 5 << 12, 768), (6, 3 << 20, 128), (7, 7 << 15, 512)]      # (the last four: unswept decimations, nearest row)
+              (12, 3 << 12, 1024), (40, 5 << 12, 768), (6, 3 << 20, 128), (7, 7 << 15, 512),      # (these four: unswept decimations, nearest row)
+              (50, 25 << 21, 401), (16, 1 << 26, 256), (100, 25 << 20, 801)]                        # (chip-filling calls of decim_mfma_real_kernel's range)
     rng = np.random.default_rng(4)
     for _ in range(12):
         M = int(rng.choice([1, 2, 3, 4, 5, 8, 10, 16]))

@@ -1276,6 +1276,15 @@ def test_mfma_decimator_shapes(ops, M, ntaps):
     assert kname(v) == "decim_mfma_kernel"
     gv, wv = np.concatenate(gv), np.concatenate(wv)
     assert gv.shape == wv.shape and rel_rms(gv, wv) < 1e-6, (M, ntaps)
+    # real data (PolyphaseResampler<float>, src/dsp/resampling.h:113-118): decim_mfma_real_kernel, the same plan on float rows (round 4)
+    xr = np.ascontiguousarray(x.real)
+    rr = ops.Resampler(taps, 1, M, complex_data=False, max_block=0)
+    gr = np.concatenate([rr.process(dev(xr[a:b])).cpu().numpy() for a, b in zip(cuts, cuts[1:])])
+    assert kname(rr) == "decim_mfma_real_kernel", rr.last_kernel()
+    ro = O.Resampler(taps, 1, M, complex_data=False, acc=O.ACC_F64)
+    wr = np.concatenate([ro.process(xr[a:b]) for a, b in zip(cuts, cuts[1:])])
+    assert gr.dtype == np.float32 and gr.shape == wr.shape and rel_rms(gr, wr) < 1e-6, (M, ntaps)
+    assert np.array_equal(rr.get_history(), xr[len(xr) - ntaps:])
 
 
 @pytest.mark.parametrize("L,M,tpp,forced", [(147, 160, 16, False), (160, 147, 16, False), (48, 50, 20, False), (192, 175, 9, False), (40, 39, 28, False),
