@@ -31,7 +31,7 @@ def _no_overrides():
     return not any(k.startswith("QDSP_HIP_") and k not in _NOT_DISPATCH for k in os.environ)
 
 FAMILIES = {"fir_core_kernel", "fir_lat_kernel", "fir_fft1k_kernel", "fir_fft_dma_kernel", "pfb_dec8_kernel", "pfb_dec4_kernel", "decim_win_kernel",
-            "decim_mfma_kernel", "decim_mfma_batch_kernel", "resamp_lm_kernel", "resamp_mfma_kernel", "resamp_any_kernel",
+            "decim_mfma_kernel", "decim_mfma_real_kernel", "decim_mfma_batch_kernel", "resamp_lm_kernel", "resamp_mfma_kernel", "resamp_any_kernel",
             "resamp_any_batch_kernel", "chan_uniform_kernel"}
 
 
@@ -126,7 +126,8 @@ REAL_DIRECTED = [
     # chip-filling rule of round 3 (2^22 samples)
     (10, 256, [(1_000_000, "resamp_any_kernel"), ((1 << 22) + 10, "fir_fft_kernel")]),        # (round 4 table: the 4096-point overlap-save form; the rules alone say the one-wave 1024-point form)
     (2, 64, [(1_000_000, "fir_core_kernel"), ((1 << 22) + 2, "fir_core_kernel")]),             # (table: the general direct kernel ahead of the strided-window one at 10^6)
-    (1, 64, [(1_000_000, "fir_core_kernel"), ((1 << 22) + 1, "fir_core_kernel")]),             # (table: direct form ahead of the one-wave overlap-save form at 64 taps)
+    (1, 64, [(1_000_000, "fir_core_kernel"), ((1 << 22) + 1, "fir_core_kernel")]),
+    (16, 200, [(1_000_000, "decim_mfma_real_kernel"), ((1 << 22) + 16, "decim_win_kernel")]),            # (round 4: the MFMA decimator on float rows; the table hands this 2^22 cell to the window kernel)             # (table: direct form ahead of the one-wave overlap-save form at 64 taps)
 ]
 
 
