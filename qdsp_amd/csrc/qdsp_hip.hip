@@ -289,7 +289,11 @@ int upload_taps(Engine* e, const float* taps, int ntaps) {
             e->rm_big_only = true;
         }
     }
-    if (e->ch == 2 && rm_wanted && e->has_filter && e->kind != KIND_FIR && !use_core(e) && e->M < (1 << 16)) {
+    // (ch == 1, round 4: PolyphaseResampler<float> -- resamp_mfma_real_kernel, the same plan on float tiles.  Against the real-data forms of the other
+    // kernels -- scripts sweep kept in profiles/r04_real_rational.txt -- it needs 14 taps per phase except on the decimating side of the small ratios:
+    // 33/32 and 100/99 at 8-12 taps per phase are 1.1-1.45x slower on it, 3/8 and 5/8 1.6-2.6x faster at every tap count)
+    if (e->ch == 1 && rm_wanted && e->P < 14 && !(e->L <= 10 && e->L < e->M && e->M >= 5)) rm_wanted = false;
+    if ((e->ch == 2 || (e->ch == 1 && !e->rotate)) && rm_wanted && e->has_filter && e->kind != KIND_FIR && !use_core(e) && e->M < (1 << 16)) {
         const int L0 = e->L, M0 = e->M, P = e->P;
         for (int J = 1; J <= 64 && !e->rm_ngrp; J++) {
             const int L = J * L0, M = J * M0, nblk = (L + 3) / 4;
@@ -1681,12 +1685,12 @@ int launch_rm(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d_
             a.rot_k[k] = make_float2((float)c, (float)sn);
         }
     }
-    const int rc = qk::launch_rm_resamp(a, e->rotate, s);
-    if (rc) return rc;
-    e->last.name = "resamp_mfma_kernel";
+    const int rc = qk::launch_rm_resamp(a, e->rotate, e->ch == 1, s);
+    if (rc) return rc < 0 && rc != -1 ? rc : QDSP_HIP_EINVAL;
+    e->last.name = e->ch == 1 ? "resamp_mfma_real_kernel" : "resamp_mfma_kernel";
     e->last.grid = (nwaves + 3) / 4 + 1;
     e->last.block = 256;
-    e->last.lds = (int)qk::rm_lds_bytes(a.ngrp, a.KB, a.G, a.pitch);
+    e->last.lds = (int)qk::rm_lds_bytes(a.ngrp, a.KB, a.G, a.pitch, e->ch == 1);
     return 0;
 }
 
@@ -1792,8 +1796,15 @@ int64_t rm_min_count(const Engine* e) {
     if (v >= 0) return v;
     // (profiles/r03_sweep_rm_grid.txt, second part: decimating ratios are ahead from 2^22 input samples; interpolating ones -- whose work follows
     // the OUTPUT count -- only from ~10 million inputs: 8/3 at 6.3 million x 1.2, at 12.6 million x 0.9)
-    if (e->rm_big_only) return e->L > e->M ? 12 << 20 : 1 << 22;
-    return e->L >= 33 ? 6 << 20 : 0;
+    int64_t base = e->rm_big_only ? (e->L > e->M ? 12 << 20 : 1 << 22) : (e->L >= 33 ? 6 << 20 : 0);
+    if (e->ch == 1) {
+        // real data (profiles/r04_real_rational.txt): the interpolating small ratios and pure interpolators only pay from 2^25 samples on (6/1 at 2^20:
+        // 2-3.4x slower than the general kernel, at 2^23 1.1-1.25x, at 2^26 0.71-0.97x; 10/7 likewise); the decimating ones at every size up to 19
+        // taps per phase, from 2^22 samples beyond that (3/8 with 20 taps per phase at 2^20: 1.38x)
+        if (e->L > e->M && e->L < 33 && base < (1 << 25)) base = 1 << 25;
+        if (e->L < e->M && e->P >= 20 && base < (1 << 22)) base = 1 << 22;
+    }
+    return base;
 }
 
 // One run() worth of work on device pointers.  Returns the output count.

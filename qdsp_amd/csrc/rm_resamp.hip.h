@@ -58,10 +58,10 @@ struct RmArgs {
     float gm1;
 };
 
-inline size_t rm_lds_bytes(int ngrp, int KB, int G, int pitch) {
-    return (size_t)((ngrp * KB * 64 + 2 * ngrp * 64 + 3) & ~3) * 4 + 4 * ((size_t)4 * G * pitch + 64) * 8;      // A operands + block tables + four waves' tiles
+inline size_t rm_lds_bytes(int ngrp, int KB, int G, int pitch, bool real = false) {
+    return (size_t)((ngrp * KB * 64 + 2 * ngrp * 64 + 3) & ~3) * 4 + 4 * ((size_t)4 * G * pitch + 64) * (real ? 4 : 8);      // A operands + block tables + four waves' tiles
 }
 
-int launch_rm_resamp(const RmArgs& a, bool rot, hipStream_t stream);
+int launch_rm_resamp(const RmArgs& a, bool rot, bool real, hipStream_t stream);      // real: float samples (in / out / hist reinterpreted), never with rot
 
 }  // namespace qk

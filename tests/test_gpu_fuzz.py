@@ -31,7 +31,7 @@ def _no_overrides():
     return not any(k.startswith("QDSP_HIP_") and k not in _NOT_DISPATCH for k in os.environ)
 
 FAMILIES = {"fir_core_kernel", "fir_lat_kernel", "fir_fft1k_kernel", "fir_fft_dma_kernel", "pfb_dec8_kernel", "pfb_dec4_kernel", "decim_win_kernel",
-            "decim_mfma_kernel", "decim_mfma_real_kernel", "decim_mfma_batch_kernel", "resamp_lm_kernel", "resamp_mfma_kernel", "resamp_any_kernel",
+            "decim_mfma_kernel", "decim_mfma_real_kernel", "decim_mfma_batch_kernel", "resamp_lm_kernel", "resamp_mfma_kernel", "resamp_mfma_real_kernel", "resamp_any_kernel",
             "resamp_any_batch_kernel", "chan_uniform_kernel"}
 
 
@@ -126,8 +126,8 @@ REAL_DIRECTED = [
     # chip-filling rule of round 3 (2^22 samples)
     (10, 256, [(1_000_000, "resamp_any_kernel"), ((1 << 22) + 10, "fir_fft_kernel")]),        # (round 4 table: the 4096-point overlap-save form; the rules alone say the one-wave 1024-point form)
     (2, 64, [(1_000_000, "fir_core_kernel"), ((1 << 22) + 2, "fir_core_kernel")]),             # (table: the general direct kernel ahead of the strided-window one at 10^6)
-    (1, 64, [(1_000_000, "fir_core_kernel"), ((1 << 22) + 1, "fir_core_kernel")]),
-    (16, 200, [(1_000_000, "decim_mfma_real_kernel"), ((1 << 22) + 16, "decim_win_kernel")]),            # (round 4: the MFMA decimator on float rows; the table hands this 2^22 cell to the window kernel)             # (table: direct form ahead of the one-wave overlap-save form at 64 taps)
+    (1, 64, [(1_000_000, "fir_core_kernel"), ((1 << 22) + 1, "fir_core_kernel")]),             # (table: direct form ahead of the one-wave overlap-save form at 64 taps)
+    (16, 200, [(1_000_000, "decim_mfma_real_kernel"), ((1 << 22) + 16, "decim_win_kernel")]),  # (round 4: the MFMA decimator on float rows; the table hands this 2^22 cell to the window kernel)
 ]
 
 
@@ -152,6 +152,27 @@ def test_directed_real_plans_default_thresholds(ops, plan):
         assert got.shape == want.shape and _rel(got, want) < TOL, (plan, count, name)
         _SEEN.add(name)
     assert names == [f for _, f in calls], (plan, names)
+
+
+def test_directed_real_rational_plans_default_thresholds(ops):
+    """PolyphaseResampler<float> with interp > 1 under the shipped thresholds (round 4: resamp_mfma_real_kernel and its real-data rules): the
+    decimating side of a small ratio at a reference-sized call, 48 kHz -> 44.1 kHz on both sides of its size rule, a pure interpolator below its own."""
+    assert _no_overrides()
+    for L, M, tpp, calls in ((3, 8, 16, [(1_000_000 // 8 * 8, "resamp_mfma_real_kernel")]),
+                             (147, 160, 16, [(160 * 6000, "resamp_any_kernel"), (160 * 52500, "resamp_mfma_real_kernel")]),
+                             (6, 1, 16, [(1_000_000, "resamp_any_kernel")])):
+        taps = (_lp(L * tpp, 0.45 / max(L, M)) * L).astype(np.float32)
+        op, orc = ops.Resampler(taps, L, M, complex_data=False, max_block=0), O.Resampler(taps, L, M, complex_data=False, acc=O.ACC_F64)
+        rng = np.random.default_rng(L * 100 + M)
+        names = []
+        for count, _ in calls:
+            x = rng.standard_normal(count).astype(np.float32)
+            got = op.process(_dev(x)).cpu().numpy()
+            names.append(op.last_kernel()["name"])
+            want = orc.process(x)
+            assert got.shape == want.shape and _rel(got, want) < TOL, (L, M, count, names)
+            _SEEN.add(names[-1])
+        assert names == [f for _, f in calls], (L, M, names)
 
 
 def test_directed_channel_banks_default_thresholds(ops):
@@ -195,6 +216,7 @@ def test_random_slice_default_thresholds_covers_every_family(ops):
             test_directed_plans_default_thresholds(ops, plan)
         for plan in REAL_DIRECTED:
             test_directed_real_plans_default_thresholds(ops, plan)
+        test_directed_real_rational_plans_default_thresholds(ops)
         test_directed_channel_banks_default_thresholds(ops)
     n, worst, kernels = fuzz_dispatch.run(600.0, 20260403, default_only=True, verbose=False, max_cases=int(os.environ.get("QDSP_TEST_FUZZ_CASES", "1500")))
     assert n >= 20 and worst < TOL, (n, worst, kernels)

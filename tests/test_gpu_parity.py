@@ -1330,6 +1330,17 @@ def test_rational_mfma_resampler(ops, L, M, tpp, forced, monkeypatch):
     assert kname(v) == "resamp_mfma_kernel"
     gv, wv = np.concatenate(gv), np.concatenate(wv)
     assert gv.shape == wv.shape and rel_rms(gv, wv) < 1e-6, (L, M)
+    # real data (PolyphaseResampler<float>, src/dsp/resampling.h:113-118): resamp_mfma_real_kernel, the same plan on float tiles (round 4) --
+    # from 14 taps per phase on, at every tap count on the decimating side of the small ratios (the real-data rules of the rm plan, qdsp_hip.hip)
+    xr = np.ascontiguousarray(x.real)
+    rr = ops.Resampler(taps, L, M, complex_data=False, max_block=0)
+    gr = np.concatenate([rr.process(dev(xr[a:b])).cpu().numpy() for a, b in zip(cuts, cuts[1:])])
+    ro = O.Resampler(taps, L, M, complex_data=False, acc=O.ACC_F64)
+    wr = np.concatenate([ro.process(xr[a:b]) for a, b in zip(cuts, cuts[1:])])
+    assert gr.dtype == np.float32 and gr.shape == wr.shape and rel_rms(gr, wr) < 1e-6, (L, M)
+    P = -(-ntaps // L)
+    if P >= 14 or (L <= 10 and L < M and M >= 5):
+        assert kname(rr) == "resamp_mfma_real_kernel", (L, M, P, rr.last_kernel())
     # the general direct kernel on the same plan agrees
     monkeypatch.setenv("QDSP_HIP_NO_RM", "1")
     r2 = ops.Resampler(taps, L, M, max_block=0)
