@@ -1708,6 +1708,9 @@ int launch_mf(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d_
     a.M = e->mf_keep2 ? e->M / 2 : e->M;
     a.keep2 = e->mf_keep2;
     if (e->mf_keep2) a.nout = 2 * nout - 1;      // (in the kernel's units: outputs of the decimator by M / 2)
+    // the kernel's unguarded loads of an interior tile read 64 (2 KJ - 2) samples from the tile's start: they must lie inside the tile's own 16 M
+    // (true for KJ = ceil(M / 8); a plan that pads KJ beyond that would read past the end of the input -- found the hard way, round 4)
+    if (128 * (e->mf_KJ - 1) > 16 * a.M) return QDSP_HIP_EINVAL;
     mf_tasks(a, a.nout, 1, e->rotate);
     if (e->rotate) {
         a.phase0 = e->phase;
