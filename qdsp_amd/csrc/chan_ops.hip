@@ -99,7 +99,7 @@ int chan_launch_uniform(Chan* c, const void* d_in, int64_t count, int64_t nout, 
     a.ntiles = (int)((nout + 15) / 16);
     a.st4 = ((reinterpret_cast<uintptr_t>(d_out) & 15) == 0 && (out_stride & 1) == 0 && !qk::knob(qk::K_CHAN_NO_ST4, 0)) ? 1 : 0;
     a.waves = 4;
-    int nwg = 256 * qk::knob(qk::K_CHAN_WG_PER_CU, 48);  // 3 resident per CU, 16 rounds (round 3: 12 -> 48: -2 %, profiles/r03_chan_tuning.txt)
+    int nwg = 256 * 48;  // 3 resident per CU, 16 rounds (round 3: 12 -> 48: -2 %, profiles/r03_chan_tuning.txt; 3 / 6 / 12 / 48 re-measured in round 4: 2.556 / 2.507 / 2.489 / 2.440 ms)
     if (nwg > (a.ntiles + a.waves - 1) / a.waves) nwg = (a.ntiles + a.waves - 1) / a.waves;
     if (nwg < 1) nwg = 1;
     a.nwg = nwg;

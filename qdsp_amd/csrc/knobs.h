@@ -13,8 +13,8 @@ namespace qk {
 #define QDSP_HIP_KNOBS(X) \
     X(ANY_SMALL_CALL_TILES) \
     X(CHAN_ABL) \
-    X(CHAN_NO_ST4) X(CHAN_WG_PER_CU) X(DECIM_SETTING) X(FFT1K_MAX_COUNT) X(FFT_ABL) X(FFT_DMA) \
-    X(FFT_MIN_TAPS) X(FFT_MIN_TAPS_DECIM) X(FFT_MIN_TAPS_REAL) \
+    X(CHAN_NO_ST4) X(DECIM_SETTING) X(FFT1K_MAX_COUNT) X(FFT_ABL) X(FFT_DMA) \
+    X(FFT_MIN_TAPS_DECIM) X(FFT_MIN_TAPS_REAL) \
     X(FFT_MIN_TAPS_SMALL) X(FFT_NT) X(FFT_PRUNE2_MAX_COUNT) X(FFT_WG_PER_CU) X(FIR_LAT_MAX_WORK) X(FIR_MODE) X(FIR_PICK) X(FORCE_ANY) \
     X(MF_BATCH_MIN_WORK) X(MF_DEPTH) X(MF_MIN_COUNT) X(MF_MIN_DECIM) \
     X(MF_TASK_MAX) X(NO_CHAN_BATCH) X(NO_DECIM_TABLE) X(NO_FFT1K) X(NO_FFT1K_REAL) X(NO_FIR_LAT) X(NO_FIR_TABLE) X(NO_LM) \

@@ -938,11 +938,11 @@ bool fft_eligible(const Engine* e, int64_t count) {
     } else if (e->M == 1 && e->kind != KIND_FIR) {
         // equal-rate resampler / pure xlating FIR: full inverse + per-element store (0.52 ms per 2^27 samples)
         // against the tile-per-block direct form (0.51 ms at 7 taps, 0.63 at 63)
-        min_taps = qk::knob(qk::K_FFT_MIN_TAPS, 24);
+        min_taps = 24;
     } else if (e->M == 1) {
         // FIR: the overlap-save kernel (a copy-speed 4.8 TB/s whatever the taps) beats the tile-per-block
         // direct form from 8 taps on (2^26 samples: 0.222 vs 0.256 ms at 7 taps, 0.225 vs 0.394 at 127)
-        min_taps = qk::knob(qk::K_FFT_MIN_TAPS, 8);
+        min_taps = 8;
         // reference-sized calls (<= 1e6 samples, stream.h:7) are latency-bound: one 4096-point segment takes ~9 us
         // whatever the taps, the direct form 4.7 / 5.7 us at 31 / 63 taps (8.3 at 1e6 samples) and 11-16 us at 256
         // (round 2: with one-wave 1024-point segments -- fft1k_fir.hip -- the small calls cross over at ~24 taps:
