@@ -94,8 +94,13 @@ __device__ __forceinline__ float2 load_stream(const float2* p) {
 // four 1024-point columns + one 1024-point inverse would take 12.5 N.  Eight waves per workgroup share the two tables
 // (G1 unpadded, its 16-byte chunks swizzled by the row so that wide reads stay conflict-free); the second phase's column
 // sums wait in a wave-private LDS patch (no register for them in the rounds), then take the same inverse.
-template <bool ROT, int PH>
+//
+// RD (round 4): REAL data -- PolyphaseResampler<float> with interp 1, decimation 8 / 4.  A real filter is linear over the reals, so TWO segments of the
+// real stream ride one set of complex transforms as re / im: pair p = segments (p, p + ceil(nseg / 2)); the loads are two 4-byte loads per row element,
+// the stores two 4-byte stores (each stream's own bounds); everything between is the complex kernel.  in / out / hist are float arrays.
+template <bool ROT, int PH, bool RD = false>
 __device__ __forceinline__ void pfb_body(const PfbArgs& a) {
+    static_assert(!(RD && ROT), "the NCO is a complex operator");
     constexpr int NT = kPfbNT * PH, NW = NT / 64;
     __shared__ __attribute__((aligned(16))) float2 sTab[kPfbTableElems + (PH - 1) * kPfbG1Elems];   // G | TW | TI1 | TI2 | EL [| G1]
     __shared__ __attribute__((aligned(16))) float2 sEx[NW][64 * kPfbRow];                          // wave-private exchange buffers
@@ -104,6 +109,16 @@ __device__ __forceinline__ void pfb_body(const PfbArgs& a) {
 
     if ((int)blockIdx.x == a.nwg) {
         // history hand-over (resampling.h:129): last H samples of hist ++ in, in the form the handle keeps them
+        if constexpr (RD) {
+            const float* inr = reinterpret_cast<const float*>(a.in);
+            const float* hk = reinterpret_cast<const float*>(a.hist_keep);
+            float* hn = reinterpret_cast<float*>(a.hist_next);
+            for (int i = t; i < H; i += NT) {
+                const long long g = a.count - H + i;
+                hn[i] = g < 0 ? hk[g + H] : inr[g];
+            }
+            return;
+        }
         for (int i = t; i < H; i += NT) {
             const long long g = a.count - H + i;
             float2 v;
@@ -194,16 +209,28 @@ __device__ __forceinline__ void pfb_body(const PfbArgs& a) {
         return make_float2(keep.x + dpp<kDppXor1>(send.x), keep.y + dpp<kDppXor1>(send.y));
     };
     float2 v[64];
-    {
+    const float* __restrict__ inr = reinterpret_cast<const float*>(a.in);        // RD: the real stream
+    const int nhalf = (a.nseg + 1) >> 1;                                          // RD: pairs; segment b rides with segment b + nhalf
+    const int nloop = RD ? nhalf : a.nseg;
+    auto segB_of = [&](int b) { return b + nhalf < a.nseg ? b + nhalf : b; };     // (an odd count: the last pair's second member repeats the first, not stored)
+    if constexpr (RD) {
+        const int b0 = wave0 < nloop ? wave0 : 0;
+        const float* __restrict__ pa = inr + clamped(seg_start(b0)) + l;
+        const float* __restrict__ pb2 = inr + clamped(seg_start(segB_of(b0))) + l;
+#pragma unroll
+        for (int r = 0; r < 64; r++) v[r] = make_float2(pa[64 * r], pb2[64 * r]);
+    } else {
         const float2* __restrict__ p = a.in + clamped(seg_start(wave0 < a.nseg ? wave0 : 0)) + l;
 #pragma unroll
         for (int r = 0; r < 64; r++) v[r] = load_stream(p + 64 * r);
     }
 #pragma unroll 1
-    for (int b = wave0; b < a.nseg; b += nwaves) {
+    for (int b = wave0; b < nloop; b += nwaves) {
         const long long S0 = seg_start(b);
+        const int bB = RD ? segB_of(b) : b;
+        const long long S0B = seg_start(bB);
         // ---- v[8 j + q'] = seg[512 j + 64 q' + l] (whole 512-byte rows), already requested ---------------------
-        if (S0 >= 0 && S0 <= last_start) {
+        if (S0 >= 0 && S0 <= last_start && (!RD || (S0B >= 0 && S0B <= last_start))) {
             if (ROT && a.gm1 != 0.0f) {
                 // VOLK's magnitude sawtooth 1 + (g mod 512) gm1 on the INPUT samples: g = S0 + 512 j + 64 q' + l takes
                 // eight values per lane and segment (512 j drops out)
@@ -213,6 +240,18 @@ __device__ __forceinline__ void pfb_body(const PfbArgs& a) {
 #pragma unroll
                     for (int j = 0; j < 8; j++) v[8 * j + q] = make_float2(v[8 * j + q].x * gg, v[8 * j + q].y * gg);
                 }
+            }
+        } else if constexpr (RD) {
+            const float* hr = reinterpret_cast<const float*>(a.hist);
+#pragma unroll
+            for (int r = 0; r < 64; r++) {
+                const long long gA = S0 + 64 * r + l, gB = S0B + 64 * r + l;
+                float xa = 0.0f, xb = 0.0f;
+                if (gA < 0) { if (gA + H >= 0) xa = hr[gA + H]; }
+                else if (gA < a.count) xa = inr[gA];
+                if (gB < 0) { if (gB + H >= 0) xb = hr[gB + H]; }
+                else if (gB < a.count) xb = inr[gB];
+                v[r] = make_float2(xa, xb);
             }
         } else {
 #pragma unroll
@@ -231,7 +270,10 @@ __device__ __forceinline__ void pfb_body(const PfbArgs& a) {
             }
         }
         // where this wave's next segment starts (clamped into the buffer: see above)
-        const float2* __restrict__ pn = a.in + clamped(seg_start(b + nwaves < a.nseg ? b + nwaves : b)) + l;
+        const int bn = b + nwaves < nloop ? b + nwaves : b;
+        const float2* __restrict__ pn = a.in + clamped(seg_start(bn)) + l;
+        const float* __restrict__ pnA = inr + clamped(seg_start(bn)) + l;
+        const float* __restrict__ pnB = inr + clamped(seg_start(RD ? segB_of(bn) : bn)) + l;
         float2 vn[64];
         // ---- forward, column index a = 64 j + 8 q' + g', bin k = k0 + 8 kq + 64 kg ----------------------------
         // pass 1 over j (for every q'): A[k0][q'] at v[8 rev8(k0) + q']
@@ -261,7 +303,10 @@ __device__ __forceinline__ void pfb_body(const PfbArgs& a) {
             for (int kq = 0; kq < 8; kq++) E[(kq * 8 + c) * kPfbRow + hi3] = v[8 * rev8(rho) + rev8(kq)];
             // the registers of row group rev8(rho) are free now: request the same rows of the next segment
 #pragma unroll
-            for (int q = 0; q < 8; q++) vn[8 * rev8(rho) + q] = load_stream(pn + 64 * (8 * rev8(rho) + q));
+            for (int q = 0; q < 8; q++) {
+                if constexpr (RD) vn[8 * rev8(rho) + q] = make_float2(pnA[64 * (8 * rev8(rho) + q)], pnB[64 * (8 * rev8(rho) + q)]);
+                else vn[8 * rev8(rho) + q] = load_stream(pn + 64 * (8 * rev8(rho) + q));
+            }
             __builtin_amdgcn_wave_barrier();
             // reader (c, mu = kq): row l holds the eight g' of bin prefix m = rho + 8 mu
             float2 r8[8], tw[8], gg[8];
@@ -357,6 +402,26 @@ __device__ __forceinline__ void pfb_body(const PfbArgs& a) {
         const int hi = room > 8192 ? 8192 : (int)room;                            // offsets below this one are inside the call
         const int lo = base > 0 ? -8 : (int)-base;                                // ... and from this one on not before its start
         float2* __restrict__ ob = a.out + base;
+        // RD: the second member of the pair has its own output window
+        const long long baseB = PH * ((long long)bB * a.Lo - (a.Q - 1));
+        const long long roomB = a.nout - baseB;
+        const bool haveB = RD && bB != b;                                                // (a repeated segment stores nothing)
+        const int hiB = haveB ? (roomB > 8192 ? 8192 : (int)roomB) : 0;
+        const int loB = haveB ? (baseB > 0 ? -8 : (int)-baseB) : 0;
+        float* __restrict__ orA = reinterpret_cast<float*>(a.out) + base;
+        float* __restrict__ orB = reinterpret_cast<float*>(a.out) + baseB;
+        auto store_real = [&](const float2 (&z)[8], int phi) {
+#pragma unroll
+            for (int b1 = 0; b1 < 8; b1++) {
+                const int ap = l + 64 * b1;
+                const int off = PH * ap - phi;
+                const float2 y = z[rev8(b1)];
+                if (ap >= a.Q - 1) {
+                    if (off >= lo && off < hi) __builtin_nontemporal_store(y.x, orA + off);
+                    if (off >= loB && off < hiB) __builtin_nontemporal_store(y.y, orB + off);
+                }
+            }
+        };
         auto store = [&](const float2 (&z)[8], int phi) {
 #pragma unroll
             for (int b1 = 0; b1 < 8; b1++) {
@@ -380,7 +445,16 @@ __device__ __forceinline__ void pfb_body(const PfbArgs& a) {
         for (int kg = 0; kg < 8; kg++) z[kg] = E[l * 9 + kg];
         __builtin_amdgcn_wave_barrier();
         inverse(z);
-        if constexpr (PH == 1 || ROT) {
+        if constexpr (RD) {
+            store_real(z, 0);
+            if constexpr (PH == 2) {
+#pragma unroll
+                for (int kg = 0; kg < 8; kg++) z[kg] = EY[l * 9 + kg];
+                __builtin_amdgcn_wave_barrier();
+                inverse(z);
+                store_real(z, 1);
+            }
+        } else if constexpr (PH == 1 || ROT) {
             // (fused VFO at decimation 4: the kernel has no sixteen registers to spare through the second inverse -- pairing the stores as below
             // spilled 11 VGPRs, parking the even outputs in LDS 2 -- so it keeps the phase-by-phase 8-byte stores)
             store(z, 0);
@@ -423,8 +497,16 @@ __device__ __forceinline__ void pfb_body(const PfbArgs& a) {
 
 template <bool ROT> __global__ __launch_bounds__(kPfbNT, 2) void pfb_dec8_kernel(const PfbArgs a) { pfb_body<ROT, 1>(a); }
 template <bool ROT> __global__ __launch_bounds__(2 * kPfbNT, 1) void pfb_dec4_kernel(const PfbArgs a) { pfb_body<ROT, 2>(a); }
+__global__ __launch_bounds__(kPfbNT, 2) void pfb_dec8_real_kernel(const PfbArgs a) { pfb_body<false, 1, true>(a); }
+// (decimate by 4 on real data: the two-phase body with two load pointers needs 258 VGPRs -- 2 spilled -- and is not instantiated)
 
 int launch_pfb_dec(const PfbArgs& a, hipStream_t stream) {
+    if (a.real) {
+        if (a.rot || a.PH != 1) return -1;
+        hipLaunchKernelGGL(pfb_dec8_real_kernel, dim3(a.nwg + 1), dim3(kPfbNT), 0, stream, a);
+        const hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : -(int)e;
+    }
     if (a.PH == 2) {
         if (a.rot) hipLaunchKernelGGL((pfb_dec4_kernel<true>), dim3(a.nwg + 1), dim3(2 * kPfbNT), 0, stream, a);
         else hipLaunchKernelGGL((pfb_dec4_kernel<false>), dim3(a.nwg + 1), dim3(2 * kPfbNT), 0, stream, a);

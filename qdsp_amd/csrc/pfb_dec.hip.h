@@ -54,6 +54,7 @@ struct PfbArgs {
     float2 wtab[8];               // exp(j 2pi * 512 b1 * dphase)
     float gm1;
     int PH;                       // output phases per column output: 1 = decimate by 8, 2 = decimate by 4 (pfb_dec.hip)
+    int real;                     // 1: real data (in / out / hist are float arrays; two segments per transform, pfb_dec.hip)
 };
 
 constexpr int kPfbTableElems = (512 + 64 + 64 + 8) * kPfbRow + 64;   // + EL: exp(j 2pi 8 l dphase) per lane (fused VFO)

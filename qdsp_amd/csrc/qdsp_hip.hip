@@ -1240,7 +1240,9 @@ int launch_xlate_inc(Engine* e, const void* d_in, int64_t count, void* d_out, un
 inline int pfb_phases(const Engine* e) { return e->M == 4 ? 2 : 1; }
 inline int pfb_Q(const Engine* e) { return (e->ntaps + e->M * (pfb_phases(e) - 1) + qk::kPfbD - 1) / qk::kPfbD; }
 bool pfb_eligible(const Engine* e, int64_t count) {
-    if (e->ch != 2 || e->L != 1 || (e->M != qk::kPfbD && e->M != 4) || e->ntaps < 2) return false;
+    // (ch == 1, round 4: PolyphaseResampler<float> at decimation 8 -- pfb_dec8_real_kernel, two real segments per set of transforms)
+    const bool real8 = e->ch == 1 && !e->rotate && e->M == qk::kPfbD && e->kind == KIND_DECIM;
+    if ((e->ch != 2 && !real8) || e->L != 1 || (e->M != qk::kPfbD && e->M != 4) || e->ntaps < 2) return false;
     if (e->kind != KIND_DECIM && e->kind != KIND_VFO) return false;
     if (pfb_Q(e) > qk::kPfbMaxQ) return false;
     if (qk::knob(qk::K_NO_PFB, 0) || (e->auto_veto & VETO_PFB)) return false;
@@ -1250,7 +1252,7 @@ bool pfb_eligible(const Engine* e, int64_t count) {
     // (never below one segment: the kernel's prefetch reads whole 4096-sample segments from a clamped in-range start)
     if (count < qk::kPfbSeg) return false;
     // (decimate by 4, profiles/r03_tune_pfb4.txt: level with fir_fft_dec_kernel<4> at 2^25 samples, 0.166 against 0.181 ms at 2^26, 0.312 against 0.330 at 2^27)
-    return count >= (int64_t)qk::knob(qk::K_PFB_MIN_COUNT, e->M == 4 ? 1 << 26 : e->rotate ? 1 << 24 : 1 << 23);
+    return count >= (int64_t)qk::knob(qk::K_PFB_MIN_COUNT, e->M == 4 ? 1 << 26 : (e->rotate || real8) ? 1 << 24 : 1 << 23);      // (real data: pairs of segments)
 }
 
 int pfb_prepare(Engine* e) {
@@ -1400,10 +1402,12 @@ int launch_pfb(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
     // persistent workgroups of 4 waves, one segment per wave at a time; 2 workgroups resident per CU (72 KB of LDS,
     // ~220 VGPRs), QDSP_HIP_PFB_WG_PER_CU queued per CU
     // (decimate by 4: 8 waves per workgroup -- they share the two spectrum tables, 159 KB of LDS -- one workgroup per CU)
+    a.real = e->ch == 1 ? 1 : 0;
     const int wpw = 4 * a.PH;
     int nwg = 256 * qk::knob(qk::K_PFB_WG_PER_CU, 2) / a.PH;
     if (nwg > 1024) nwg = 1024;
-    const int need = (a.nseg + wpw - 1) / wpw;
+    const int nunits = a.real ? (a.nseg + 1) / 2 : a.nseg;      // (real data: a wave takes a PAIR of segments at a time)
+    const int need = (nunits + wpw - 1) / wpw;
     if (nwg > need) nwg = need;
     if (nwg < 1) nwg = 1;
     a.nwg = nwg;
@@ -1426,7 +1430,7 @@ int launch_pfb(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
     rc = qk::launch_pfb_dec(a, s);
     if (rc) return rc;
     e->raw_valid = e->rotate && e->H > 0;   // (the caller flips cur: the raw hand-over then sits at d_hist_raw[cur])
-    e->last.name = a.PH == 2 ? "pfb_dec4_kernel" : "pfb_dec8_kernel";
+    e->last.name = a.real ? "pfb_dec8_real_kernel" : a.PH == 2 ? "pfb_dec4_kernel" : "pfb_dec8_kernel";
     e->last.grid = nwg + 1;
     e->last.block = qk::kPfbNT * a.PH;
     e->last.lds = (int)((qk::kPfbTableElems + (a.PH - 1) * qk::kPfbG1Elems + wpw * 64 * qk::kPfbRow + (a.PH - 1) * wpw * 64 * 9) * sizeof(float2));
