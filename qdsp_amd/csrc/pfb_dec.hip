@@ -272,8 +272,12 @@ __device__ __forceinline__ void pfb_body(const PfbArgs& a) {
         // where this wave's next segment starts (clamped into the buffer: see above)
         const int bn = b + nwaves < nloop ? b + nwaves : b;
         const float2* __restrict__ pn = a.in + clamped(seg_start(bn)) + l;
+        // RD: ONE per-lane pointer (stream A) through the rounds; stream B's is rebuilt in each round from the wave-uniform distance between the two
+        // segments (two pointers held across the rounds cost the two-phase body its last two registers; bases in SGPRs with a 32-bit lane offset
+        // -- the other way to save them -- run 40 % slower: 95 against 67 us per 2^26 samples at decimation 8)
         const float* __restrict__ pnA = inr + clamped(seg_start(bn)) + l;
-        const float* __restrict__ pnB = inr + clamped(seg_start(RD ? segB_of(bn) : bn)) + l;
+        const long long dAB64 = clamped(seg_start(RD ? segB_of(bn) : bn)) - clamped(seg_start(bn));
+        unsigned dABlo = __builtin_amdgcn_readfirstlane((unsigned)dAB64), dABhi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)dAB64 >> 32));
         float2 vn[64];
         // ---- forward, column index a = 64 j + 8 q' + g', bin k = k0 + 8 kq + 64 kg ----------------------------
         // pass 1 over j (for every q'): A[k0][q'] at v[8 rev8(k0) + q']
@@ -302,10 +306,14 @@ __device__ __forceinline__ void pfb_body(const PfbArgs& a) {
 #pragma unroll
             for (int kq = 0; kq < 8; kq++) E[(kq * 8 + c) * kPfbRow + hi3] = v[8 * rev8(rho) + rev8(kq)];
             // the registers of row group rev8(rho) are free now: request the same rows of the next segment
+            if constexpr (RD) {
+                asm volatile("" : "+s"(dABlo), "+s"(dABhi));    // (opaque per round: pnA + distance is not hoisted into a second pointer)
+                const float* __restrict__ pnB = pnA + (long long)(((unsigned long long)dABhi << 32) | dABlo);
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                if constexpr (RD) vn[8 * rev8(rho) + q] = make_float2(pnA[64 * (8 * rev8(rho) + q)], pnB[64 * (8 * rev8(rho) + q)]);
-                else vn[8 * rev8(rho) + q] = load_stream(pn + 64 * (8 * rev8(rho) + q));
+                for (int q = 0; q < 8; q++) vn[8 * rev8(rho) + q] = make_float2(pnA[64 * (8 * rev8(rho) + q)], pnB[64 * (8 * rev8(rho) + q)]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; q++) vn[8 * rev8(rho) + q] = load_stream(pn + 64 * (8 * rev8(rho) + q));
             }
             __builtin_amdgcn_wave_barrier();
             // reader (c, mu = kq): row l holds the eight g' of bin prefix m = rho + 8 mu
@@ -417,8 +425,14 @@ __device__ __forceinline__ void pfb_body(const PfbArgs& a) {
                 const int off = PH * ap - phi;
                 const float2 y = z[rev8(b1)];
                 if (ap >= a.Q - 1) {
-                    if (off >= lo && off < hi) __builtin_nontemporal_store(y.x, orA + off);
-                    if (off >= loB && off < hiB) __builtin_nontemporal_store(y.y, orB + off);
+                    // (decimate by 4: the two phases interleave 4-byte pieces -- plain stores, which L2 merges; non-temporal ones do not combine)
+                    if constexpr (PH == 1) {
+                        if (off >= lo && off < hi) __builtin_nontemporal_store(y.x, orA + off);
+                        if (off >= loB && off < hiB) __builtin_nontemporal_store(y.y, orB + off);
+                    } else {
+                        if (off >= lo && off < hi) orA[off] = y.x;
+                        if (off >= loB && off < hiB) orB[off] = y.y;
+                    }
                 }
             }
         };
@@ -498,12 +512,13 @@ __device__ __forceinline__ void pfb_body(const PfbArgs& a) {
 template <bool ROT> __global__ __launch_bounds__(kPfbNT, 2) void pfb_dec8_kernel(const PfbArgs a) { pfb_body<ROT, 1>(a); }
 template <bool ROT> __global__ __launch_bounds__(2 * kPfbNT, 1) void pfb_dec4_kernel(const PfbArgs a) { pfb_body<ROT, 2>(a); }
 __global__ __launch_bounds__(kPfbNT, 2) void pfb_dec8_real_kernel(const PfbArgs a) { pfb_body<false, 1, true>(a); }
-// (decimate by 4 on real data: the two-phase body with two load pointers needs 258 VGPRs -- 2 spilled -- and is not instantiated)
+__global__ __launch_bounds__(2 * kPfbNT, 1) void pfb_dec4_real_kernel(const PfbArgs a) { pfb_body<false, 2, true>(a); }
 
 int launch_pfb_dec(const PfbArgs& a, hipStream_t stream) {
     if (a.real) {
-        if (a.rot || a.PH != 1) return -1;
-        hipLaunchKernelGGL(pfb_dec8_real_kernel, dim3(a.nwg + 1), dim3(kPfbNT), 0, stream, a);
+        if (a.rot) return -1;
+        if (a.PH == 2) hipLaunchKernelGGL(pfb_dec4_real_kernel, dim3(a.nwg + 1), dim3(2 * kPfbNT), 0, stream, a);
+        else hipLaunchKernelGGL(pfb_dec8_real_kernel, dim3(a.nwg + 1), dim3(kPfbNT), 0, stream, a);
         const hipError_t e = hipGetLastError();
         return e == hipSuccess ? 0 : -(int)e;
     }

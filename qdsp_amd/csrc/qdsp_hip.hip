@@ -1240,8 +1240,8 @@ int launch_xlate_inc(Engine* e, const void* d_in, int64_t count, void* d_out, un
 inline int pfb_phases(const Engine* e) { return e->M == 4 ? 2 : 1; }
 inline int pfb_Q(const Engine* e) { return (e->ntaps + e->M * (pfb_phases(e) - 1) + qk::kPfbD - 1) / qk::kPfbD; }
 bool pfb_eligible(const Engine* e, int64_t count) {
-    // (ch == 1, round 4: PolyphaseResampler<float> at decimation 8 -- pfb_dec8_real_kernel, two real segments per set of transforms)
-    const bool real8 = e->ch == 1 && !e->rotate && e->M == qk::kPfbD && e->kind == KIND_DECIM;
+    // (ch == 1, round 4: PolyphaseResampler<float> at decimation 8 / 4 -- pfb_dec8_real_kernel / pfb_dec4_real_kernel, two real segments per set of transforms)
+    const bool real8 = e->ch == 1 && !e->rotate && (e->M == qk::kPfbD || e->M == 4) && e->kind == KIND_DECIM;
     if ((e->ch != 2 && !real8) || e->L != 1 || (e->M != qk::kPfbD && e->M != 4) || e->ntaps < 2) return false;
     if (e->kind != KIND_DECIM && e->kind != KIND_VFO) return false;
     if (pfb_Q(e) > qk::kPfbMaxQ) return false;
@@ -1430,7 +1430,7 @@ int launch_pfb(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
     rc = qk::launch_pfb_dec(a, s);
     if (rc) return rc;
     e->raw_valid = e->rotate && e->H > 0;   // (the caller flips cur: the raw hand-over then sits at d_hist_raw[cur])
-    e->last.name = a.real ? "pfb_dec8_real_kernel" : a.PH == 2 ? "pfb_dec4_kernel" : "pfb_dec8_kernel";
+    e->last.name = a.real ? (a.PH == 2 ? "pfb_dec4_real_kernel" : "pfb_dec8_real_kernel") : a.PH == 2 ? "pfb_dec4_kernel" : "pfb_dec8_kernel";
     e->last.grid = nwg + 1;
     e->last.block = qk::kPfbNT * a.PH;
     e->last.lds = (int)((qk::kPfbTableElems + (a.PH - 1) * qk::kPfbG1Elems + wpw * 64 * qk::kPfbRow + (a.PH - 1) * wpw * 64 * 9) * sizeof(float2));

@@ -30,7 +30,7 @@ _NOT_DISPATCH = ("QDSP_HIP_LIB", "QDSP_HIP_NO_AUTOBUILD", "QDSP_HIP_DEVICE")
 def _no_overrides():
     return not any(k.startswith("QDSP_HIP_") and k not in _NOT_DISPATCH for k in os.environ)
 
-FAMILIES = {"fir_core_kernel", "fir_lat_kernel", "fir_fft1k_kernel", "fir_fft_dma_kernel", "pfb_dec8_kernel", "pfb_dec8_real_kernel", "pfb_dec4_kernel", "decim_win_kernel",
+FAMILIES = {"fir_core_kernel", "fir_lat_kernel", "fir_fft1k_kernel", "fir_fft_dma_kernel", "pfb_dec8_kernel", "pfb_dec8_real_kernel", "pfb_dec4_kernel", "pfb_dec4_real_kernel", "decim_win_kernel",
             "decim_mfma_kernel", "decim_mfma_real_kernel", "decim_mfma_batch_kernel", "resamp_lm_kernel", "resamp_mfma_kernel", "resamp_mfma_real_kernel", "resamp_any_kernel",
             "resamp_any_batch_kernel", "chan_uniform_kernel"}
 
@@ -129,6 +129,7 @@ REAL_DIRECTED = [
     (1, 64, [(1_000_000, "fir_core_kernel"), ((1 << 22) + 1, "fir_core_kernel")]),             # (table: direct form ahead of the one-wave overlap-save form at 64 taps)
     (16, 200, [(1_000_000, "decim_mfma_real_kernel"), ((1 << 22) + 16, "decim_win_kernel")]),  # (round 4: the MFMA decimator on float rows; the table hands this 2^22 cell to the window kernel)
     (8, 128, [(1_000_000, "decim_win_kernel"), (1 << 26, "pfb_dec8_real_kernel")]),            # (round 4: two real segments per set of polyphase transforms on chip-filling calls)
+    (4, 256, [(1 << 26, "pfb_dec4_real_kernel")]),
 ]
 
 

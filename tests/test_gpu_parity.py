@@ -400,35 +400,36 @@ def test_decimate_by_two_both_overlap_save_forms(ops, monkeypatch, ntaps, rot):
 
 
 @pytest.mark.parametrize("ntaps", [2, 17, 64, 255, 256, 257, 700, 1009, 1024])
-def test_polyphase_overlap_save_decimator_real_data(ops, monkeypatch, ntaps):
-    """pfb_dec8_real_kernel (round 4): PolyphaseResampler<float> at decimation 8 -- TWO segments of the real stream ride one set of complex
-    transforms as re / im (pair p = segments p and p + ceil(nseg / 2)).  Ragged calls: an odd and an even number of segments, a call of exactly
+@pytest.mark.parametrize("dec", [8, 4])
+def test_polyphase_overlap_save_decimator_real_data(ops, monkeypatch, ntaps, dec):
+    """pfb_dec8_real_kernel / pfb_dec4_real_kernel (round 4): PolyphaseResampler<float> at decimation 8 / 4 -- TWO segments of the real stream ride
+    one set of complex transforms as re / im (pair p = segments p and p + ceil(nseg / 2)).  Ragged calls: an odd and an even number of segments, a call of exactly
     one segment (its partner repeats it and stores nothing), pairs whose members read the history / are zero-filled at the end, a call below
     one segment (another kernel), the history handed on; against the FP64 oracle and against the 4096-point kernel on the same stream."""
     import torch
 
     monkeypatch.setenv("QDSP_HIP_PFB_MIN_COUNT", "0")
-    taps = O.lowpass_taps_f64(ntaps, 0.5 / 8).astype(np.float32) if ntaps > 8 else np.arange(1, ntaps + 1, dtype=np.float32)
+    taps = O.lowpass_taps_f64(ntaps, 0.5 / dec).astype(np.float32) if ntaps > 8 else np.arange(1, ntaps + 1, dtype=np.float32)
     x = np.ascontiguousarray(O.synth_iq(0, 500_000, seed=900 + ntaps).real)
-    cuts = [0, 8 * 13001, 8 * 13001 + 8 * 9, 8 * 13010 + 4096, 8 * 30000 + 3, 8 * 30000 + 8 * 481 * 2 + 3, 500_000]
-    op = ops.Resampler(taps, 1, 8, complex_data=False, max_block=0)
+    cuts = [0, 8 * 13001, 8 * 13001 + 8 * 9, 8 * 13010 + 4096, 8 * 30000 + 4, 8 * 30000 + 8 * 481 * 2 + 4, 500_000]
+    op = ops.Resampler(taps, 1, dec, complex_data=False, max_block=0)
     op.set_mode(op.FFT)
     ys = []
     for a, b in zip(cuts, cuts[1:]):
         ys.append(op.process(dev(x[a:b])).cpu().numpy())
-        assert (kname(op) == "pfb_dec8_real_kernel") == (b - a >= 4096), (a, b, op.last_kernel())
+        assert (kname(op) == f"pfb_dec{dec}_real_kernel") == (b - a >= 4096), (a, b, op.last_kernel())
     torch.cuda.synchronize()
     y = np.concatenate(ys)
-    rs = O.Resampler(taps, 1, 8, complex_data=False, acc=O.ACC_F64)
+    rs = O.Resampler(taps, 1, dec, complex_data=False, acc=O.ACC_F64)
     want = np.concatenate([rs.process(x[a:b]) for a, b in zip(cuts, cuts[1:])])
     assert y.dtype == np.float32 and len(y) == len(want) and rel_rms(y, want) < 1e-6
     assert np.abs(y - want).max() < 4e-6 * np.abs(want).max()
     assert np.array_equal(op.get_history(), x[len(x) - ntaps:])
     monkeypatch.setenv("QDSP_HIP_NO_PFB", "1")
-    op2 = ops.Resampler(taps, 1, 8, complex_data=False, max_block=0)
+    op2 = ops.Resampler(taps, 1, dec, complex_data=False, max_block=0)
     op2.set_mode(op2.FFT)
     y2 = np.concatenate([op2.process(dev(x[a:b])).cpu().numpy() for a, b in zip(cuts, cuts[1:])])
-    assert kname(op2) != "pfb_dec8_real_kernel" and rel_rms(y, y2) < 2e-6
+    assert "pfb_dec" not in kname(op2) and rel_rms(y, y2) < 2e-6
 
 
 def test_polyphase_overlap_save_decimator_switches_forms_mid_stream(ops, gold, monkeypatch):
