@@ -75,6 +75,12 @@ WORKLOADS = {
     "chan64": dict(ntaps=256, decim=64, rot=True, bytes=16.0, flops=1408.0, nchan=64),
     # its oversampled variant (SURVEY 8d config 5 "and M = 8"): 8 B in + 64*8/8 B out per input sample
     "chan64m8": dict(ntaps=256, decim=8, rot=True, bytes=72.0, flops=16384.0, nchan=64),
+    # REAL data (FIR<float>, PolyphaseResampler<float>: SURVEY 8f rank 3), single GPU only: 4 B in + 4 L / M B out per sample.  Round 4.
+    "fir256_real": dict(ntaps=256, decim=1, rot=False, bytes=8.0, flops=512.0, real=True),
+    "decim8_real": dict(ntaps=256, decim=8, rot=False, bytes=4.5, flops=64.0, real=True),
+    "decim4_real": dict(ntaps=256, decim=4, rot=False, bytes=5.0, flops=128.0, real=True),
+    "decim50_real": dict(ntaps=401, decim=50, rot=False, bytes=4.08, flops=16.0, real=True, fc=0.4 / 50),
+    "resamp147_160_real": dict(ntaps=147 * 16 - 3, decim=160, interp=147, rot=False, bytes=4.0 + 4.0 * 147 / 160, flops=2 * 16 * 147 / 160, real=True, fc=0.4 / 160),
 }
 
 
@@ -110,9 +116,10 @@ def make_op(ops, name: str, device: int):
         taps = (taps * L).astype(taps.dtype)       # unit pass-band gain after the zero-stuffing
     if w["rot"]:
         return ops.Vfo(taps, L, w["decim"], ops.phase_delta(1.0, 0.1234), device=device, max_block=0)
+    cplx = not w.get("real", False)
     if w["decim"] > 1 or L > 1:
-        return ops.Resampler(taps, L, w["decim"], device=device, max_block=0)
-    return ops.Fir(taps, device=device, max_block=0)
+        return ops.Resampler(taps, L, w["decim"], complex_data=cplx, device=device, max_block=0)
+    return ops.Fir(taps, complex_data=cplx, device=device, max_block=0)
 
 
 def _cpu_model() -> str:
@@ -258,6 +265,11 @@ WORKLOAD_TEXT = {
     "resamp147_160": "rational resampler 147/160 (48 kHz -> 44.1 kHz), 16 taps per phase",
     "chan64": "64-channel polyphase channelizer, 256 taps, decimate 64 (BASELINE configs[4])",
     "chan64m8": "64-channel polyphase channelizer oversampled by 8: 256 taps, decimate 8 (BASELINE configs[4], M = 8 variant)",
+    "fir256_real": "256-tap FIR<float> on real samples",
+    "decim8_real": "256-tap polyphase decimate-by-8 on real samples",
+    "decim4_real": "256-tap polyphase decimate-by-4 on real samples",
+    "decim50_real": "401-tap polyphase decimate-by-50 on real samples",
+    "resamp147_160_real": "rational resampler 147/160 on real samples, 16 taps per phase",
 }
 
 
@@ -355,11 +367,16 @@ def run_workload(name: str, args, ctx) -> dict:
     # [(s*world + r)*n, +n).  The synthetic block content repeats every step (same buffer), the halo hand-off is
     # the real one: every step each rank's tail goes to its ring successor over RCCL, prefetched under the kernel.
     x = ops.synth_iq(n, first_sample=rank * n, seed=1234, device=local_rank)
+    is_real = w.get("real", False)
+    if is_real:
+        if world > 1 or self_ring:
+            raise SystemExit(f"workload {name}: the real-data workloads run on one GPU (the ring halo carries complex samples)")
+        x = torch.view_as_real(x)[:, 0].contiguous()          # the real parts: uniform [-1, 1)
     nout = n // w["decim"] * w.get("interp", 1)
     # channel rows 32 samples (256 bytes) longer than the data: with a power-of-two row stride (2^24 samples at M = 8) the 64 lines a
     # tile writes -- one per channel -- fall on the same memory channel (chan64m8: 2.85 ms, 2.46 with the pad; EXPERIMENTS.md section 4).  The
     # stride is the caller's to choose (qdsp_hip_chan_cf32_process_dev's out_stride argument); reported in config.out_row_stride.
-    out = torch.empty((w["nchan"], nout + CHAN_ROW_PAD) if is_chan else nout, dtype=torch.complex64, device=dev)
+    out = torch.empty((w["nchan"], nout + CHAN_ROW_PAD) if is_chan else nout, dtype=torch.float32 if is_real else torch.complex64, device=dev)
     ring = RingStream(op, n, rank, world, transport="host" if rehearse else "device", align=align,
                       exchange=(world > 1 or self_ring), ctrl_group=ctrl,
                       prefetch=os.environ.get("QDSP_BENCH_NO_PREFETCH", "0") != "1")
@@ -575,8 +592,11 @@ def block_call(name: str, ctx) -> dict:
     n -= n % (w["decim"] if w.get("interp", 1) > 1 else 1)
     op = make_op(ops, name, ctx["local_rank"])
     x = ops.synth_iq(n, seed=4321, device=ctx["local_rank"])
+    if w.get("real", False):
+        x = torch.view_as_real(x)[:, 0].contiguous()
     nout = n // w["decim"] * w.get("interp", 1)
-    out = torch.empty((w["nchan"], nout + CHAN_ROW_PAD) if name in ("chan64", "chan64m8") else nout + 8, dtype=torch.complex64, device=ctx["dev"])
+    out = torch.empty((w["nchan"], nout + CHAN_ROW_PAD) if name in ("chan64", "chan64m8") else nout + 8,
+                      dtype=torch.float32 if w.get("real", False) else torch.complex64, device=ctx["dev"])
     op.process(x, out)
     torch.cuda.synchronize()
     ms = min(op.time_dev(x, out, 200) for _ in range(3))
