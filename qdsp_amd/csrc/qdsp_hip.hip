@@ -290,9 +290,9 @@ int upload_taps(Engine* e, const float* taps, int ntaps) {
         }
     }
     // (ch == 1, round 4: PolyphaseResampler<float> -- resamp_mfma_real_kernel, the same plan on float tiles.  Against the real-data forms of the other
-    // kernels -- scripts sweep kept in profiles/r04_real_rational.txt -- it needs 14 taps per phase except on the decimating side of the small ratios:
-    // 33/32 and 100/99 at 8-12 taps per phase are 1.1-1.45x slower on it, 3/8 and 5/8 1.6-2.6x faster at every tap count)
-    if (e->ch == 1 && rm_wanted && e->P < 14 && !(e->L <= 10 && e->L < e->M && e->M >= 5)) rm_wanted = false;
+    // kernels -- scripts/sweep_real_rational.py forced, profiles/r04_real_rational.txt -- it wins on chip-filling calls at every tap count (147/160 with
+    // 8 / 12 taps per phase: x 0.63 / 0.54 of their time) but for 33/32 below 14 taps per phase (x 1.05-1.10); small calls: rm_min_count)
+    if (e->ch == 1 && rm_wanted && e->P < 14 && e->L >= 33 && e->L < 48) rm_wanted = false;
     if ((e->ch == 2 || (e->ch == 1 && !e->rotate)) && rm_wanted && e->has_filter && e->kind != KIND_FIR && !use_core(e) && e->M < (1 << 16)) {
         const int L0 = e->L, M0 = e->M, P = e->P;
         for (int J = 1; J <= 64 && !e->rm_ngrp; J++) {
@@ -1805,10 +1805,10 @@ int64_t rm_min_count(const Engine* e) {
     // the OUTPUT count -- only from ~10 million inputs: 8/3 at 6.3 million x 1.2, at 12.6 million x 0.9)
     int64_t base = e->rm_big_only ? (e->L > e->M ? 12 << 20 : 1 << 22) : (e->L >= 33 ? 6 << 20 : 0);
     if (e->ch == 1) {
-        // real data (profiles/r04_real_rational.txt): the interpolating small ratios and pure interpolators only pay from 2^25 samples on (6/1 at 2^20:
-        // 2-3.4x slower than the general kernel, at 2^23 1.1-1.25x, at 2^26 0.71-0.97x; 10/7 likewise); the decimating ones at every size up to 19
-        // taps per phase, from 2^22 samples beyond that (3/8 with 20 taps per phase at 2^20: 1.38x)
-        if (e->L > e->M && e->L < 33 && base < (1 << 25)) base = 1 << 25;
+        // real data (profiles/r04_real_rational.txt): interpolating ratios only pay from 2^25 samples on (6/1 at 2^20: 2-3.3x slower than the general
+        // kernel, at 2^23 1.07-1.23x, at 2^26 0.53-0.74x; 48/5 at 2^23 1.09-1.33x; 160/147 level at 2^23); the decimating ones at every size up
+        // to 19 taps per phase, from 2^22 samples beyond that (3/8 with 20 taps per phase at 2^20: 1.31x)
+        if (e->L > e->M && base < (1 << 25)) base = 1 << 25;
         if (e->L < e->M && e->P >= 20 && base < (1 << 22)) base = 1 << 22;
     }
     return base;

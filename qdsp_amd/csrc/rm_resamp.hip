@@ -175,9 +175,14 @@ template <bool ROT, bool RD> __device__ __forceinline__ void resamp_mfma_body(co
                     if (o < L && n < a.nout) {
                         S* dst = out_s + n;
                         if constexpr (RD) {
+                            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));      // (the block starts on any sample: 4-byte aligned)
+                            if (o + 3 < L && n + 3 < a.nout) {
+                                *reinterpret_cast<f4u*>(dst) = (f4u){zr[0], zr[1], zr[2], zr[3]};
+                            } else {
 #pragma unroll
-                            for (int v = 0; v < 4; v++)
-                                if (o + v < L && n + v < a.nout) dst[v] = zr[v];
+                                for (int v = 0; v < 4; v++)
+                                    if (o + v < L && n + v < a.nout) dst[v] = zr[v];
+                            }
                         } else if (o + 3 < L && n + 3 < a.nout) {
                             // (round 3: the lane's 32 contiguous bytes as two 16-byte stores at 8-byte alignment -- odd L puts odd periods on
                             // odd samples -- measured 0.451 against 0.442 ms for these four 8-byte ones on 147/160: not kept)

@@ -1364,7 +1364,7 @@ def test_rational_mfma_resampler(ops, L, M, tpp, forced, monkeypatch):
     gv, wv = np.concatenate(gv), np.concatenate(wv)
     assert gv.shape == wv.shape and rel_rms(gv, wv) < 1e-6, (L, M)
     # real data (PolyphaseResampler<float>, src/dsp/resampling.h:113-118): resamp_mfma_real_kernel, the same plan on float tiles (round 4) --
-    # from 14 taps per phase on, at every tap count on the decimating side of the small ratios (the real-data rules of the rm plan, qdsp_hip.hip)
+    # at every tap count but for 33/32-like ratios below 14 taps per phase (the real-data rule of the rm plan, qdsp_hip.hip)
     xr = np.ascontiguousarray(x.real)
     rr = ops.Resampler(taps, L, M, complex_data=False, max_block=0)
     gr = np.concatenate([rr.process(dev(xr[a:b])).cpu().numpy() for a, b in zip(cuts, cuts[1:])])
@@ -1372,7 +1372,7 @@ def test_rational_mfma_resampler(ops, L, M, tpp, forced, monkeypatch):
     wr = np.concatenate([ro.process(xr[a:b]) for a, b in zip(cuts, cuts[1:])])
     assert gr.dtype == np.float32 and gr.shape == wr.shape and rel_rms(gr, wr) < 1e-6, (L, M)
     P = -(-ntaps // L)
-    if P >= 14 or (L <= 10 and L < M and M >= 5):
+    if not (P < 14 and 33 <= L < 48):
         assert kname(rr) == "resamp_mfma_real_kernel", (L, M, P, rr.last_kernel())
     # the general direct kernel on the same plan agrees
     monkeypatch.setenv("QDSP_HIP_NO_RM", "1")
