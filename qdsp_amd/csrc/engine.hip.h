@@ -218,7 +218,7 @@ int launch_pfb(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d
 int launch_fft(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d_out, hipStream_t s);
 int launch_xlate_raw(Engine* e, const void* d_in, int64_t count, void* d_out, unsigned long long phase0, float gm1, hipStream_t s);
 int launch_xlate(Engine* e, const void* d_in, int64_t count, void* d_out, hipStream_t s);
-void mf_tasks(qk::MfArgs& a, int64_t nout, int nchan, bool rot);
+void mf_tasks(qk::MfArgs& a, int64_t nout, int nchan, bool rot, bool real = false);
 void mf_rot_tables(unsigned long long dphase, int M, int KJ, double2* step, float2* rot_k);
 bool fir_lat_eligible(const Engine* e, int64_t count);
 int launch_fir_lat(Engine* e, const void* d_in, int64_t count, void* d_out, hipStream_t s);

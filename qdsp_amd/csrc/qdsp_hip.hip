@@ -1591,10 +1591,12 @@ int launch_xlate_inc(Engine* e, const void* d_in, int64_t count, void* d_out, un
 
 // outputs per wave task: a task reads one tile of 16 rows beyond its own (T = 256: 6 %); small calls take shorter
 // tasks so that a reference-sized block still spreads over the chip (1e6 samples at decimation 50: 20 000 outputs)
-void mf_tasks(qk::MfArgs& a, int64_t nout, int nchan, bool rot) {
+void mf_tasks(qk::MfArgs& a, int64_t nout, int nchan, bool rot, bool real) {
     long long T = nout * nchan / 2048;      // (one round of the chip: 3072 wave slots; 8192 left a 4M-sample call at T = 16 -- half of every task's reads its neighbour's -- and 18 us instead of 14)
     T = (T + 15) / 16 * 16;
-    const long long tmax = qk::knob(qk::K_MF_TASK_MAX, rot ? 256 : 128);
+    // (real data, round 4: 256 outputs per task on chip-filling calls -- decimate-by-50 0.118 -> 0.110 ms per 2^27 samples, by-200 -10 %, by-32 +1 %;
+    // at 2^23 samples 128 keeps twice the tasks and decimate-by-16 a third quicker)
+    const long long tmax = qk::knob(qk::K_MF_TASK_MAX, (rot || (real && a.count >= (1LL << 26))) ? 256 : 128);
     if (T > tmax) T = tmax;
     if (T < 16) T = 16;
     a.T = (int)T;
@@ -1715,7 +1717,7 @@ int launch_mf(Engine* e, const void* d_in, int64_t count, int64_t nout, void* d_
     // the kernel's unguarded loads of an interior tile read 64 (2 KJ - 2) samples from the tile's start: they must lie inside the tile's own 16 M
     // (true for KJ = ceil(M / 8); a plan that pads KJ beyond that would read past the end of the input -- found the hard way, round 4)
     if (128 * (e->mf_KJ - 1) > 16 * a.M) return QDSP_HIP_EINVAL;
-    mf_tasks(a, a.nout, 1, e->rotate);
+    mf_tasks(a, a.nout, 1, e->rotate, e->ch == 1);
     if (e->rotate) {
         a.phase0 = e->phase;
         a.dphase = e->dphase;

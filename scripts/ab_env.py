@@ -43,10 +43,12 @@ def main():
     if w.get("interp", 1) > 1:
         n -= n % w["decim"]
     x = ops.synth_iq(n, seed=1234)
+    if w.get("real", False):
+        x = torch.view_as_real(x)[:, 0].contiguous()
     if a.zeros:
         x.zero_()
     nout = n // w["decim"] * w.get("interp", 1)
-    out = torch.empty((w["nchan"], nout + bench.CHAN_ROW_PAD) if "nchan" in w else nout + 8, dtype=torch.complex64, device="cuda")
+    out = torch.empty((w["nchan"], nout + bench.CHAN_ROW_PAD) if "nchan" in w else nout + 8, dtype=torch.float32 if w.get("real", False) else torch.complex64, device="cuda")
     op = bench.make_op(ops, a.workload, 0)
     apply(a.settings[0], names)
     for _ in range(5):   # settle the clocks
