@@ -317,11 +317,34 @@ int upload_taps(Engine* e, const float* taps, int ntaps) {
             if (used < 0.6) continue;                  // (more merged periods may fill the steps better)
             int pitch = M + ext;
             pitch += (pitch & 1) ^ 1;                  // odd: the four periods of a quad start on different banks
+            if (e->ch == 1) {
+                // Real data: the B operand of a step is one ds_read_b32 per lane -- 32-lane groups, bank = sample index mod 32 -- from sample
+                // (period l % 4) * pitch + c0[block l / 4] + k.  PMC of resamp_mfma_real_kernel at the odd pitch: LDS 70 % busy, a third of it bank
+                // conflicts (profiles/r04_pmc_resamp_mfma_real.json).  Of the 32 pitches from M + ext on, take the one whose lane groups meet the
+                // fewest busy banks (the float tiles are half the size of the complex ones: the longer rows cost nothing that matters).
+                int best_cost = 1 << 30;
+                for (int cand = M + ext; cand < M + ext + 32; cand++) {
+                    int cost = 0;
+                    for (int g = 0; g < ngrp; g++)
+                        for (int half = 0; half < 2; half++) {
+                            int busy[32] = {0}, worst = 0;
+                            for (int l = 32 * half; l < 32 * half + 32; l++) {
+                                const int slot = l / 4;
+                                const int b = ngrp > 1 || qpb == 1 ? 16 * g + slot : slot % nblk;
+                                const int pq = ngrp > 1 || qpb == 1 ? 0 : slot / nblk;
+                                const int sidx = ((4 * pq + l % 4) * cand + (b < nblk ? c0[b] : 0)) & 31;
+                                if (++busy[sidx] > worst) worst = busy[sidx];
+                            }
+                            cost += worst;
+                        }
+                    if (cost < best_cost) { best_cost = cost; pitch = cand; }
+                }
+            }
             // period quads per tile: as many as the register prefetch (kRmNE samples per lane) holds, a multiple of qpb
             int G = (64 * qk::kRmNE - ext) / (4 * M);
             if (G > 16) G = 16;
             G -= G % qpb;
-            if (G < 1 || qk::rm_lds_bytes(ngrp, KB, G, pitch) > 64 * 1024) continue;
+            if (G < 1 || qk::rm_lds_bytes(ngrp, KB, G, pitch, e->ch == 1) > 64 * 1024) continue;
             std::vector<float> tab((size_t)ngrp * KB * 64 + (size_t)2 * ngrp * 64, 0.0f);
             int* cbl = reinterpret_cast<int*>(tab.data() + (size_t)ngrp * KB * 64);
             int* meta = cbl + (size_t)ngrp * 64;
