@@ -317,7 +317,7 @@ int upload_taps(Engine* e, const float* taps, int ntaps) {
             if (used < 0.6) continue;                  // (more merged periods may fill the steps better)
             int pitch = M + ext;
             pitch += (pitch & 1) ^ 1;                  // odd: the four periods of a quad start on different banks
-            if (e->ch == 1) {
+            if (e->ch == 1) {      // (complex data: the same search changes nothing -- 0.4155 / 0.4378 / 0.4394 against 0.4139 / 0.4415 / 0.4431 ms, alternated)
                 // Real data: the B operand of a step is one ds_read_b32 per lane -- 32-lane groups, bank = sample index mod 32 -- from sample
                 // (period l % 4) * pitch + c0[block l / 4] + k.  PMC of resamp_mfma_real_kernel at the odd pitch: LDS 70 % busy, a third of it bank
                 // conflicts (profiles/r04_pmc_resamp_mfma_real.json).  Of the 32 pitches from M + ext on, take the one whose lane groups meet the
